@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def alley():
+    z = np.load(os.path.join(GOLDEN, "alley_1_gray.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def alley_golden_flow():
+    return np.load(os.path.join(GOLDEN, "alley_0001_flo.npz"))["flow"]
+
+
+def load_fdf(noc):
+    z = np.load(os.path.join(GOLDEN, "fdf_ref_%s.npz" % ("gray" if noc == 1 else "rgb")))
+    cases = {}
+    for k in z.files:
+        name, key = k.split("/")
+        cases.setdefault(name, {})[key] = z[k]
+    return cases
+
+
+def synth_pair(h, w, seed=1234, noc=1, shift=(5.0, 2.0), truth=False):
+    """Seeded synthetic frame pair: band-limited 8-bit texture, frame1 = frame0 warped by a
+    smooth known flow.  Same generator on the CPU (oracle) and GPU sides."""
+    rng = np.random.default_rng(seed)
+    img = np.zeros((h, w, noc), np.float64)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    for o, g in enumerate((8, 16, 32, 64, 128, 256)):
+        gh, gw = max(2, h * g // max(h, w) + 2), g + 2
+        n = rng.uniform(-1, 1, (gh, gw, noc))
+        fy, fx = yy * (gh - 1.001) / h, xx * (gw - 1.001) / w
+        y0, x0 = fy.astype(int), fx.astype(int)
+        ay, ax = (fy - y0)[..., None], (fx - x0)[..., None]
+        v = (n[y0, x0] * (1 - ay) * (1 - ax) + n[y0, x0 + 1] * (1 - ay) * ax +
+             n[y0 + 1, x0] * ay * (1 - ax) + n[y0 + 1, x0 + 1] * ay * ax)
+        img += v / (o + 1)
+    img = (img - img.min()) / (img.max() - img.min()) * 255.0
+    f0 = np.round(img).astype(np.float32)
+    u = shift[0] + 2.0 * np.sin(yy / h * 3.0) * np.cos(xx / w * 2.0)
+    v = shift[1] + 2.0 * np.cos(yy / h * 2.0 + 1.0) * np.sin(xx / w * 3.0)
+    sx, sy = np.clip(xx - u, 0, w - 1.001), np.clip(yy - v, 0, h - 1.001)
+    x0, y0 = sx.astype(int), sy.astype(int)
+    ax, ay = (sx - x0)[..., None], (sy - y0)[..., None]
+    f1 = (f0[y0, x0] * (1 - ay) * (1 - ax) + f0[y0, x0 + 1] * (1 - ay) * ax +
+          f0[y0 + 1, x0] * ay * (1 - ax) + f0[y0 + 1, x0 + 1] * ay * ax)
+    f1 = np.round(f1).astype(np.float32)
+    if noc == 1:
+        f0, f1 = f0[..., 0], f1[..., 0]
+    if truth:
+        return f0, f1, np.stack([u, v], -1).astype(np.float32)
+    return f0, f1

@@ -1,0 +1,122 @@
+"""CPU tests of the oracle itself: pinned against (1) the reference's golden .flo, (2) golden vectors
+produced by the reference's own FDF code (tests/golden/fdf_ref_*.npz), (3) oracle/_ref live when present."""
+import numpy as np
+import pytest
+
+from conftest import load_fdf, synth_pair
+from oracle import oracle as O
+from oracle import fdf_ref as R
+
+
+def epe(a, b):
+    return np.sqrt(((a - b) ** 2).sum(-1))
+
+
+def test_op_points():
+    # kroeger/run_dense.cpp:225-268; SURVEY.md section 8 table
+    p = O.op_point(2, 1024)
+    assert (p.sc_f, p.sc_l, p.ps, p.max_iter, p.usetvref) == (5, 3, 8, 12, 1)
+    p = O.op_point(2, 1920)
+    assert (p.sc_f, p.sc_l) == (6, 4)
+    p = O.op_point(4, 3840)
+    assert (p.sc_f, p.sc_l, p.ps, p.max_iter) == (7, 2, 12, 128)
+    p = O.op_point(1, 1024)
+    assert (p.usetvref, p.max_iter) == (0, 16)
+    assert O.padded_size(1920, 1080, 6) == (1920, 1088, 0, 8)
+    assert O.padded_size(1024, 436, 5) == (1024, 448, 0, 12)
+
+
+def test_grid_geometry():
+    # patch counts SURVEY.md section 8: 1080p op-2 -> 40/135/510, Sintel -> 32/112/448
+    p = O.op_point(2, 1920)
+    for (w, h), n in (((30, 17), 40), ((60, 34), 135), ((120, 68), 510)):
+        g = O.Grid(w, h, 4, p)
+        assert g.nop == n and g.steps == 4
+    p = O.op_point(4, 3840)
+    g = O.Grid(960, 544, 2, p)
+    assert g.nop == 58240 and g.steps == 3
+
+
+def test_golden_flo(alley, alley_golden_flow):
+    """the reference's only golden result: kroeger/flows/alley_0001.flo (run_OF_INT, op-pt 2).
+    The survey's build of the unmodified kroeger sources reproduces it to mean 0.026 / p99 0.17 /
+    max 0.50 px; the oracle must land in the same place."""
+    fl = O.full_flow(alley["frame_0001"].astype(np.float32), alley["frame_0002"].astype(np.float32), op=2)
+    e = epe(fl, alley_golden_flow)
+    assert fl.shape == alley_golden_flow.shape == (436, 1024, 2)
+    assert e.mean() < 0.03 and np.percentile(e, 99) < 0.2 and e.max() < 0.6
+
+
+@pytest.mark.parametrize("noc", [1, 3])
+def test_fdf_golden_vectors(noc):
+    """oracle FDF restatement == outputs of the reference's own FDF1.0.1 C code, bit for bit"""
+    L = O.lib()
+    f = np.float32
+    for name, c in load_fdf(noc).items():
+        im1, im2, wx, wy, lvl = c["im1"], c["im2"], c["wx"], c["wy"], int(c["lvl"])
+        _, h, w = im1.shape
+        st = L.dis_stride(w)
+
+        def pl(a):          # (h,w) or (noc,h,w) -> stride-padded planar
+            a = a.reshape(-1, h, w)
+            o = np.zeros((a.shape[0], h, st), f)
+            o[:, :, :w] = a
+            return o
+        I1, I2, WX, WY = pl(im1), pl(im2), pl(wx), pl(wy)
+        w2, mask = np.zeros_like(I1), np.zeros((1, h, st), f)
+        L.dis_image_warp(O.P(w2), O.P(mask), O.P(I2), O.P(WX), O.P(WY), w, h, noc)
+        assert np.array_equal(w2[:, :, :w], c["w2"]) and np.array_equal(mask[0, :, :w], c["mask"])
+        D = {k: np.zeros_like(I1) for k in ("Ix", "Iy", "Iz", "Ixx", "Ixy", "Iyy", "Ixz", "Iyz")}
+        L.dis_get_derivatives(O.P(I1), O.P(w2), w, h, noc, *[O.P(D[k]) for k in ("Ix", "Iy", "Iz", "Ixx", "Ixy", "Iyy", "Ixz", "Iyz")])
+        for k in D:
+            assert np.array_equal(D[k][:, :, :w], c[k]), (name, k)
+        # whole chain through dis_varref on a padded level image
+        ps = 8
+        p = O.op_point(2, 1024, noc)
+
+        def padlvl(a):
+            return np.pad(a.transpose(1, 2, 0), ((ps, ps), (ps, ps), (0, 0)), mode="edge")
+        fl = np.stack([wx, wy], -1)
+        out = O.varref(padlvl(im1), padlvl(im2), w, h, lvl, p, fl)
+        assert np.array_equal(out[..., 0], c["out_x"]) and np.array_equal(out[..., 1], c["out_y"]), name
+
+
+@pytest.mark.skipif(not R.available(1), reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("noc,w,h", [(1, 30, 17), (1, 37, 19), (3, 33, 18), (1, 120, 68)])
+def test_varref_vs_live_reference(noc, w, h):
+    """random smooth inputs through the live reference FDF library vs the oracle, incl. widths that are
+    not multiples of 4 (stride padding) -- bit-exact"""
+    rng = np.random.default_rng(w * 100 + h)
+    f0, f1 = synth_pair(h, w, seed=w, noc=noc, shift=(0.7, -0.4))
+    im1 = f0.reshape(h, w, noc).transpose(2, 0, 1).copy()
+    im2 = f1.reshape(h, w, noc).transpose(2, 0, 1).copy()
+    wx = (0.7 + 0.3 * rng.standard_normal((h, w))).astype(np.float32)
+    wy = (-0.4 + 0.3 * rng.standard_normal((h, w))).astype(np.float32)
+    ox, oy = R.FdfRef(noc).ref_level_of(im1, im2, wx, wy, 3)
+    p = O.op_point(2, 1024, noc)
+    ps = 8
+    padlvl = lambda a: np.pad(a.transpose(1, 2, 0), ((ps, ps), (ps, ps), (0, 0)), mode="edge")
+    out = O.varref(padlvl(im1), padlvl(im2), w, h, 3, p, np.stack([wx, wy], -1))
+    assert np.array_equal(out[..., 0], ox) and np.array_equal(out[..., 1], oy)
+
+
+def test_synthetic_flow_recovers_shift():
+    f0, f1, gt = synth_pair(272, 480, seed=5, truth=True)
+    fl = O.full_flow(f0, f1, op=2)
+    assert np.median(epe(fl, gt)) < 0.5
+
+
+def test_redblack_is_not_reference(alley):
+    a, b = alley["frame_0001"].astype(np.float32), alley["frame_0002"].astype(np.float32)
+    e = epe(O.full_flow(a, b, op=2), O.full_flow(a, b, op=2, sor_mode=1))
+    assert 0.01 < e.mean() < 0.2      # red-black moves the result by ~0.068 px
+
+
+def test_dis_sum_order():
+    v = np.arange(64, dtype=np.float32) * np.float32(1.000001) + np.float32(1e-3)
+    t = v.copy()
+    k = 1
+    while k < 64:
+        t = t + t[np.arange(64) ^ k]
+        k <<= 1
+    assert O.lib().dis_sum(O.P(v), 64, 1) == t[0]
