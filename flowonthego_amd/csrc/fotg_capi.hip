@@ -1,0 +1,508 @@
+// fotg_capi.hip -- host side of libfotg.so: context, workspace arenas, launch sequencing, C-ABI (include/fotg.h).
+// gfx950 only.  One context = one fixed (size, parameters, max_batch) configuration, reusable across calls;
+// every per-call state is re-initialised by the kernels (the reference's CUDA port is only correct for the first
+// calc(), src/kernels/extract.cu:139-140).  No hipMalloc / sync inside the launch path (graph-capturable).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include "common.h"
+#include "pyramid.hip.h"
+#include "lk.hip.h"
+#include "densify.hip.h"
+#include "varref.hip.h"
+#include "upsample.hip.h"
+
+using namespace fotg;
+
+static thread_local int g_last_hip = 0;
+
+#define HIPCHK(x)                                   \
+  do {                                              \
+    hipError_t e_ = (x);                            \
+    if (e_ != hipSuccess) { g_last_hip = (int)e_; return FOTG_ERR_HIP; } \
+  } while (0)
+#define LAUNCHCHK() HIPCHK(hipGetLastError())
+
+struct GridState {
+  const float *I0 = nullptr, *I0x = nullptr, *I0y = nullptr, *I1 = nullptr;
+  long stride = 0;
+  const float *flow_prev = nullptr;
+  float *trace_host = nullptr;
+};
+
+struct fotg_ctx {
+  fotg_params p;
+  int w_org, h_org, Wp, Hp, padw, padh, device, max_batch, noc, ps;
+  int base_lv;                       // first level the pyramid materialises: min(sc_l, 4)
+  LevelGeom geom[FOTG_MAXLEV];
+  float *im[2][FOTG_MAXLEV];         // padded level images  [B][th][tw][noc]
+  float *dx0[FOTG_MAXLEV], *dy0[FOTG_MAXLEV];
+  long lev_stride[FOTG_MAXLEV];      // floats per pair in a level buffer
+  float *flow[FOTG_MAXLEV];          // [B][h][w][2]
+  float *p_iter[FOTG_MAXLEV];        // [B][nop][2]
+  float *pweight[FOTG_MAXLEV];       // [B][nop][nv]
+  float *tap_t[FOTG_MAXLEV], *tap_tx[FOTG_MAXLEV], *tap_ty[FOTG_MAXLEV], *tap_hes[FOTG_MAXLEV];
+  int *tap_cnt[FOTG_MAXLEV];
+  float *trace_dev[FOTG_MAXLEV];
+  bool taps;
+  float *vr;                         // refinement workspace
+  long vr_pair_stride;
+  GridState gs[FOTG_MAXLEV];
+};
+
+static void fill_geom(const fotg_params &p, int Wp, int Hp, int l, LevelGeom &g)
+{
+  g.lvl = l;
+  g.w = Wp >> l; g.h = Hp >> l;                                    // kroeger/oflow.cpp:144-145
+  g.tw = g.w + 2 * p.ps; g.th = g.h + 2 * p.ps;                    // :150-151
+  g.st = ((g.w + 3) / 4) * 4;
+  int steps = (int)floor(p.ps * (1 - p.patove));                   // :91
+  g.steps = steps > 1 ? steps : 1;
+  g.lb = -(float)p.ps / 2;                                         // :147
+  g.ubw = (float)(g.w + p.ps / 2 - 2);                             // :148
+  g.ubh = (float)(g.h + p.ps / 2 - 2);
+  g.nopw = (int)ceil((float)g.w / (float)g.steps);                 // patchgrid.cpp:43-44
+  g.noph = (int)ceil((float)g.h / (float)g.steps);
+  g.offw = (int)floor((g.w - (g.nopw - 1) * g.steps) / 2);         // :45-46
+  g.offh = (int)floor((g.h - (g.noph - 1) * g.steps) / 2);
+  g.nop = g.nopw * g.noph;
+}
+
+extern "C" {
+
+const char *fotg_version(void) { return "fotg-mi355x 0.1 (gfx950)"; }
+int fotg_last_hip_error(void) { return g_last_hip; }
+
+const char *fotg_strerror(int s)
+{
+  switch (s) {
+    case FOTG_OK: return "ok";
+    case FOTG_ERR_ARG: return "invalid argument";
+    case FOTG_ERR_HIP: return "HIP runtime error";
+    case FOTG_ERR_BATCH: return "batch larger than max_batch";
+    case FOTG_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+  }
+}
+
+/* kroeger/run_dense.cpp:180-183, 225-268 */
+int fotg_op_point(int op, int width_org, int channels, fotg_params *p)
+{
+  if (!p || width_org <= 0 || (channels != 1 && channels != 3)) return FOTG_ERR_ARG;
+  memset(p, 0, sizeof(*p));
+  p->dp_thresh = 0.05f; p->dr_thresh = 0.95f; p->res_thresh = 0.0f; p->patnorm = 1; p->noc = channels;
+  p->tv_alpha = 10.0f; p->tv_gamma = 10.0f; p->tv_delta = 5.0f; p->tv_innerit = 1; p->tv_solverit = 3; p->tv_sor = 1.6f;
+  p->sor_mode = FOTG_SOR_LEXICOGRAPHIC;
+  int sub;
+  switch (op) {
+    case 1: p->ps = 8;  p->patove = 0.3f;  sub = 2; p->max_iter = 16;  p->usetvref = 0; break;
+    case 3: p->ps = 12; p->patove = 0.75f; sub = 4; p->max_iter = 16;  p->usetvref = 1; break;
+    case 4: p->ps = 12; p->patove = 0.75f; sub = 5; p->max_iter = 128; p->usetvref = 1; break;
+    case 2:
+    default: p->ps = 8; p->patove = 0.4f;  sub = 2; p->max_iter = 12;  p->usetvref = 1; break;
+  }
+  p->min_iter = p->max_iter;
+  const int fratio = 5;
+  float v = (2.0f * (float)width_org) / ((float)fratio * (float)p->ps);
+  int f = (int)floor(log2(v));
+  p->sc_f = f > 0 ? f : 0;
+  p->sc_l = p->sc_f - sub > 0 ? p->sc_f - sub : 0;
+  return FOTG_OK;
+}
+
+int fotg_padded_size(int w, int h, int sc_f, int *wp, int *hp, int *padw, int *padh)
+{
+  if (w <= 0 || h <= 0 || sc_f < 0 || sc_f >= FOTG_MAXLEV) return FOTG_ERR_ARG;
+  int scfct = 1 << sc_f, pw = 0, ph = 0;
+  int div = w % scfct; if (div > 0) pw = scfct - div;
+  div = h % scfct;     if (div > 0) ph = scfct - div;
+  if (wp) *wp = w + pw; if (hp) *hp = h + ph; if (padw) *padw = pw; if (padh) *padh = ph;
+  return FOTG_OK;
+}
+
+void fotg_destroy(fotg_ctx *c)
+{
+  if (!c) return;
+  for (int l = 0; l < FOTG_MAXLEV; ++l) {
+    (void)hipFree(c->im[0][l]); hipFree(c->im[1][l]); hipFree(c->dx0[l]); hipFree(c->dy0[l]);
+    (void)hipFree(c->flow[l]); hipFree(c->p_iter[l]); hipFree(c->pweight[l]);
+    (void)hipFree(c->tap_t[l]); hipFree(c->tap_tx[l]); hipFree(c->tap_ty[l]); hipFree(c->tap_hes[l]); hipFree(c->tap_cnt[l]);
+    (void)hipFree(c->trace_dev[l]);
+  }
+  (void)hipFree(c->vr);
+  delete c;
+}
+
+int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_batch, fotg_ctx **out)
+{
+  if (!p || !out || w_org <= 0 || h_org <= 0 || max_batch <= 0) return FOTG_ERR_ARG;
+  if (p->noc != 1 && p->noc != 3) return FOTG_ERR_ARG;
+  if (p->ps != 8 && p->ps != 12) return FOTG_ERR_UNSUPPORTED;     // op-points use 8 and 12 (run_dense.cpp:242-261)
+  if (p->sc_l < 0 || p->sc_f < p->sc_l || p->sc_f >= FOTG_MAXLEV) return FOTG_ERR_ARG;
+  if (p->max_iter < 0 || p->tv_solverit < 0 || p->tv_innerit < 0) return FOTG_ERR_ARG;
+  HIPCHK(hipSetDevice(device));
+  fotg_ctx *c = new (std::nothrow) fotg_ctx();
+  if (!c) return FOTG_ERR_ARG;
+  memset((void *)c, 0, sizeof(*c));
+  c->p = *p; c->w_org = w_org; c->h_org = h_org; c->device = device; c->max_batch = max_batch;
+  c->noc = p->noc; c->ps = p->ps;
+  fotg_padded_size(w_org, h_org, p->sc_f, &c->Wp, &c->Hp, &c->padw, &c->padh);
+  c->base_lv = p->sc_l < 4 ? p->sc_l : 4;
+  const size_t B = (size_t)max_batch;
+  for (int l = c->base_lv; l <= p->sc_f; ++l) {
+    LevelGeom &g = c->geom[l];
+    fill_geom(*p, c->Wp, c->Hp, l, g);
+    if (g.w < 1 || g.h < 1) { fotg_destroy(c); return FOTG_ERR_ARG; }
+    c->lev_stride[l] = (long)g.tw * g.th * c->noc;
+    const size_t bytes = B * c->lev_stride[l] * sizeof(float);
+#define ALLOC(ptr, nbytes) do { if (hipMalloc((void **)&(ptr), (nbytes)) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; } } while (0)
+    ALLOC(c->im[0][l], bytes);
+    ALLOC(c->im[1][l], bytes);
+    if (l >= p->sc_l) {
+      ALLOC(c->dx0[l], bytes);
+      ALLOC(c->dy0[l], bytes);
+      ALLOC(c->flow[l], B * g.w * g.h * 2 * sizeof(float));
+      ALLOC(c->p_iter[l], B * g.nop * 2 * sizeof(float));
+      ALLOC(c->pweight[l], B * g.nop * (size_t)(p->ps * p->ps * c->noc) * sizeof(float));
+    }
+  }
+  if (p->usetvref) {
+    const LevelGeom &g = c->geom[p->sc_l];
+    if (g.h > 1024 && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
+    if (g.w < 3 || c->geom[p->sc_f].h < 5 || c->geom[p->sc_f].w < 3) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
+    c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc);
+    ALLOC(c->vr, B * c->vr_pair_stride * sizeof(float));
+  }
+#undef ALLOC
+  *out = c;
+  return FOTG_OK;
+}
+
+int fotg_enable_taps(fotg_ctx *c, int on)
+{
+  if (!c) return FOTG_ERR_ARG;
+  if (on && !c->taps) {
+    HIPCHK(hipSetDevice(c->device));
+    for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) {
+      const size_t n = (size_t)c->max_batch * c->geom[l].nop, nv = (size_t)c->ps * c->ps * c->noc;
+      HIPCHK(hipMalloc((void **)&c->tap_t[l], n * nv * 4)); HIPCHK(hipMalloc((void **)&c->tap_tx[l], n * nv * 4));
+      HIPCHK(hipMalloc((void **)&c->tap_ty[l], n * nv * 4)); HIPCHK(hipMalloc((void **)&c->tap_hes[l], n * 3 * 4));
+      HIPCHK(hipMalloc((void **)&c->tap_cnt[l], n * 4));
+      HIPCHK(hipMalloc((void **)&c->trace_dev[l], (size_t)c->geom[l].nop * (c->p.max_iter + 1) * 4 * 4));
+    }
+    c->taps = true;
+  }
+  return FOTG_OK;
+}
+
+int fotg_level_size(const fotg_ctx *c, int l, int *w, int *h)
+{
+  if (!c || l < c->base_lv || l > c->p.sc_f) return FOTG_ERR_ARG;
+  if (w) *w = c->geom[l].w; if (h) *h = c->geom[l].h;
+  return FOTG_OK;
+}
+int fotg_out_size(const fotg_ctx *c, int *w, int *h) { return c ? fotg_level_size(c, c->p.sc_l, w, h) : FOTG_ERR_ARG; }
+int fotg_num_patches(const fotg_ctx *c, int l, int *nopw, int *noph)
+{
+  if (!c || l < c->p.sc_l || l > c->p.sc_f) return FOTG_ERR_ARG;
+  if (nopw) *nopw = c->geom[l].nopw; if (noph) *noph = c->geom[l].noph;
+  return FOTG_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* pyramid                                                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+}  // extern "C"
+template <int NOC>
+static int pyramid_impl(fotg_ctx *c, int n, const float *I, int which, hipStream_t s)
+{
+  const int lv = c->base_lv, ps = c->ps;
+  const LevelGeom &g0 = c->geom[lv];
+  const int strips = (c->Wp + 255) >> 8, tiles = strips * (c->Hp >> lv);
+  const long fstride = (long)c->w_org * c->h_org * NOC;
+  const int fast = (c->padw == 0) && ((c->w_org * NOC) % 4 == 0) && (((uintptr_t)I & 15) == 0) && ((fstride % 4) == 0);
+  dim3 grid((tiles + 3) / 4, n), block(256);
+  float *dst = c->im[which][lv];
+#define BASE(LV) pyr_base_kernel<NOC, LV><<<grid, block, 0, s>>>(I, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dst, c->lev_stride[lv], g0.tw, ps, fast)
+  switch (lv) {
+    case 0: BASE(0); break;
+    case 1: BASE(1); break;
+    case 2: BASE(2); break;
+    case 3: BASE(3); break;
+    default: BASE(4); break;
+  }
+#undef BASE
+  LAUNCHCHK();
+  for (int l = lv + 1; l <= c->p.sc_f; ++l) {
+    const LevelGeom &gs = c->geom[l - 1], &gd = c->geom[l];
+    const int tot = gd.w * gd.h * NOC;
+    pyr_halve_kernel<NOC><<<dim3((tot + 255) / 256, n), 256, 0, s>>>(c->im[which][l - 1], c->lev_stride[l - 1], gs.tw,
+                                                                     c->im[which][l], c->lev_stride[l], gd.tw, gd.w, gd.h, ps);
+    LAUNCHCHK();
+  }
+  for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) {
+    const LevelGeom &g = c->geom[l];
+    const int tot = g.tw * g.th * NOC;
+    pyr_border_grad_kernel<NOC><<<dim3((tot + 255) / 256, n), 256, 0, s>>>(
+        c->im[which][l], which == 0 ? c->dx0[l] : nullptr, which == 0 ? c->dy0[l] : nullptr, c->lev_stride[l], g.w, g.h, ps);
+    LAUNCHCHK();
+  }
+  return FOTG_OK;
+}
+
+extern "C" {
+int fotg_pyramid(fotg_ctx *c, int n, const float *I, int which, void *stream)
+{
+  if (!c || !I || (which != 0 && which != 1)) return FOTG_ERR_ARG;
+  if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  return c->noc == 1 ? pyramid_impl<1>(c, n, I, which, (hipStream_t)stream) : pyramid_impl<3>(c, n, I, which, (hipStream_t)stream);
+}
+
+int fotg_level_ptr(fotg_ctx *c, int which, int l, int kind, float **ptr, long *pair_stride)
+{
+  if (!c || !ptr || l < c->p.sc_l || l > c->p.sc_f || (which != 0 && which != 1)) return FOTG_ERR_ARG;
+  float *p = nullptr;
+  if (kind == 0) p = c->im[which][l];
+  else if (which == 0 && kind == 1) p = c->dx0[l];
+  else if (which == 0 && kind == 2) p = c->dy0[l];
+  if (!p) return FOTG_ERR_ARG;
+  *ptr = p;
+  if (pair_stride) *pair_stride = c->lev_stride[l];
+  return FOTG_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* patch grid                                                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+static int check_level(fotg_ctx *c, int l, int n)
+{
+  if (!c || l < c->p.sc_l || l > c->p.sc_f) return FOTG_ERR_ARG;
+  if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  return FOTG_OK;
+}
+
+int fotg_grid_init(fotg_ctx *c, int l, int n, const float *I0, const float *I0x, const float *I0y, long pair_stride, void *stream)
+{
+  (void)stream;
+  int st = check_level(c, l, n); if (st) return st;
+  if (!I0 || !I0x || !I0y) return FOTG_ERR_ARG;
+  GridState &g = c->gs[l];
+  g.I0 = I0; g.I0x = I0x; g.I0y = I0y; g.stride = pair_stride;
+  g.flow_prev = nullptr;                                            // p_init.setZero() (patchgrid.cpp:113)
+  return FOTG_OK;
+}
+int fotg_grid_set_target(fotg_ctx *c, int l, const float *I1, long pair_stride)
+{
+  int st = check_level(c, l, 1); if (st) return st;
+  if (!I1) return FOTG_ERR_ARG;
+  c->gs[l].I1 = I1;
+  if (c->gs[l].stride && c->gs[l].stride != pair_stride) return FOTG_ERR_ARG;
+  c->gs[l].stride = pair_stride;
+  return FOTG_OK;
+}
+int fotg_grid_init_from_coarser(fotg_ctx *c, int l, int n, const float *flow_prev, void *stream)
+{
+  (void)stream;
+  int st = check_level(c, l, n); if (st) return st;
+  if (!flow_prev) return FOTG_ERR_ARG;
+  c->gs[l].flow_prev = flow_prev;
+  return FOTG_OK;
+}
+int fotg_grid_set_trace(fotg_ctx *c, int l, float *trace_host)
+{
+  int st = check_level(c, l, 1); if (st) return st;
+  if (trace_host) { st = fotg_enable_taps(c, 1); if (st) return st; }
+  c->gs[l].trace_host = trace_host;
+  return FOTG_OK;
+}
+
+int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
+{
+  int st = check_level(c, l, n); if (st) return st;
+  GridState &gs = c->gs[l];
+  if (!gs.I0 || !gs.I1) return FOTG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const LevelGeom &g = c->geom[l];
+  LkArgs a;
+  memset(&a, 0, sizeof(a));
+  a.I0 = gs.I0; a.I0x = gs.I0x; a.I0y = gs.I0y; a.I1 = gs.I1; a.img_stride = gs.stride;
+  a.flow_prev = gs.flow_prev;
+  a.flow_prev_stride = (long)(g.w / 2) * (g.h / 2) * 2;
+  a.p_iter = c->p_iter[l]; a.pweight = c->pweight[l];
+  if (c->taps) { a.tmpl = c->tap_t[l]; a.tdx = c->tap_tx[l]; a.tdy = c->tap_ty[l]; a.hes = c->tap_hes[l]; a.cnt = c->tap_cnt[l]; }
+  a.trace = gs.trace_host ? c->trace_dev[l] : nullptr;
+  a.g = g;
+  a.max_iter = c->p.max_iter; a.min_iter = c->p.min_iter; a.patnorm = c->p.patnorm;
+  a.dp_thresh_sq = c->p.dp_thresh * c->p.dp_thresh;                 // kroeger/oflow.cpp:88
+  a.dr_thresh = c->p.dr_thresh; a.res_thresh = c->p.res_thresh;
+  a.outlier = (float)c->ps / 2;                                     // :82
+  dim3 grid((g.nop + 3) / 4, n), block(256);
+  if (c->ps == 8 && c->noc == 1) lk_kernel<8, 1><<<grid, block, 0, s>>>(a);
+  else if (c->ps == 8) lk_kernel<8, 3><<<grid, block, 0, s>>>(a);
+  else if (c->noc == 1) lk_kernel<12, 1><<<grid, block, 0, s>>>(a);
+  else lk_kernel<12, 3><<<grid, block, 0, s>>>(a);
+  LAUNCHCHK();
+  if (gs.trace_host) {
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(gs.trace_host, c->trace_dev[l], (size_t)g.nop * (c->p.max_iter + 1) * 16, hipMemcpyDeviceToHost));
+  }
+  return FOTG_OK;
+}
+
+int fotg_grid_aggregate(fotg_ctx *c, int l, int n, float *flowout, void *stream)
+{
+  int st = check_level(c, l, n); if (st) return st;
+  if (!flowout) return FOTG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const LevelGeom &g = c->geom[l];
+  dim3 grid((g.w * g.h + 255) / 256, n), block(256);
+  const long fs = (long)g.w * g.h * 2;
+  if (c->ps == 8 && c->noc == 1) densify_kernel<8, 1><<<grid, block, 0, s>>>(c->p_iter[l], c->pweight[l], flowout, fs, g);
+  else if (c->ps == 8) densify_kernel<8, 3><<<grid, block, 0, s>>>(c->p_iter[l], c->pweight[l], flowout, fs, g);
+  else if (c->noc == 1) densify_kernel<12, 1><<<grid, block, 0, s>>>(c->p_iter[l], c->pweight[l], flowout, fs, g);
+  else densify_kernel<12, 3><<<grid, block, 0, s>>>(c->p_iter[l], c->pweight[l], flowout, fs, g);
+  LAUNCHCHK();
+  return FOTG_OK;
+}
+
+int fotg_grid_read(fotg_ctx *c, int l, int pair, float *p_iter, float *pweight, float *tmpl, float *tdx, float *tdy,
+                   float *hes, int *cnt)
+{
+  int st = check_level(c, l, 1); if (st) return st;
+  if (pair < 0 || pair >= c->max_batch) return FOTG_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  const size_t nop = c->geom[l].nop, nv = (size_t)c->ps * c->ps * c->noc, pb = (size_t)pair * nop;
+  if (p_iter) HIPCHK(hipMemcpy(p_iter, c->p_iter[l] + pb * 2, nop * 2 * 4, hipMemcpyDeviceToHost));
+  if (pweight) HIPCHK(hipMemcpy(pweight, c->pweight[l] + pb * nv, nop * nv * 4, hipMemcpyDeviceToHost));
+  if (tmpl || tdx || tdy || hes || cnt) {
+    if (!c->taps) return FOTG_ERR_ARG;
+    if (tmpl) HIPCHK(hipMemcpy(tmpl, c->tap_t[l] + pb * nv, nop * nv * 4, hipMemcpyDeviceToHost));
+    if (tdx) HIPCHK(hipMemcpy(tdx, c->tap_tx[l] + pb * nv, nop * nv * 4, hipMemcpyDeviceToHost));
+    if (tdy) HIPCHK(hipMemcpy(tdy, c->tap_ty[l] + pb * nv, nop * nv * 4, hipMemcpyDeviceToHost));
+    if (hes) HIPCHK(hipMemcpy(hes, c->tap_hes[l] + pb * 3, nop * 3 * 4, hipMemcpyDeviceToHost));
+    if (cnt) HIPCHK(hipMemcpy(cnt, c->tap_cnt[l] + pb, nop * 4, hipMemcpyDeviceToHost));
+  }
+  return FOTG_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* variational refinement                                                                           */
+/* ------------------------------------------------------------------------------------------------ */
+}  // extern "C"
+template <int NOC>
+static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *I1, long img_stride, float *flow, hipStream_t s)
+{
+  const LevelGeom &g = c->geom[l];
+  VrArgs a;
+  a.base = c->vr; a.pair_stride = c->vr_pair_stride; a.w = g.w; a.h = g.h; a.st = g.st; a.noc = NOC; a.pl = (long)g.st * g.h;
+  const long fs = (long)g.w * g.h * 2;
+  dim3 grid((g.w * g.h + 255) / 256, n), block(256);
+  // kroeger/refine_variational.cpp:31-43
+  const float quarter_alpha = 0.25f * c->p.tv_alpha;
+  const float half_gamma_over3 = c->p.tv_gamma * 0.5f / 3.0f;
+  const float half_delta_over3 = c->p.tv_delta * 0.5f / 3.0f;
+  const int inner = c->p.tv_innerit * (l + 1);
+  vr_prep_kernel<NOC><<<grid, block, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
+  LAUNCHCHK();
+  vr_deriv1_kernel<NOC><<<grid, block, 0, s>>>(a);
+  LAUNCHCHK();
+  vr_deriv2_kernel<NOC><<<grid, block, 0, s>>>(a);
+  LAUNCHCHK();
+  for (int it = 0; it < inner; ++it) {
+    vr_smooth_kernel<<<grid, block, 0, s>>>(a, quarter_alpha);
+    LAUNCHCHK();
+    vr_data_kernel<NOC><<<grid, block, 0, s>>>(a, half_delta_over3, half_gamma_over3);
+    LAUNCHCHK();
+    if (c->p.tv_solverit > 0) {
+      if (c->p.sor_mode == FOTG_SOR_REDBLACK) vr_sor_redblack_kernel<<<n, 1024, 0, s>>>(a, c->p.tv_solverit, c->p.tv_sor);
+      else vr_sor_wavefront_kernel<<<n, ((g.h + 63) / 64) * 64, 0, s>>>(a, c->p.tv_solverit, c->p.tv_sor);
+      LAUNCHCHK();
+    }
+  }
+  vr_finish_kernel<<<grid, block, 0, s>>>(a, flow, fs);
+  LAUNCHCHK();
+  return FOTG_OK;
+}
+
+extern "C" {
+int fotg_varref(fotg_ctx *c, int l, int n, const float *I0, const float *I1, long pair_stride, float *flow, void *stream)
+{
+  int st = check_level(c, l, n); if (st) return st;
+  if (!I0 || !I1 || !flow || !c->vr) return FOTG_ERR_ARG;
+  if (c->geom[l].h < 5 || c->geom[l].w < 3) return FOTG_ERR_UNSUPPORTED;
+  return c->noc == 1 ? varref_impl<1>(c, l, n, I0, I1, pair_stride, flow, (hipStream_t)stream)
+                     : varref_impl<3>(c, l, n, I0, I1, pair_stride, flow, (hipStream_t)stream);
+}
+
+int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *host_out)
+{
+  int st = check_level(c, l, 1); if (st) return st;
+  if (!name || !host_out || !c->vr || pair < 0 || pair >= c->max_batch) return FOTG_ERR_ARG;
+  static const char *singles[] = {"wx", "wy", "du", "dv", "mask", "s", "sh", "sv", "a11", "a12", "a22", "b1", "b2"};
+  static const char *colors[] = {"avg", "Iz", "Ix", "Iy", "Ixx", "Ixy", "Iyy", "Ixz", "Iyz"};
+  const LevelGeom &g = c->geom[l];
+  const size_t pl = (size_t)g.st * g.h;
+  HIPCHK(hipDeviceSynchronize());
+  for (int i = 0; i < P_NSINGLE; ++i)
+    if (!strcmp(name, singles[i])) {
+      HIPCHK(hipMemcpy(host_out, c->vr + (size_t)pair * c->vr_pair_stride + i * pl, pl * 4, hipMemcpyDeviceToHost));
+      return FOTG_OK;
+    }
+  for (int i = 0; i < C_NCOLOR; ++i)
+    if (!strcmp(name, colors[i])) {
+      HIPCHK(hipMemcpy(host_out, c->vr + (size_t)pair * c->vr_pair_stride + (P_NSINGLE + (size_t)i * c->noc) * pl,
+                       pl * c->noc * 4, hipMemcpyDeviceToHost));
+      return FOTG_OK;
+    }
+  return FOTG_ERR_ARG;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* whole flow: OFClass::calc (src/oflow.cpp:211-368) with kroeger numerics (kroeger/oflow.cpp:184-337)   */
+/* ------------------------------------------------------------------------------------------------ */
+int fotg_calc_batch(fotg_ctx *c, int n, const float *I0, const float *I1, const float *initflow, float *outflow, void *stream)
+{
+  if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
+  if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  int st;
+  if ((st = fotg_pyramid(c, n, I0, 0, stream))) return st;
+  if ((st = fotg_pyramid(c, n, I1, 1, stream))) return st;
+  for (int l = c->p.sc_f; l >= c->p.sc_l; --l) {
+    if ((st = fotg_grid_init(c, l, n, c->im[0][l], c->dx0[l], c->dy0[l], c->lev_stride[l], stream))) return st;
+    if ((st = fotg_grid_set_target(c, l, c->im[1][l], c->lev_stride[l]))) return st;
+    if (l < c->p.sc_f) { if ((st = fotg_grid_init_from_coarser(c, l, n, c->flow[l + 1], stream))) return st; }
+    else if (initflow) { if ((st = fotg_grid_init_from_coarser(c, l, n, initflow, stream))) return st; }
+    if ((st = fotg_grid_optimize(c, l, n, stream))) return st;
+    float *out = (l == c->p.sc_l) ? outflow : c->flow[l];
+    if ((st = fotg_grid_aggregate(c, l, n, out, stream))) return st;
+    if (c->p.usetvref)
+      if ((st = fotg_varref(c, l, n, c->im[0][l], c->im[1][l], c->lev_stride[l], out, stream))) return st;
+  }
+  return FOTG_OK;
+}
+
+int fotg_calc(fotg_ctx *c, const float *I0, const float *I1, const float *initflow, float *outflow_host)
+{
+  if (!c || !outflow_host) return FOTG_ERR_ARG;
+  const LevelGeom &g = c->geom[c->p.sc_l];
+  int st = fotg_calc_batch(c, 1, I0, I1, initflow, c->flow[c->p.sc_l], nullptr);
+  if (st) return st;
+  HIPCHK(hipMemcpy(outflow_host, c->flow[c->p.sc_l], (size_t)g.w * g.h * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  return FOTG_OK;
+}
+
+int fotg_upsample_crop(fotg_ctx *c, int n, const float *flow, float *out, void *stream)
+{
+  if (!c || !flow || !out) return FOTG_ERR_ARG;
+  if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  const LevelGeom &g = c->geom[c->p.sc_l];
+  dim3 grid((c->w_org * c->h_org + 255) / 256, n), block(256);
+  upsample_crop_kernel<<<grid, block, 0, (hipStream_t)stream>>>(flow, (long)g.w * g.h * 2, g.w, g.h, c->p.sc_l, c->padw / 2, c->padh / 2,
+                                                                 c->w_org, c->h_org, out, (long)c->w_org * c->h_org * 2);
+  LAUNCHCHK();
+  return FOTG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// pyramid.hip.h -- image pyramid + gradients (kroeger/run_dense.cpp:130-178, :298-311).
+//
+// The only HBM-heavy stage of the path: each input frame is read exactly once.
+//   pyr_base_kernel   frame (h_org x w_org x NOC, unpadded) -> level LV interior, cascading the 2x2 means
+//                     in registers / across lanes (one wave = 256 px x 2^LV rows, 16-B loads per lane).
+//                     The replicate padding to multiples of 2^sc_f (run_dense.cpp:298-311) is a clamp
+//                     on the source coordinate -- no padded copy of the frame is ever materialised.
+//   pyr_halve_kernel  level l -> level l+1 (small images)
+//   pyr_border_grad_kernel  replicate border of the image, [-1 0 1] gradients with REFLECT_101 inside,
+//                     zero border for the gradients (run_dense.cpp:156-175)
+// 2x2 mean order: ((a+c)+(b+d))*0.25, a,b = upper row, c,d = lower row (oracle definition D4).
+#pragma once
+#include "common.h"
+
+namespace fotg {
+
+template <int NOC, int LV>
+__global__ __launch_bounds__(256) void pyr_base_kernel(
+    const float *__restrict__ frames, long frame_stride,  // n frames, h_org x w_org x NOC
+    int w_org, int h_org, int left, int top,               // padding offsets (floor(pad/2))
+    int Wp, int Hp,                                        // padded frame size
+    float *__restrict__ dst, long dst_stride, int tw, int ps,  // level LV padded buffer
+    int fast)                                              // 1: 16-B loads legal (no horizontal pad, aligned rows)
+{
+  constexpr int R = 1 << LV;                 // source rows per output row
+  constexpr int C = 4 * NOC;                 // floats per lane per row
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int strips = (Wp + 255) >> 8;
+  const int tile = blockIdx.x * 4 + wave;
+  const int oh = Hp >> LV;
+  if (tile >= strips * oh) return;
+  const int strip = tile % strips, oy = tile / strips;
+  const int img = blockIdx.y;
+  const float *src = frames + (size_t)img * frame_stride;
+  const int x0 = strip * 256 + lane * 4;     // first of this lane's 4 source pixels (padded coords)
+  const bool active = x0 < Wp;               // Wp is a multiple of 4 whenever LV >= 2
+  float v[R][C];
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int sy = clampi(oy * R + r - top, h_org);
+      const float *row = src + (size_t)sy * w_org * NOC;
+      if (fast) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(row + (size_t)x0 * NOC);
+#pragma unroll
+        for (int k = 0; k < NOC; ++k) {
+          float4 t = p4[k];
+          v[r][4 * k] = t.x; v[r][4 * k + 1] = t.y; v[r][4 * k + 2] = t.z; v[r][4 * k + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          const int sx = clampi(x0 + px - left, w_org);
+#pragma unroll
+          for (int c = 0; c < NOC; ++c) v[r][px * NOC + c] = row[(size_t)sx * NOC + c];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < C; ++k) v[r][k] = 0.f;
+  }
+  float *out = dst + (size_t)img * dst_stride;
+  if constexpr (LV == 0) {
+    if (active) {
+#pragma unroll
+      for (int px = 0; px < 4; ++px)
+        if (x0 + px < Wp)
+#pragma unroll
+          for (int c = 0; c < NOC; ++c) out[((size_t)(oy + ps) * tw + (x0 + px + ps)) * NOC + c] = v[0][px * NOC + c];
+    }
+    return;
+  } else {
+    // level 1: 2 px per lane
+    float l1[R / 2][2 * NOC];
+#pragma unroll
+    for (int y = 0; y < R / 2; ++y)
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) {
+          const float a = v[2 * y][(2 * px) * NOC + c], b = v[2 * y][(2 * px + 1) * NOC + c];
+          const float cc = v[2 * y + 1][(2 * px) * NOC + c], d = v[2 * y + 1][(2 * px + 1) * NOC + c];
+          l1[y][px * NOC + c] = ((a + cc) + (b + d)) * 0.25f;
+        }
+    if constexpr (LV == 1) {
+      if (active) {
+        const int ox = x0 >> 1;
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+          if (ox + px < (Wp >> 1))
+#pragma unroll
+            for (int c = 0; c < NOC; ++c) out[((size_t)(oy + ps) * tw + (ox + px + ps)) * NOC + c] = l1[0][px * NOC + c];
+      }
+      return;
+    } else {
+      // level 2: 1 px per lane
+      float cur[R / 4][NOC];
+#pragma unroll
+      for (int y = 0; y < R / 4; ++y)
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) {
+          const float a = l1[2 * y][c], b = l1[2 * y][NOC + c], cc = l1[2 * y + 1][c], d = l1[2 * y + 1][NOC + c];
+          cur[y][c] = ((a + cc) + (b + d)) * 0.25f;
+        }
+      // levels 3..LV: partner lanes lane^1, lane^2 hold the neighbouring column
+      int rows = R / 4;
+#pragma unroll
+      for (int k = 3; k <= LV; ++k) {
+        const int xm = 1 << (k - 3);
+#pragma unroll
+        for (int y = 0; y < (R >> k); ++y)
+#pragma unroll
+          for (int c = 0; c < NOC; ++c) {
+            const float s = cur[2 * y][c] + cur[2 * y + 1][c];     // (a+c) of this column
+            const float t = __shfl_xor(s, xm, 64);                   // (b+d) of the partner column
+            cur[y][c] = (s + t) * 0.25f;
+          }
+        rows >>= 1;
+      }
+      (void)rows;
+      constexpr int G = 1 << (LV - 2);          // lanes sharing one output pixel
+      if (active && (lane % G) == 0) {
+        const int ox = (strip * 256 >> LV) + lane / G;
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) out[((size_t)(oy + ps) * tw + (ox + ps)) * NOC + c] = cur[0][c];
+      }
+    }
+  }
+}
+
+// level l (padded buffer, interior valid) -> level l+1 interior
+template <int NOC>
+__global__ __launch_bounds__(256) void pyr_halve_kernel(const float *__restrict__ src, long src_stride, int stw,
+                                                        float *__restrict__ dst, long dst_stride, int dtw,
+                                                        int dw, int dh, int ps)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= dw * dh * NOC) return;
+  const int c = idx % NOC, x = (idx / NOC) % dw, y = idx / (NOC * dw);
+  const float *s = src + (size_t)blockIdx.y * src_stride;
+  const float a = s[((size_t)(2 * y + ps) * stw + (2 * x + ps)) * NOC + c];
+  const float b = s[((size_t)(2 * y + ps) * stw + (2 * x + 1 + ps)) * NOC + c];
+  const float cc = s[((size_t)(2 * y + 1 + ps) * stw + (2 * x + ps)) * NOC + c];
+  const float d = s[((size_t)(2 * y + 1 + ps) * stw + (2 * x + 1 + ps)) * NOC + c];
+  dst[(size_t)blockIdx.y * dst_stride + ((size_t)(y + ps) * dtw + (x + ps)) * NOC + c] = ((a + cc) + (b + d)) * 0.25f;
+}
+
+// one thread per element of the padded level buffer
+template <int NOC>
+__global__ __launch_bounds__(256) void pyr_border_grad_kernel(float *__restrict__ im, float *__restrict__ dx,
+                                                              float *__restrict__ dy, long stride,
+                                                              int w, int h, int ps)
+{
+  const int tw = w + 2 * ps, th = h + 2 * ps;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= tw * th * NOC) return;
+  const int c = idx % NOC, X = (idx / NOC) % tw, Y = idx / (NOC * tw);
+  float *I = im + (size_t)blockIdx.y * stride;
+  const int x = X - ps, y = Y - ps;
+  const bool inside = x >= 0 && x < w && y >= 0 && y < h;
+#define PIX(yy, xx) I[((size_t)((yy) + ps) * tw + ((xx) + ps)) * NOC + c]
+  if (!inside) I[idx] = PIX(clampi(y, h), clampi(x, w));                    // copyMakeBorder REPLICATE (:166)
+  if (dx) {
+    float gx = 0.f, gy = 0.f;                                                 // BORDER_CONSTANT 0 (:171-172)
+    if (inside) {                                                             // Sobel ksize=1, REFLECT_101 (:156-157)
+      gx = PIX(y, reflect101(x + 1, w)) - PIX(y, reflect101(x - 1, w));
+      gy = PIX(reflect101(y + 1, h), x) - PIX(reflect101(y - 1, h), x);
+    }
+    dx[(size_t)blockIdx.y * stride + idx] = gx;
+    dy[(size_t)blockIdx.y * stride + idx] = gy;
+  }
+#undef PIX
+}
+
+}  // namespace fotg

@@ -1,0 +1,42 @@
+// upsample.hip.h -- final flow to full resolution (kroeger/run_dense.cpp:407-414 == src/run_dense.cpp:293-303):
+// flow *= 2^sc_l; cv::resize(INTER_LINEAR) by 2^sc_l; crop the divisibility padding.
+// cv::resize semantics: source coordinate (d+0.5)/s-0.5 evaluated in double, floor, weights clamped
+// to 0 at the borders; horizontal pass then vertical pass.
+#pragma once
+#include "common.h"
+
+namespace fotg {
+
+__global__ __launch_bounds__(256) void upsample_crop_kernel(const float *__restrict__ flow, long in_stride, int wl, int hl,
+                                                            int sc_l, int x0, int y0, int w_org, int h_org,
+                                                            float *__restrict__ out, long out_stride)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= w_org * h_org) return;
+  const int pair = blockIdx.y, x = idx % w_org, y = idx / w_org;
+  const float *f = flow + (size_t)pair * in_stride;
+  const float scf = (float)(1 << sc_l);
+  const double scale = 1.0 / (double)(1 << sc_l);
+  float fy = (float)((y + y0 + 0.5) * scale - 0.5);
+  int sy = (int)floorf(fy); fy -= sy;
+  if (sy < 0) { fy = 0; sy = 0; }
+  if (sy >= hl - 1) { fy = 0; sy = hl - 1; }
+  const int sy1 = sy + 1 < hl ? sy + 1 : hl - 1;
+  float fx = (float)((x + x0 + 0.5) * scale - 0.5);
+  int sx = (int)floorf(fx); fx -= sx;
+  if (sx < 0) { fx = 0; sx = 0; }
+  if (sx >= wl - 1) { fx = 0; sx = wl - 1; }
+  const int sx1 = sx + 1 < wl ? sx + 1 : wl - 1;
+  float *o = out + (size_t)pair * out_stride + 2 * (size_t)idx;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float v00 = f[2 * (sy * wl + sx) + c], v01 = f[2 * (sy * wl + sx1) + c];
+    float v10 = f[2 * (sy1 * wl + sx) + c], v11 = f[2 * (sy1 * wl + sx1) + c];
+    if (sc_l != 0) { v00 *= scf; v01 *= scf; v10 *= scf; v11 *= scf; }
+    const float r0 = v00 * (1.f - fx) + v01 * fx;
+    const float r1 = v10 * (1.f - fx) + v11 * fx;
+    o[c] = r0 * (1.f - fy) + r1 * fy;
+  }
+}
+
+}  // namespace fotg

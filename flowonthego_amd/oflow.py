@@ -1,0 +1,234 @@
+"""Host-side mirror of the reference's flow orchestrator API (src/oflow.h:22-46, src/patchgrid.h:13-86,
+src/refine_variational.h:35-57) over the C-ABI of libfotg.so.  Same class and method names, argument meaning and
+ownership as the reference; PyTorch is used only to hold device memory and streams.
+
+    ofc = OFClass(op, iparams)                       # src/run_dense.cpp:277
+    ofc.calc(I0, I1, iparams, None, outflow)         # src/run_dense.cpp:286
+
+Numerics are those of the reference's kroeger/ CPU implementation, evaluated by hand-written HIP
+kernels; nothing here computes on the CPU and there is no fallback path.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import FotgError, check, lib
+from .params import img_params, opt_params, padded_size
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise FotgError("%s must be a contiguous float32 CUDA(HIP) tensor" % name)
+    return t
+
+
+class OFClass:
+    """src/oflow.h:22-46.  One object = one fixed (size, parameters) configuration, reusable across calc() calls.
+
+    iparams.width/height may be the ORIGINAL frame size: the replicate padding to multiples of 2^coarsest_scale that
+    the reference's driver does first (src/run_dense.cpp:231-253) is folded into the pyramid kernel.  Passing already
+    padded frames (the reference's calling convention) is the special case pad = 0.
+    """
+
+    def __init__(self, _op: opt_params, _i_params: img_params, max_batch: int = 1, device: int = 0):
+        self.op = _op.derive()
+        self.max_batch = int(max_batch)
+        self.width_org, self.height_org = int(_i_params.width), int(_i_params.height)
+        self.width, self.height, self.padw, self.padh = padded_size(self.width_org, self.height_org, self.op.coarsest_scale)
+        if _i_params.padding not in (0, self.op.patch_size):
+            raise FotgError("img_params.padding must equal patch_size (src/run_dense.cpp:263)")
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        cp = self.op.to_c()
+        check(lib().fotg_create(cp, self.width_org, self.height_org, device, self.max_batch, h))
+        self._h = h
+        # per-scale img_params exactly as src/oflow.cpp:84-95
+        self.iparams = []
+        ps = self.op.patch_size
+        for i in range(self.op.n_scales):
+            sl = self.op.finest_scale + i
+            w, hh = self.width >> sl, self.height >> sl
+            self.iparams.append(img_params(width=w, height=hh, padding=ps, l_bound=-ps / 2.0,
+                                           u_bound_width=float(w + ps // 2 - 2), u_bound_height=float(hh + ps // 2 - 2),
+                                           width_pad=w + 2 * ps, height_pad=hh + 2 * ps, scale_fact=2.0 ** -sl, curr_lvl=sl))
+        self.grid = [PatGridClass(self, ip) for ip in self.iparams]
+
+    # -- geometry -------------------------------------------------------------------------------------------
+    def out_size(self):
+        w, h = C.c_int(), C.c_int()
+        check(lib().fotg_out_size(self._h, w, h))
+        return w.value, h.value
+
+    def new_outflow(self, n=1):
+        w, h = self.out_size()
+        return torch.empty((n, h, w, 2), dtype=torch.float32, device=self.device)
+
+    # -- the reference call ---------------------------------------------------------------------------------
+    def calc(self, _I0, _I1, _iparams=None, initflow=None, outflow=None):
+        """src/oflow.cpp:211-368.  _I0/_I1: device tensors (h, w, channels) or (h, w) float32; outflow: device tensor
+        (h/2^finest, w/2^finest, 2), allocated if None.  Returns outflow."""
+        single = _I0.dim() == (2 if self.op.channels == 1 else 3)
+        I0 = _I0.unsqueeze(0) if single else _I0
+        I1 = _I1.unsqueeze(0) if single else _I1
+        out = self.calc_batch(I0, I1, initflow, None if outflow is None else (outflow.unsqueeze(0) if single else outflow))
+        return out[0] if single else out
+
+    def calc_batch(self, I0, I1, initflow=None, outflow=None):
+        """n frame pairs at once: I0, I1 (n, h, w[, channels]); outflow (n, h_l, w_l, 2)"""
+        I0, I1 = _dev_f32(I0, "I0"), _dev_f32(I1, "I1")
+        n = I0.shape[0]
+        exp = (n, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
+        if tuple(I0.shape) != exp and tuple(I0.shape) != exp + (1,):
+            raise FotgError("frame shape %s does not match the configured %s" % (tuple(I0.shape), exp))
+        if I1.shape != I0.shape:
+            raise FotgError("I0 and I1 differ in shape")
+        if outflow is None:
+            outflow = self.new_outflow(n)
+        _dev_f32(outflow, "outflow")
+        if initflow is not None:
+            _dev_f32(initflow, "initflow")
+        check(lib().fotg_calc_batch(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(outflow), _stream()))
+        return outflow
+
+    def upsample_crop(self, flow, out=None):
+        """src/run_dense.cpp:293-303: x 2^finest, bilinear upsample, crop the padding -> (n, h_org, w_org, 2)"""
+        flow = _dev_f32(flow, "flow")
+        n = flow.shape[0]
+        if out is None:
+            out = torch.empty((n, self.height_org, self.width_org, 2), dtype=torch.float32, device=self.device)
+        check(lib().fotg_upsample_crop(self._h, n, _ptr(flow), _ptr(out), _stream()))
+        return out
+
+    # -- pyramid (src/oflow.cpp:182-207 ConstructImgPyramids) -----------------------------------------------
+    def ConstructImgPyramids(self, I0, I1):
+        I0, I1 = _dev_f32(I0, "I0"), _dev_f32(I1, "I1")
+        check(lib().fotg_pyramid(self._h, I0.shape[0], _ptr(I0), 0, _stream()))
+        check(lib().fotg_pyramid(self._h, I1.shape[0], _ptr(I1), 1, _stream()))
+
+    def level(self, which, sl, kind=0, n=1):
+        """padded pyramid plane as a tensor VIEW-COPY (n, h+2ps, w+2ps, channels); kind 0 image, 1 dx, 2 dy"""
+        p, stride = C.c_void_p(), C.c_long()
+        check(lib().fotg_level_ptr(self._h, which, sl, kind, p, stride))
+        ip = self.iparams[sl - self.op.finest_scale]
+        out = torch.empty((n, ip.height_pad, ip.width_pad, self.op.channels), dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize()
+        for k in range(n):
+            _hip_copy(out[k], p.value + 4 * stride.value * k)
+        return out
+
+    def level_ptr(self, which, sl, kind=0):
+        p, stride = C.c_void_p(), C.c_long()
+        check(lib().fotg_level_ptr(self._h, which, sl, kind, p, stride))
+        return p.value, stride.value
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().fotg_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+
+def _hip_copy(dst_tensor, src_ptr):
+    """device->device copy of a raw library pointer into a tensor (test/inspection helper)"""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    r = hip.hipMemcpy(C.c_void_p(dst_tensor.data_ptr()), C.c_void_p(src_ptr), dst_tensor.numel() * 4, 3)
+    if r != 0:
+        raise FotgError("hipMemcpy failed: %d" % r)
+
+
+class PatGridClass:
+    """src/patchgrid.h:13-86: the grid of patches of one scale.  Methods take device tensors in the reference's padded
+    level layout (h+2ps, w+2ps, channels) with a leading batch dimension."""
+
+    def __init__(self, ofc: OFClass, _i_params: img_params):
+        self._ofc = ofc
+        self.i_params = _i_params
+        self.lvl = _i_params.curr_lvl
+        a, b = C.c_int(), C.c_int()
+        check(lib().fotg_num_patches(ofc._h, self.lvl, a, b))
+        self.n_patches_width, self.n_patches_height = a.value, b.value
+        self.n_patches = a.value * b.value
+        self._n = 1
+        self._keep = []
+
+    def GetNumPatches(self): return self.n_patches
+    def GetNumPatchesW(self): return self.n_patches_width
+    def GetNumPatchesH(self): return self.n_patches_height
+
+    def GetRefPatchPos(self, i):
+        """src/patchgrid.cpp:54-63: id = x*n_patches_height + y"""
+        steps = self._ofc.op.steps
+        offw = (self.i_params.width - (self.n_patches_width - 1) * steps) // 2
+        offh = (self.i_params.height - (self.n_patches_height - 1) * steps) // 2
+        x, y = divmod(i, self.n_patches_height)
+        return (float(x * steps + offw), float(y * steps + offh))
+
+    def InitializeGrid(self, _I0, _I0x, _I0y):
+        ts = [_dev_f32(t, "I0") for t in (_I0, _I0x, _I0y)]
+        self._n = ts[0].shape[0]
+        self._keep = ts
+        stride = ts[0][0].numel()
+        check(lib().fotg_grid_init(self._ofc._h, self.lvl, self._n, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), stride, _stream()))
+
+    def SetTargetImage(self, _I1):
+        _dev_f32(_I1, "I1")
+        self._keep.append(_I1)
+        check(lib().fotg_grid_set_target(self._ofc._h, self.lvl, _ptr(_I1), _I1[0].numel()))
+
+    def InitializeFromCoarserOF(self, flow_prev):
+        _dev_f32(flow_prev, "flow_prev")
+        self._keep.append(flow_prev)
+        check(lib().fotg_grid_init_from_coarser(self._ofc._h, self.lvl, self._n, _ptr(flow_prev), _stream()))
+
+    def Optimize(self):
+        check(lib().fotg_grid_optimize(self._ofc._h, self.lvl, self._n, _stream()))
+
+    def AggregateFlowDense(self, flowout=None):
+        if flowout is None:
+            flowout = torch.empty((self._n, self.i_params.height, self.i_params.width, 2), dtype=torch.float32, device=self._ofc.device)
+        check(lib().fotg_grid_aggregate(self._ofc._h, self.lvl, self._n, _ptr(_dev_f32(flowout, "flowout")), _stream()))
+        return flowout
+
+    def printTimings(self):
+        """src/patchgrid.cpp:334-345 prints host-side launch times that never synchronise; per-kernel times here
+        come from rocprofv3 (profiles/)."""
+        print("[timings] use rocprofv3 --kernel-trace --stats (see profiles/)")
+
+    # test taps
+    def read_state(self, pair=0, taps=False):
+        import numpy as np
+        nv = self._ofc.op.n_vals
+        p = np.zeros((self.n_patches, 2), np.float32)
+        w = np.zeros((self.n_patches, nv), np.float32)
+        vp_ = lambda a: a.ctypes.data_as(C.c_void_p)
+        if not taps:
+            check(lib().fotg_grid_read(self._ofc._h, self.lvl, pair, vp_(p), vp_(w), None, None, None, None, None))
+            return {"p_iter": p, "pweight": w}
+        t, tx, ty = (np.zeros((self.n_patches, nv), np.float32) for _ in range(3))
+        hes = np.zeros((self.n_patches, 3), np.float32)
+        cnt = np.zeros((self.n_patches,), np.int32)
+        check(lib().fotg_grid_read(self._ofc._h, self.lvl, pair, vp_(p), vp_(w), vp_(t), vp_(tx), vp_(ty), vp_(hes), vp_(cnt)))
+        return {"p_iter": p, "pweight": w, "tmpl": t, "tdx": tx, "tdy": ty, "hes": hes, "cnt": cnt}
+
+
+class VarRefClass:
+    """src/refine_variational.h:35-57: like the reference, the constructor does all the work, in place on flowout.
+    _I0/_I1: padded level images (n, h+2ps, w+2ps, channels) on the device; flowout (n, h, w, 2) on the device."""
+
+    def __init__(self, ofc: OFClass, _I0, _I1, _i_params: img_params, _op: opt_params, flowout):
+        _dev_f32(_I0, "I0"); _dev_f32(_I1, "I1"); _dev_f32(flowout, "flowout")
+        check(lib().fotg_varref(ofc._h, _i_params.curr_lvl, flowout.shape[0], _ptr(_I0), _ptr(_I1), _I0[0].numel(),
+                                _ptr(flowout), _stream()))
+        self.flowout = flowout

@@ -1,0 +1,130 @@
+/*
+ * fotg.h -- C-ABI of the MI355X-native Dense-Inverse-Search optical-flow engine (libfotg.so).
+ *
+ * This is the drop-in boundary for the reference's flow path: the C++ classes of the reference's
+ * CUDA build (src/oflow.h:22-46 OFClass, src/patchgrid.h:13-86 PatGridClass,
+ * src/refine_variational.h:35-57 VarRefClass, src/params.h:9-65 opt_params/img_params) are thin
+ * header-only wrappers over these entry points (include/fotg/oflow.h, include/fotg/patchgrid.h).
+ * Plain pointers and sizes only; no C++/torch types.  All image/flow pointers are DEVICE pointers
+ * (hipMalloc / any HIP-visible allocation) unless the name says host.  Every call returns a status
+ * code (0 = ok); the library never calls exit() -- the C++ shim reproduces the reference's
+ * print-and-exit behaviour (src/common/cuda_helper.h:286-299).
+ *
+ * Numerics follow the reference's kroeger/ CPU implementation (the parity oracle), not the
+ * reference's CUDA port, which deviates from it.
+ */
+#ifndef FOTG_H
+#define FOTG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOTG_OK               0
+#define FOTG_ERR_ARG          1   /* bad argument / unsupported parameter combination */
+#define FOTG_ERR_HIP          2   /* a HIP runtime call failed (fotg_last_hip_error()) */
+#define FOTG_ERR_BATCH        3   /* n > max_batch */
+#define FOTG_ERR_UNSUPPORTED  4   /* valid in the reference but not implemented here */
+
+#define FOTG_SOR_LEXICOGRAPHIC 0  /* kroeger FDF1.0.1/solver.c:77-421 order (parity mode, default) */
+#define FOTG_SOR_REDBLACK      1  /* red-black ordering of the same 2x2 block update (src/kernels/flowUtil.cu:297-362 ordering) */
+
+/* == optparam of kroeger/oflow.h:33-76 / opt_params of src/params.h:23-65 (explicitly set part) */
+typedef struct fotg_params {
+  int sc_f;            /* coarsest scale            (src: coarsest_scale) */
+  int sc_l;            /* finest scale              (src: finest_scale) */
+  int ps;              /* patch size 8 or 12        (src: patch_size) */
+  int max_iter;        /* LK iterations             (src: grad_descent_iter) */
+  int min_iter;
+  float dp_thresh;     /* 0.05 (squared internally, kroeger/oflow.cpp:88; src/oflow.cpp:53) */
+  float dr_thresh;     /* 0.95 */
+  float res_thresh;    /* 0.0  */
+  float patove;        /* patch overlap             (src: patch_stride) */
+  int patnorm;         /* mean normalisation        (src: use_mean_normalization) */
+  int noc;             /* channels: 1 gray (kroeger run_OF_INT), 3 interleaved (src/, run_OF_RGB) */
+  int usetvref;        /* variational refinement    (src: use_var_ref) */
+  float tv_alpha, tv_gamma, tv_delta;   /* 10, 10, 5 */
+  int tv_innerit;      /* 1: inner iterations = tv_innerit*(level+1) */
+  int tv_solverit;     /* 3                         (src: var_ref_iter) */
+  float tv_sor;        /* 1.6                       (src: var_ref_sor_weight) */
+  int sor_mode;        /* FOTG_SOR_* */
+} fotg_params;
+
+typedef struct fotg_ctx fotg_ctx;
+
+/* operating points 1..4: kroeger/run_dense.cpp:225-268 == src/run_dense.cpp:168-209 */
+int fotg_op_point(int op, int width_org, int channels, fotg_params *out);
+/* padding that makes W,H multiples of 2^sc_f: kroeger/run_dense.cpp:298-305 == src/run_dense.cpp:231-237 */
+int fotg_padded_size(int w, int h, int sc_f, int *wp, int *hp, int *padw, int *padh);
+
+/* Replaces OFClass::OFClass(opt_params, img_params) (src/oflow.cpp:38-145): allocates pyramids, per-scale
+ * flow buffers, patch-grid state and refinement workspace for `max_batch` frame pairs of w_org x h_org
+ * (unpadded).  Padding to multiples of 2^sc_f (src/run_dense.cpp:231-253, cu::pad) is folded into the
+ * pyramid kernel, so callers pass the ORIGINAL frames; already padded frames work too (pad = 0). */
+int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_batch, fotg_ctx **out);
+/* Replaces OFClass::~OFClass (src/oflow.cpp:147-179) */
+void fotg_destroy(fotg_ctx *ctx);
+
+/* Replaces OFClass::calc(I0, I1, iparams, initflow, outflow) (src/oflow.cpp:211-368) for n pairs at once.
+ * I0, I1: n contiguous frames, each h_org x w_org x noc float32 interleaved (src/run_dense.cpp:137-162).
+ * initflow: NULL (as every reference caller passes, src/run_dense.cpp:286) or n x (h/2^(sc_f+1)) x (w/2^(sc_f+1)) x 2.
+ * outflow: n x (Hp/2^sc_l) x (Wp/2^sc_l) x 2 float32 interleaved (u,v), row-major (src/run_dense.cpp:280-289).
+ * stream: hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
+int fotg_calc_batch(fotg_ctx *ctx, int n, const float *I0, const float *I1, const float *initflow,
+                    float *outflow, void *stream);
+/* Single pair, outflow in HOST memory, synchronous -- the exact shape of the reference call. */
+int fotg_calc(fotg_ctx *ctx, const float *I0, const float *I1, const float *initflow, float *outflow_host);
+
+/* kroeger/run_dense.cpp:407-414 == src/run_dense.cpp:293-303: flow *= 2^sc_l, bilinear x2^sc_l, crop the
+ * padding.  in: n x hl x wl x 2 (device), out: n x h_org x w_org x 2 (device). */
+int fotg_upsample_crop(fotg_ctx *ctx, int n, const float *flow, float *out, void *stream);
+
+/* geometry queries */
+int fotg_level_size(const fotg_ctx *ctx, int level, int *w, int *h);        /* unpadded level size */
+int fotg_out_size(const fotg_ctx *ctx, int *w, int *h);                     /* finest-scale flow size */
+int fotg_num_patches(const fotg_ctx *ctx, int level, int *nopw, int *noph); /* PatGridClass::GetNumPatches{W,H} */
+
+/* ---- per-stage entry points (what PatGridClass / VarRefClass / the pyramid helpers bind to) ---- */
+
+/* cu::constructImgPyramids (src/kernels/pyramid.cpp:32-223) with kroeger semantics (run_dense.cpp:130-178).
+ * which: 0 -> I0 (image + gradients), 1 -> I1 (image only; its gradients are never read, patch.cpp:266). */
+int fotg_pyramid(fotg_ctx *ctx, int n, const float *I, int which, void *stream);
+/* device pointer of a pyramid plane of pair 0 (pairs are `*pair_stride` floats apart).
+ * kind: 0 image, 1 dx, 2 dy.  Layout (h_l+2ps) x (w_l+2ps) x noc, like the reference's padded levels. */
+int fotg_level_ptr(fotg_ctx *ctx, int which, int level, int kind, float **ptr, long *pair_stride);
+
+/* PatGridClass (src/patchgrid.h:13-86).  Grid state lives in the context, one grid per level.
+ * All level images use the padded layout above; n pairs, `pair_stride` floats apart. */
+int fotg_grid_init(fotg_ctx *ctx, int level, int n, const float *I0, const float *I0x, const float *I0y,
+                   long pair_stride, void *stream);                                   /* InitializeGrid */
+int fotg_grid_set_target(fotg_ctx *ctx, int level, const float *I1, long pair_stride);  /* SetTargetImage */
+int fotg_grid_init_from_coarser(fotg_ctx *ctx, int level, int n, const float *flow_prev, void *stream); /* InitializeFromCoarserOF */
+int fotg_grid_optimize(fotg_ctx *ctx, int level, int n, void *stream);                /* Optimize */
+int fotg_grid_aggregate(fotg_ctx *ctx, int level, int n, float *flowout, void *stream); /* AggregateFlowDense */
+/* test taps: copy grid state of pair `pair` to host.  Any pointer may be NULL.
+ * p_iter: nop x 2, pweight: nop x nv, tmpl/tdx/tdy: nop x nv, hes: nop x 3, cnt: nop ints */
+int fotg_grid_read(fotg_ctx *ctx, int level, int pair, float *p_iter, float *pweight, float *tmpl,
+                   float *tdx, float *tdy, float *hes, int *cnt);
+/* allocate the optional tap buffers (templates, Hessians, iteration counts) that fotg_grid_read returns;
+ * off by default so the production path writes nothing it does not need */
+int fotg_enable_taps(fotg_ctx *ctx, int on);
+/* per-iteration trace for tests: host buffer nop x (max_iter+1) x 4 [p0,p1,mares,cnt] of pair 0; the next
+ * fotg_grid_optimize on this level fills it (synchronously).  NULL disables. */
+int fotg_grid_set_trace(fotg_ctx *ctx, int level, float *trace_host);
+
+/* VarRefClass::VarRefClass(I0, I1, iparams, op, flowout) (src/refine_variational.cpp:31-145):
+ * refines `flow` (n x h_l x w_l x 2, device) in place. */
+int fotg_varref(fotg_ctx *ctx, int level, int n, const float *I0, const float *I1, long pair_stride,
+                float *flow, void *stream);
+/* test tap: copy one refinement workspace plane (stride-padded, FDF image_t layout) of pair `pair` to host.
+ * name: "wx","wy","du","dv","mask","s","sh","sv","a11","a12","a22","b1","b2","avg","Iz","Ix","Iy","Ixx","Ixy","Iyy","Ixz","Iyz" */
+int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, float *host_out);
+
+const char *fotg_strerror(int status);
+int fotg_last_hip_error(void);
+const char *fotg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOTG_H */

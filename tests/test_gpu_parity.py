@@ -1,0 +1,253 @@
+"""GPU parity tests: the HIP engine (through the C-ABI of libfotg.so) against the CPU oracle, the committed golden
+vectors of the reference's own FDF code, and the reference's golden .flo.  Integer/bit work is compared with ==;
+the engine evaluates the oracle's f32 expressions in the same order (no FMA contraction), so floats are compared
+bit-for-bit as well (np.array_equal; +0 == -0)."""
+import numpy as np
+import pytest
+
+from conftest import load_fdf, synth_pair
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _mods():
+    import flowonthego_amd as F
+    from flowonthego_amd.oflow import OFClass, VarRefClass
+    from oracle import oracle as O
+    return F, OFClass, VarRefClass, O
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def epe(a, b):
+    return np.sqrt(((a - b) ** 2).sum(-1))
+
+
+def oracle_params(O, op):
+    p = O.DisParams()
+    p.sc_f, p.sc_l, p.ps = op.coarsest_scale, op.finest_scale, op.patch_size
+    p.max_iter = p.min_iter = op.grad_descent_iter
+    p.dp_thresh, p.dr_thresh, p.res_thresh = op.dp_thresh, op.dr_thresh, op.res_thresh
+    p.patove, p.patnorm, p.noc, p.usetvref = op.patch_stride, int(op.use_mean_normalization), op.channels, int(op.use_var_ref)
+    p.tv_alpha, p.tv_gamma, p.tv_delta = op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta
+    p.tv_innerit, p.tv_solverit, p.tv_sor = 1, op.var_ref_iter, op.var_ref_sor_weight
+    return p
+
+
+def frames(case, alley):
+    if case == "alley":
+        return alley["frame_0001"].astype(np.float32), alley["frame_0002"].astype(np.float32), 1
+    if case == "alley_rgb":
+        return alley["rgb_crop_0001"][..., ::-1].astype(np.float32), alley["rgb_crop_0002"][..., ::-1].astype(np.float32), 3
+    if case == "synth_1080p":
+        a, b = synth_pair(1080, 1920, seed=1234)
+        return a, b, 1
+    if case == "synth_odd":            # needs horizontal and vertical padding (slow load path)
+        a, b = synth_pair(270, 500, seed=77)
+        return a, b, 1
+    if case == "synth_rgb":
+        a, b = synth_pair(200, 328, seed=9, noc=3)
+        return a, b, 3
+    raise KeyError(case)
+
+
+@pytest.mark.parametrize("case,op_point", [("alley", 2), ("alley_rgb", 2), ("synth_1080p", 2), ("synth_odd", 2),
+                                           ("synth_odd", 3), ("synth_rgb", 1)])
+def test_pyramid_parity(case, op_point, alley):
+    F, OFClass, _, O = _mods()
+    f0, f1, noc = frames(case, alley)
+    h, w = f0.shape[:2]
+    op = F.operating_point(op_point, w, noc)
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    ofc.ConstructImgPyramids(dev(f0)[None], dev(f1)[None])
+    P0 = O.Pyramid(O.pad_frame(f0, op.coarsest_scale), op.coarsest_scale, op.patch_size)
+    P1 = O.Pyramid(O.pad_frame(f1, op.coarsest_scale), op.coarsest_scale, op.patch_size)
+    for sl in range(op.finest_scale, op.coarsest_scale + 1):
+        assert np.array_equal(ofc.level(0, sl, 0)[0].cpu().numpy(), P0.im[sl]), (sl, "I0")
+        assert np.array_equal(ofc.level(0, sl, 1)[0].cpu().numpy(), P0.dx[sl]), (sl, "I0x")
+        assert np.array_equal(ofc.level(0, sl, 2)[0].cpu().numpy(), P0.dy[sl]), (sl, "I0y")
+        assert np.array_equal(ofc.level(1, sl, 0)[0].cpu().numpy(), P1.im[sl]), (sl, "I1")
+
+
+@pytest.mark.parametrize("case,op_point", [("alley", 2), ("alley_rgb", 2), ("synth_odd", 3), ("synth_rgb", 1)])
+def test_patchgrid_stages_parity(case, op_point, alley):
+    """InitializeGrid / InitializeFromCoarserOF / Optimize / AggregateFlowDense per scale, incl. per-iteration trace"""
+    import ctypes as C
+    F, OFClass, _, O = _mods()
+    f0, f1, noc = frames(case, alley)
+    h, w = f0.shape[:2]
+    op = F.operating_point(op_point, w, noc)
+    op.use_var_ref = False
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    F.lib().fotg_enable_taps(ofc._h, 1)
+    p = oracle_params(O, op)
+    P0 = O.Pyramid(O.pad_frame(f0, op.coarsest_scale), op.coarsest_scale, op.patch_size)
+    P1 = O.Pyramid(O.pad_frame(f1, op.coarsest_scale), op.coarsest_scale, op.patch_size)
+    prev_o = None
+    for sl in range(op.coarsest_scale, op.finest_scale - 1, -1):
+        ii = sl - op.finest_scale
+        g = ofc.grid[ii]
+        lw, lh = P0.level_wh(sl)
+        og = O.Grid(lw, lh, sl, p)
+        assert (g.GetNumPatches(), g.GetNumPatchesW(), g.GetNumPatchesH()) == (og.nop, og.nopw, og.noph)
+        assert np.array_equal(np.array([g.GetRefPatchPos(i) for i in range(og.nop)], np.float32), og.pt_ref)
+        og.init(P0.im[sl], P0.dx[sl], P0.dy[sl])
+        g.InitializeGrid(dev(P0.im[sl])[None], dev(P0.dx[sl])[None], dev(P0.dy[sl])[None])
+        g.SetTargetImage(dev(P1.im[sl])[None])
+        if prev_o is not None:
+            og.init_from_coarser(prev_o)
+            g.InitializeFromCoarserOF(dev(prev_o)[None])
+        trace = np.zeros((og.nop, op.grad_descent_iter + 1, 4), np.float32)
+        F._lib.check(F.lib().fotg_grid_set_trace(ofc._h, sl, trace.ctypes.data_as(C.c_void_p)))
+        otrace = og.optimize(P1.im[sl], trace=True)
+        g.Optimize()
+        F.lib().fotg_grid_set_trace(ofc._h, sl, None)
+        st = g.read_state(0, taps=True)
+        assert np.array_equal(st["tmpl"], og.tmpl) and np.array_equal(st["tdx"], og.tdx) and np.array_equal(st["tdy"], og.tdy)
+        assert np.array_equal(st["hes"], og.hes)
+        assert np.array_equal(st["cnt"], og.cnt)
+        assert np.array_equal(trace, otrace), "per-iteration LK trace differs at scale %d" % sl
+        assert np.array_equal(st["p_iter"], og.p_iter)
+        assert np.array_equal(st["pweight"], og.pweight)
+        fo = og.aggregate()
+        fg = g.AggregateFlowDense()[0].cpu().numpy()
+        assert np.array_equal(fg, fo), "densified flow differs at scale %d" % sl
+        prev_o = fo
+
+
+@pytest.mark.parametrize("noc", [1, 3])
+def test_varref_golden_reference_vectors(noc):
+    """VarRefClass against outputs of the reference's own FDF1.0.1 code (tests/golden/fdf_ref_*.npz): every
+    intermediate plane of the last inner iteration and the refined flow, bit for bit"""
+    F, OFClass, VarRefClass, O = _mods()
+    for name, c in load_fdf(noc).items():
+        im1, im2, wx, wy, lvl = c["im1"], c["im2"], c["wx"], c["wy"], int(c["lvl"])
+        _, h, w = im1.shape
+        op = F.operating_point(2, 1024, noc)
+        op.coarsest_scale = op.finest_scale = lvl
+        ofc = OFClass(op, F.img_params(width=w << lvl, height=h << lvl, padding=8))
+        ps = 8
+        padlvl = lambda a: np.pad(a.transpose(1, 2, 0), ((ps, ps), (ps, ps), (0, 0)), mode="edge")
+        flow = dev(np.stack([wx, wy], -1))[None].contiguous()
+        VarRefClass(ofc, dev(padlvl(im1))[None], dev(padlvl(im2))[None], ofc.iparams[0], op, flow)
+        out = flow[0].cpu().numpy()
+        st = ((w + 3) // 4) * 4
+
+        def plane(nm, k=1):
+            buf = np.zeros((k, h, st), np.float32)
+            F._lib.check(F.lib().fotg_varref_plane(ofc._h, 0, nm.encode(), lvl, buf.ctypes.data))
+            return buf[:, :, :w]
+        for nm in ("mask", "sh", "sv", "a11", "a12", "a22", "b1", "b2", "du", "dv"):
+            ref = c[nm]
+            if nm in ("a11", "a12", "a22"):
+                continue            # the reference overwrites these in place with the block inverse; checked via du/dv
+            assert np.array_equal(plane(nm)[0], ref), (name, nm)
+        for nm in ("Ix", "Iy", "Iz", "Ixx", "Ixy", "Iyy", "Ixz", "Iyz"):
+            assert np.array_equal(plane(nm, noc), c[nm]), (name, nm)
+        assert np.array_equal(out[..., 0], c["out_x"]) and np.array_equal(out[..., 1], c["out_y"]), name
+
+
+@pytest.mark.parametrize("case,op_point,sor_mode", [("alley", 2, 0), ("alley", 2, 1), ("alley_rgb", 2, 0),
+                                                    ("synth_odd", 3, 0), ("synth_odd", 1, 0), ("synth_rgb", 2, 0)])
+def test_end_to_end_parity(case, op_point, sor_mode, alley):
+    """OFClass::calc on original (unpadded) frames == oracle pipeline, finest-scale flow and full-resolution flow"""
+    F, OFClass, _, O = _mods()
+    f0, f1, noc = frames(case, alley)
+    h, w = f0.shape[:2]
+    op = F.operating_point(op_point, w, noc, sor_mode=sor_mode)
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    out = ofc.calc(dev(f0), dev(f1), None, None, None)
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, sor_mode)
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref), "max abs diff %g" % np.abs(got - ref).max()
+    full = ofc.upsample_crop(out[None])[0].cpu().numpy()
+    wp, hp, padw, padh = O.padded_size(w, h, p.sc_f)
+    assert np.array_equal(full, O.upsample_crop(ref, p.sc_l, padw, padh, w, h))
+    # a second call on the same object gives the same answer (state is reset per call)
+    assert np.array_equal(ofc.calc(dev(f0), dev(f1)).cpu().numpy(), ref)
+
+
+def test_golden_flo(alley, alley_golden_flow):
+    """the reference's only golden output (kroeger/flows/alley_0001.flo): mean EPE <= 0.03 px, the same distance the
+    unmodified kroeger build has to it (0.026 / 0.17 / 0.50)"""
+    F, OFClass, _, O = _mods()
+    f0, f1, _ = frames("alley", alley)
+    op = F.operating_point(2, 1024, 1)
+    ofc = OFClass(op, F.img_params(width=1024, height=436, padding=8))
+    full = ofc.upsample_crop(ofc.calc(dev(f0), dev(f1))[None])[0].cpu().numpy()
+    e = epe(full, alley_golden_flow)
+    assert e.mean() < 0.03 and np.percentile(e, 99) < 0.2 and e.max() < 0.6
+
+
+def test_batch_1080p_parity_and_independence():
+    """BASELINE config: 1080p op-pt 2 + refinement, a batch; every pair equals the oracle and equals its own
+    single-pair result (pairs are independent; frame-pair sharding needs no exchange)"""
+    F, OFClass, _, O = _mods()
+    n = 4
+    pairs = [synth_pair(1080, 1920, seed=1234 + k) for k in range(n)]
+    I0 = dev(np.stack([p[0] for p in pairs])); I1 = dev(np.stack([p[1] for p in pairs]))
+    op = F.operating_point(2, 1920, 1)
+    ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=8), max_batch=n)
+    out = ofc.calc_batch(I0, I1).cpu().numpy()
+    assert out.shape == (n, 68, 120, 2)
+    p = oracle_params(O, op)
+    for k in (0, n - 1):
+        ref = O.flow(O.pad_frame(pairs[k][0], p.sc_f), O.pad_frame(pairs[k][1], p.sc_f), p, 0)
+        assert np.array_equal(out[k], ref)
+    single = OFClass(op, F.img_params(width=1920, height=1080, padding=8), max_batch=1)
+    assert np.array_equal(single.calc(I0[2], I1[2]).cpu().numpy(), out[2])
+    # recovered flow is sane: median close to the synthetic ground truth
+    _, _, gt = synth_pair(1080, 1920, seed=1234, truth=True)
+    full = ofc.upsample_crop(torch.from_numpy(out[:1]).cuda())[0].cpu().numpy()
+    assert np.median(epe(full, gt)) < 0.5
+
+
+def test_op4_quality_preset_small():
+    """op-pt 4 (ps=12, 128 iterations, 6 scales) on a small frame: ps=12 kernels (3 pixels per lane) + deep pyramid"""
+    F, OFClass, _, O = _mods()
+    f0, f1 = synth_pair(384, 640, seed=21)
+    op = F.operating_point(4, 640, 1)
+    assert (op.patch_size, op.grad_descent_iter) == (12, 128)
+    ofc = OFClass(op, F.img_params(width=640, height=384, padding=12))
+    got = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    assert np.array_equal(got, ref)
+
+
+def test_degenerate_inputs():
+    """flat frames (zero gradients -> det==0 Hessian path, patch.cpp:78-82) and identical frames"""
+    F, OFClass, _, O = _mods()
+    op = F.operating_point(2, 512, 1)
+    ofc = OFClass(op, F.img_params(width=512, height=256, padding=8))
+    p = oracle_params(O, op)
+    flat = np.full((256, 512), 37.0, np.float32)
+    out = ofc.calc(dev(flat), dev(flat)).cpu().numpy()
+    assert np.array_equal(out, O.flow(O.pad_frame(flat, p.sc_f), O.pad_frame(flat, p.sc_f), p, 0))
+    assert np.all(out == 0)
+    a, _ = synth_pair(256, 512, seed=3)
+    out = ofc.calc(dev(a), dev(a)).cpu().numpy()
+    assert np.array_equal(out, O.flow(O.pad_frame(a, p.sc_f), O.pad_frame(a, p.sc_f), p, 0))
+    big = np.roll(a, 60, axis=1)       # large motion: outlier resets / out-of-bounds starts
+    out = ofc.calc(dev(a), dev(big)).cpu().numpy()
+    assert np.array_equal(out, O.flow(O.pad_frame(a, p.sc_f), O.pad_frame(big, p.sc_f), p, 0))
+
+
+def test_errors():
+    F, OFClass, _, O = _mods()
+    op = F.operating_point(2, 512, 1)
+    ofc = OFClass(op, F.img_params(width=512, height=256, padding=8), max_batch=2)
+    with pytest.raises(F.FotgError):
+        ofc.calc_batch(torch.zeros((3, 256, 512), device="cuda"), torch.zeros((3, 256, 512), device="cuda"))   # > max_batch
+    with pytest.raises(F.FotgError):
+        ofc.calc(torch.zeros((128, 512), device="cuda"), torch.zeros((128, 512), device="cuda"))               # wrong size
+    bad = F.operating_point(2, 512, 1)
+    bad.patch_size = 10
+    with pytest.raises(F.FotgError):
+        OFClass(bad, F.img_params(width=512, height=256, padding=10))

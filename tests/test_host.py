@@ -1,0 +1,62 @@
+"""CPU tests of the host side: C-ABI library loads and exports every symbol include/fotg.h declares, host logic
+(operating points, padding, derived parameters) matches the reference tables, no compute calls."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import flowonthego_amd as F
+    hdr = open(os.path.join(ROOT, "include", "fotg.h")).read()
+    declared = set(re.findall(r"\b(fotg_[a-z_0-9]+)\s*\(", hdr))
+    declared.discard("fotg_ctx")
+    bound = {s[0] for s in F._lib.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    L = F.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.fotg_version()
+
+
+def test_operating_points_match_reference_table():
+    # src/run_dense.cpp:168-209 / kroeger/run_dense.cpp:225-268; SURVEY.md section 8
+    import flowonthego_amd as F
+    from oracle import oracle as O
+    for op_point in (1, 2, 3, 4):
+        for w in (640, 1024, 1920, 3840):
+            a, b = F.operating_point(op_point, w), O.op_point(op_point, w)
+            assert (a.coarsest_scale, a.finest_scale, a.patch_size, a.grad_descent_iter, int(a.use_var_ref)) == \
+                   (b.sc_f, b.sc_l, b.ps, b.max_iter, b.usetvref)
+            assert abs(a.patch_stride - b.patove) < 1e-6
+    op = F.operating_point(2, 1920)
+    assert (op.coarsest_scale, op.finest_scale, op.steps, op.n_vals, op.n_scales) == (6, 4, 4, 64, 3)
+    op = F.operating_point(4, 3840)
+    assert (op.coarsest_scale, op.finest_scale, op.steps) == (7, 2, 3)
+    assert F.AutoFirstScaleSelect(1024, 5, 8) == 5
+    assert F.padded_size(1920, 1080, 6) == (1920, 1088, 0, 8)
+    assert F.padded_size(1024, 436, 5) == (1024, 448, 0, 12)
+
+
+def test_status_strings_and_bad_arguments():
+    import ctypes as C
+    import flowonthego_amd as F
+    L = F.lib()
+    assert L.fotg_strerror(0) == b"ok" and L.fotg_strerror(3) == b"batch larger than max_batch"
+    assert L.fotg_op_point(2, -5, 1, F._lib.FotgParams()) == 1           # FOTG_ERR_ARG
+    assert L.fotg_op_point(2, 640, 2, F._lib.FotgParams()) == 1
+    assert L.fotg_padded_size(0, 10, 3, None, None, None, None) == 1
+    with pytest.raises(F.FotgError):
+        F._lib.check(1)
+
+
+def test_product_package_does_not_import_oracle():
+    """the oracle is test infrastructure: nothing under flowonthego_amd/ may reference it"""
+    pkg = os.path.join(ROOT, "flowonthego_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "dis_oracle" not in txt.replace("oracle/dis_oracle.c", ""), f
