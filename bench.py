@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- 1080p frame-pairs/s at DIS operating point 2 (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the whole hot path (pyramid+gradients -> per-scale LK -> densify -> variational refinement)
+over one batch of synthetic 1920x1080 frame pairs already resident in HBM (BASELINE.json configs[2]: batch 64,
+op-pt 2 + refinement on).  Frame pairs are independent, so N ranks each process their own batch (weak scaling, no
+data-path collective); value = pairs all ranks processed / max-over-ranks time.
+
+Extra objects in the JSON line:
+  roofline      for the dominant kernel of the step (by GPU time, measured live with HIP events on the launch stream)
+  cpu_baseline  the CPU oracle (oracle/, a scalar port of the reference's kroeger/ path) timed on this box's host
+                cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, OP_POINT = 1920, 1080, 2
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def synth_batch(n, seed, device):
+    """n synthetic 1080p gray pairs on the device, values on the 8-bit grid: band-limited texture (6 octaves of
+    bilinearly upsampled noise) and the same texture shifted by a smooth flow (global (5,2) px + +-2 px field)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    img = torch.zeros((n, 1, H, W), device=device)
+    for o, gs in enumerate((8, 16, 32, 64, 128, 256)):
+        noise = torch.rand((n, 1, max(2, gs * H // W), gs), generator=g).to(device) * 2 - 1
+        img += torch.nn.functional.interpolate(noise, size=(H, W), mode="bilinear", align_corners=True) / (o + 1)
+    mn, mx = img.amin(dim=(2, 3), keepdim=True), img.amax(dim=(2, 3), keepdim=True)
+    f0 = torch.round((img - mn) / (mx - mn) * 255.0)
+    yy, xx = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                            torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+    u = 5.0 + 2.0 * torch.sin(yy / H * 3.0) * torch.cos(xx / W * 2.0)
+    v = 2.0 + 2.0 * torch.cos(yy / H * 2.0 + 1.0) * torch.sin(xx / W * 3.0)
+    gx = ((xx - u) / (W - 1)) * 2 - 1
+    gy = ((yy - v) / (H - 1)) * 2 - 1
+    grid = torch.stack([gx, gy], -1)[None].expand(n, -1, -1, -1)
+    f1 = torch.round(torch.nn.functional.grid_sample(f0, grid, mode="bilinear", padding_mode="border", align_corners=True))
+    return f0[:, 0].contiguous(), f1[:, 0].contiguous()
+
+
+class HipEvents:
+    """hipEvent timing on an explicit stream (torch.cuda.Event only sees torch's current stream)"""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+
+    def time_ms(self, fn, stream, reps):
+        a, b = C.c_void_p(), C.c_void_p()
+        self.hip.hipEventCreate(a); self.hip.hipEventCreate(b)
+        fn()
+        self.hip.hipEventRecord(a, stream)
+        for _ in range(reps):
+            fn()
+        self.hip.hipEventRecord(b, stream)
+        self.hip.hipEventSynchronize(b)
+        ms = C.c_float()
+        self.hip.hipEventElapsedTime(ms, a, b)
+        return ms.value / reps
+
+
+def kernel_breakdown(ofc, I0, I1, out, lib, stream_ptr, reps=5):
+    """per-stage GPU time of one step, each stage launched alone between HIP events on the launch stream"""
+    from flowonthego_amd._lib import check
+    ev = HipEvents()
+    op, n, h = ofc.op, I0.shape[0], ofc._h
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = {}
+    st["pyramid(I0)+pyramid(I1)"] = ev.time_ms(lambda: (check(lib.fotg_pyramid(h, n, p(I0), 0, stream_ptr)),
+                                                        check(lib.fotg_pyramid(h, n, p(I1), 1, stream_ptr))), stream_ptr, reps)
+    check(lib.fotg_calc_batch(h, n, p(I0), p(I1), None, p(out), stream_ptr))      # leaves every level's state valid
+    for sl in range(op.coarsest_scale, op.finest_scale - 1, -1):
+        i0, s0 = ofc.level_ptr(0, sl, 0); ix, _ = ofc.level_ptr(0, sl, 1); iy, _ = ofc.level_ptr(0, sl, 2)
+        i1, _ = ofc.level_ptr(1, sl, 0)
+        st["lk[%d]" % sl] = ev.time_ms(lambda: check(lib.fotg_grid_optimize(h, sl, n, stream_ptr)), stream_ptr, reps)
+        fl = torch.empty((n, ofc.iparams[sl - op.finest_scale].height, ofc.iparams[sl - op.finest_scale].width, 2), device=I0.device)
+        st["densify[%d]" % sl] = ev.time_ms(lambda: check(lib.fotg_grid_aggregate(h, sl, n, p(fl), stream_ptr)), stream_ptr, reps)
+        if op.use_var_ref:
+            st["varref[%d]" % sl] = ev.time_ms(lambda: check(lib.fotg_varref(h, sl, n, C.c_void_p(i0), C.c_void_p(i1), s0, p(fl), stream_ptr)), stream_ptr, reps)
+    return st
+
+
+def cpu_baseline(I0, I1, budget_s=15.0):
+    """the oracle (scalar C port of the reference's kroeger/ path, pyramid included) on the host, one thread,
+    on the first pairs of the same batch until ~budget_s of CPU time is spent"""
+    from oracle import oracle as O
+    p = O.op_point(OP_POINT, W, 1)
+    done, t0 = 0, time.perf_counter()
+    while done < I0.shape[0] and (time.perf_counter() - t0) < budget_s:
+        a, b = I0[done].cpu().numpy(), I1[done].cpu().numpy()
+        t1 = time.perf_counter()
+        O.flow(O.pad_frame(a, p.sc_f), O.pad_frame(b, p.sc_f), p, 0)
+        done += 1
+        if done == 1:
+            first = time.perf_counter() - t1
+    el = time.perf_counter() - t0
+    return {"value": done / el, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d of the batch's 1080p pairs, op-pt 2 + refinement, pyramid included, oracle/libdis_oracle.so "
+                      "(gcc -O2, scalar, 1 thread) in %.1f s" % (done, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU per step (BASELINE configs[2]: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--sor-mode", type=int, default=0, help="0 lexicographic (reference order, parity mode), 1 red-black")
+    a = ap.parse_args()
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import flowonthego_amd as F
+    from flowonthego_amd.oflow import OFClass
+    lib = F.lib()                               # raises if libfotg.so is missing: no fallback
+    op = F.operating_point(OP_POINT, W, 1, sor_mode=a.sor_mode)
+    ofc = OFClass(op, F.img_params(width=W, height=H, padding=op.patch_size), max_batch=a.batch, device=local)
+    I0, I1 = synth_batch(a.batch, 1234 + rank, dev)
+    out = ofc.new_outflow(a.batch)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ofc.calc_batch(I0, I1, None, out)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ofc.calc_batch(I0, I1, None, out)
+    barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        el = float(t.item())
+    ms_step = el / a.steps * 1e3
+    value = world * a.batch * a.steps / el
+
+    res = {"metric": "frame-pairs/sec @1080p DIS op-pt 2", "value": value, "unit": "frame-pairs/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: batch=%d synthetic 1920x1080 gray f32 pairs per GPU, DIS op-pt 2 "
+                                  "(ps=8, stride 4, scales 6-5-4, 12 LK iterations) + variational refinement on, "
+                                  "%s SOR; inputs resident in HBM, output = finest-scale flow 120x68x2" %
+                                  (a.batch, "lexicographic (reference order)" if a.sor_mode == 0 else "red-black"),
+                      "global_batch": world * a.batch, "parallelism": "frame-pair sharding x%d (no collective)" % world}}
+
+    if rank == 0:
+        stream_ptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if not a.no_breakdown:
+            st = kernel_breakdown(ofc, I0, I1, out, lib, stream_ptr)
+            res["stage_ms"] = {k: round(v, 4) for k, v in st.items()}
+            # dominant kernel for the roofline: the pyramid base kernel is the only HBM-streaming kernel; it reads every
+            # input byte exactly once.  Algorithmic bytes per pair = 2*W*H*4 + 2*120*68*4.
+            from flowonthego_amd._lib import check
+            ev = HipEvents()
+            pI0 = C.c_void_p(I0.data_ptr())
+            ms = ev.time_ms(lambda: check(lib.fotg_pyramid(ofc._h, a.batch, pI0, 1, stream_ptr)), stream_ptr, 10)
+            alg = a.batch * (W * H * 4)                     # one launch = one frame of each of `batch` pairs
+            res["roofline"] = {"bound": "hbm", "kernel": "pyr_base_kernel<1,4> (+2 halve, +3 border launches, timed together)",
+                               "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "bytes_per_launch": alg, "ms_per_launch": ms}
+            res["whole_path_hbm_frac"] = value / world * (2 * W * H * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(I0, I1)
+        print(json.dumps(res))
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
