@@ -47,8 +47,11 @@ struct fotg_ctx {
   int *tap_cnt[FOTG_MAXLEV];
   float *trace_dev[FOTG_MAXLEV];
   bool taps;
-  float *vr;                         // refinement workspace
+  float *vr;                         // refinement workspace (planes)
   long vr_pair_stride;
+  float4 *vrC[FOTG_MAXLEV];          // skewed system per level (cells outside the image stay zero forever)
+  float2 *vrD[FOTG_MAXLEV];          // skewed (du,dv) per level
+  VrArgs vra[FOTG_MAXLEV];
   GridState gs[FOTG_MAXLEV];
 };
 
@@ -126,10 +129,11 @@ void fotg_destroy(fotg_ctx *c)
 {
   if (!c) return;
   for (int l = 0; l < FOTG_MAXLEV; ++l) {
-    (void)hipFree(c->im[0][l]); hipFree(c->im[1][l]); hipFree(c->dx0[l]); hipFree(c->dy0[l]);
-    (void)hipFree(c->flow[l]); hipFree(c->p_iter[l]); hipFree(c->pweight[l]);
-    (void)hipFree(c->tap_t[l]); hipFree(c->tap_tx[l]); hipFree(c->tap_ty[l]); hipFree(c->tap_hes[l]); hipFree(c->tap_cnt[l]);
+    (void)hipFree(c->im[0][l]); (void)hipFree(c->im[1][l]); (void)hipFree(c->dx0[l]); (void)hipFree(c->dy0[l]);
+    (void)hipFree(c->flow[l]); (void)hipFree(c->p_iter[l]); (void)hipFree(c->pweight[l]);
+    (void)hipFree(c->tap_t[l]); (void)hipFree(c->tap_tx[l]); (void)hipFree(c->tap_ty[l]); (void)hipFree(c->tap_hes[l]); (void)hipFree(c->tap_cnt[l]);
     (void)hipFree(c->trace_dev[l]);
+    (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]);
   }
   (void)hipFree(c->vr);
   delete c;
@@ -174,6 +178,24 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
     if (g.w < 3 || c->geom[p->sc_f].h < 5 || c->geom[p->sc_f].w < 3) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc);
     ALLOC(c->vr, B * c->vr_pair_stride * sizeof(float));
+    static const int ks[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int l = p->sc_l; l <= p->sc_f; ++l) {
+      const LevelGeom &gl = c->geom[l];
+      VrArgs &a = c->vra[l];
+      memset(&a, 0, sizeof(a));
+      a.base = c->vr; a.pair_stride = c->vr_pair_stride; a.w = gl.w; a.h = gl.h; a.st = gl.st; a.noc = c->noc;
+      a.pl = (long)gl.st * gl.h;
+      int K = 16;
+      for (int k : ks) if (k * 64 >= gl.h) { K = k; break; }
+      a.K = K; a.nlanes = (gl.h + K - 1) / K; a.RP = a.nlanes * K; a.RPD = ((a.RP + K + 1 + 1) / 2) * 2;      // + K padding rows for idle lanes, + 1 for the bottom neighbour
+      a.S = gl.w + gl.h - 1; a.SC = a.S + 1;        // one spare (zero) row: idle lanes read past the last row
+      a.c_pair_stride = (long)a.SC * a.RP * 2;
+      a.d_pair_stride = (long)(a.S + 1) * a.RPD;
+      ALLOC(c->vrC[l], B * a.c_pair_stride * sizeof(float4));
+      ALLOC(c->vrD[l], B * a.d_pair_stride * sizeof(float2));
+      if (hipMemset(c->vrC[l], 0, B * a.c_pair_stride * sizeof(float4)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+      a.C = c->vrC[l]; a.D = c->vrD[l];
+    }
   }
 #undef ALLOC
   *out = c;
@@ -391,12 +413,39 @@ int fotg_grid_read(fotg_ctx *c, int l, int pair, float *p_iter, float *pweight, 
 /* variational refinement                                                                           */
 /* ------------------------------------------------------------------------------------------------ */
 }  // extern "C"
+template <int K, int P>
+static void launch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
+{
+  vr_sor_kernel<K, P><<<n, 64, 0, s>>>(a, sweeps, omega);
+}
+
+static void dispatch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
+{
+  // prefetch depth: as deep as the register budget of K rows per lane allows, and 2P+2 <= S (ring never
+  // runs ahead into rows the current sweep has not rewritten yet)
+  const int cap = (a.S - 2) / 2;
+  auto pick = [&](int pmax) { int p = pmax; while (p > 1 && p > cap) p >>= 1; return p; };
+  switch (a.K) {
+    case 1: switch (pick(8)) { case 8: launch_sor<1, 8>(a, n, sweeps, omega, s); break; case 4: launch_sor<1, 4>(a, n, sweeps, omega, s); break;
+                               case 2: launch_sor<1, 2>(a, n, sweeps, omega, s); break; default: launch_sor<1, 1>(a, n, sweeps, omega, s); } break;
+    case 2: switch (pick(4)) { case 8: launch_sor<2, 8>(a, n, sweeps, omega, s); break; case 4: launch_sor<2, 4>(a, n, sweeps, omega, s); break;
+                               case 2: launch_sor<2, 2>(a, n, sweeps, omega, s); break; default: launch_sor<2, 1>(a, n, sweeps, omega, s); } break;
+    case 3: switch (pick(4)) { case 4: launch_sor<3, 4>(a, n, sweeps, omega, s); break; case 2: launch_sor<3, 2>(a, n, sweeps, omega, s); break;
+                               default: launch_sor<3, 1>(a, n, sweeps, omega, s); } break;
+    case 4: switch (pick(4)) { case 4: launch_sor<4, 4>(a, n, sweeps, omega, s); break; case 2: launch_sor<4, 2>(a, n, sweeps, omega, s); break;
+                               default: launch_sor<4, 1>(a, n, sweeps, omega, s); } break;
+    case 6: launch_sor<6, 1>(a, n, sweeps, omega, s); break;
+    case 8: launch_sor<8, 1>(a, n, sweeps, omega, s); break;
+    case 12: launch_sor<12, 1>(a, n, sweeps, omega, s); break;
+    default: launch_sor<16, 1>(a, n, sweeps, omega, s); break;
+  }
+}
+
 template <int NOC>
 static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *I1, long img_stride, float *flow, hipStream_t s)
 {
   const LevelGeom &g = c->geom[l];
-  VrArgs a;
-  a.base = c->vr; a.pair_stride = c->vr_pair_stride; a.w = g.w; a.h = g.h; a.st = g.st; a.noc = NOC; a.pl = (long)g.st * g.h;
+  const VrArgs &a = c->vra[l];
   const long fs = (long)g.w * g.h * 2;
   dim3 grid((g.w * g.h + 255) / 256, n), block(256);
   // kroeger/refine_variational.cpp:31-43
@@ -404,6 +453,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   const float half_gamma_over3 = c->p.tv_gamma * 0.5f / 3.0f;
   const float half_delta_over3 = c->p.tv_delta * 0.5f / 3.0f;
   const int inner = c->p.tv_innerit * (l + 1);
+  HIPCHK(hipMemsetAsync(a.D, 0, (size_t)n * a.d_pair_stride * sizeof(float2), s));      // image_erase(du), image_erase(dv) (:185-186)
   vr_prep_kernel<NOC><<<grid, block, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
   LAUNCHCHK();
   vr_deriv1_kernel<NOC><<<grid, block, 0, s>>>(a);
@@ -411,13 +461,11 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   vr_deriv2_kernel<NOC><<<grid, block, 0, s>>>(a);
   LAUNCHCHK();
   for (int it = 0; it < inner; ++it) {
-    vr_smooth_kernel<<<grid, block, 0, s>>>(a, quarter_alpha);
-    LAUNCHCHK();
-    vr_data_kernel<NOC><<<grid, block, 0, s>>>(a, half_delta_over3, half_gamma_over3);
+    vr_data_kernel<NOC><<<grid, block, 0, s>>>(a, quarter_alpha, half_delta_over3, half_gamma_over3);
     LAUNCHCHK();
     if (c->p.tv_solverit > 0) {
       if (c->p.sor_mode == FOTG_SOR_REDBLACK) vr_sor_redblack_kernel<<<n, 1024, 0, s>>>(a, c->p.tv_solverit, c->p.tv_sor);
-      else vr_sor_wavefront_kernel<<<n, ((g.h + 63) / 64) * 64, 0, s>>>(a, c->p.tv_solverit, c->p.tv_sor);
+      else dispatch_sor(a, n, c->p.tv_solverit, c->p.tv_sor, s);
       LAUNCHCHK();
     }
   }
@@ -440,9 +488,11 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
 {
   int st = check_level(c, l, 1); if (st) return st;
   if (!name || !host_out || !c->vr || pair < 0 || pair >= c->max_batch) return FOTG_ERR_ARG;
-  static const char *singles[] = {"wx", "wy", "du", "dv", "mask", "s", "sh", "sv", "a11", "a12", "a22", "b1", "b2"};
+  static const char *singles[] = {"wx", "wy", "mask"};
   static const char *colors[] = {"avg", "Iz", "Ix", "Iy", "Ixx", "Ixy", "Iyy", "Ixz", "Iyz"};
+  static const char *sys[] = {"a11", "a12", "a22", "b1", "b2", "sh", "sv", "svt"};
   const LevelGeom &g = c->geom[l];
+  const VrArgs &a = c->vra[l];
   const size_t pl = (size_t)g.st * g.h;
   HIPCHK(hipDeviceSynchronize());
   for (int i = 0; i < P_NSINGLE; ++i)
@@ -456,6 +506,29 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
                        pl * c->noc * 4, hipMemcpyDeviceToHost));
       return FOTG_OK;
     }
+  // planes that live in the skewed solver arrays: copy and de-skew on the host
+  for (int k = 0; k < 8; ++k)
+    if (!strcmp(name, sys[k])) {
+      float *tmp = (float *)malloc((size_t)a.c_pair_stride * sizeof(float4));
+      if (!tmp) return FOTG_ERR_ARG;
+      hipError_t e = hipMemcpy(tmp, a.C + (size_t)pair * a.c_pair_stride, (size_t)a.c_pair_stride * sizeof(float4), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { free(tmp); g_last_hip = (int)e; return FOTG_ERR_HIP; }
+      memset(host_out, 0, pl * 4);
+      for (int j = 0; j < g.h; ++j) for (int i = 0; i < g.w; ++i) host_out[(size_t)j * g.st + i] = tmp[a.cidx(i, j) * 4 + k];
+      free(tmp);
+      return FOTG_OK;
+    }
+  if (!strcmp(name, "du") || !strcmp(name, "dv")) {
+    float *tmp = (float *)malloc((size_t)a.d_pair_stride * sizeof(float2));
+    if (!tmp) return FOTG_ERR_ARG;
+    hipError_t e = hipMemcpy(tmp, a.D + (size_t)pair * a.d_pair_stride, (size_t)a.d_pair_stride * sizeof(float2), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(tmp); g_last_hip = (int)e; return FOTG_ERR_HIP; }
+    memset(host_out, 0, pl * 4);
+    const int comp = name[1] == 'v';
+    for (int j = 0; j < g.h; ++j) for (int i = 0; i < g.w; ++i) host_out[(size_t)j * g.st + i] = tmp[a.didx(i, j) * 2 + comp];
+    free(tmp);
+    return FOTG_OK;
+  }
   return FOTG_ERR_ARG;
 }
 

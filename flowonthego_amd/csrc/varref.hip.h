@@ -1,30 +1,48 @@
 // varref.hip.h -- variational refinement of one pyramid level
 // (kroeger/refine_variational.cpp:25-241 driving FDF1.0.1/{opticalflow_aux,solver,image}.c).
 //
-// All planes use the FDF image_t layout (stride = ceil4(w), FDF1.0.1/image.c:15-31), one set per pair:
-//   wx wy du dv mask s sh sv a11 a12 a22 b1 b2          (13 single planes)
+// Planes use the FDF image_t layout (stride = ceil4(w), FDF1.0.1/image.c:15-31), one set per pair:
+//   wx wy mask                                          (3 single planes)
 //   avg Iz Ix Iy Ixx Ixy Iyy Ixz Iyz                    (9 x NOC planes, channel-planar like color_image_t)
-// Kernels (per inner iteration: smooth -> data -> sor):
+// plus the solver's skewed arrays C (system) and D (du,dv), see VrArgs.
+// Kernels (per inner iteration: data -> sor):
 //   vr_prep     de-interleave flow, image_warp + mask (opticalflow_aux.c:18-60), 0.5*(I0+Iw), Iw-I0 (:80-83)
 //   vr_deriv1/2 the seven 5-tap derivative images (opticalflow_aux.c:85-92, image.c:401-434,466-502)
-//   vr_smooth   s = 1/4 alpha / sqrt(|grad uu|^2+|grad vv|^2+eps)  (opticalflow_aux.c:123-139), uu = wx+du on the fly
-//   vr_data     sh/sv (:141-163), data term (:310-438), sub_laplacian (:172-199, gather form),
-//               and the 2x2 block inverse of sor_coupled's first sweep (solver.c:115-120)
-//   vr_sor_*    the sweeps of sor_coupled (solver.c:77-421)
+//   vr_data     smoothness s = 1/4 alpha / sqrt(|grad uu|^2+|grad vv|^2+eps) with uu = wx+du on the fly
+//               (opticalflow_aux.c:123-139) and its pair sums (:141-163), data term (:310-438), sub_laplacian
+//               (:172-199, gather form), the 2x2 block inverse of sor_coupled's first sweep (solver.c:115-120);
+//               writes the skewed system C
+//   vr_sor      the sweeps of sor_coupled (solver.c:77-421) as a register-pipelined single-wave wavefront
 //   vr_finish   flow = (wx+du, wy+dv) (refine_variational.cpp:208-221)
 #pragma once
 #include "common.h"
 
 namespace fotg {
 
-enum VrPlane { P_WX = 0, P_WY, P_DU, P_DV, P_MASK, P_S, P_SH, P_SV, P_A11, P_A12, P_A22, P_B1, P_B2, P_NSINGLE };
+enum VrPlane { P_WX = 0, P_WY, P_MASK, P_NSINGLE };
 enum VrCPlane { C_AVG = 0, C_IZ, C_IX, C_IY, C_IXX, C_IXY, C_IYY, C_IXZ, C_IYZ, C_NCOLOR };
 
+// Skewed (anti-diagonal major) arrays used by the solver: cell (i,j) of the image lives at [i+j][j].
+//   C[s][r] = {a11,a12,a22 (2x2 block inverse), b1, b2, psi_right, psi_bottom, psi_top}   8 floats
+//   D[s][r] = {du, dv}                                                                     2 floats
+// Row s holds exactly the pixels the lexicographic sweep may process together (step s of the wavefront),
+// contiguous in the row index r, so one wave reads/writes a step with fully coalesced 16-B / 8-B accesses.
+// Cells outside the image stay zero for the life of the context (C) / of a refinement (D); a zero cell is a
+// fixed point of the update, so the solver needs no bounds predicates.
 struct VrArgs {
   float *base;           // workspace of pair 0
   long pair_stride;      // floats between pairs
   long pl;               // floats per plane (st*h)
   int w, h, st, noc;
+  float4 *C;             // [pair][SC][RP][2] float4
+  float2 *D;             // [pair][SC+1][RPD] float2
+  long c_pair_stride;    // in float4
+  long d_pair_stride;    // in float2
+  int S, SC, RP, RPD, K, nlanes;
+  __host__ __device__ float4 *Cp(int pair) const { return C + (size_t)pair * c_pair_stride; }
+  __host__ __device__ float2 *Dp(int pair) const { return D + (size_t)pair * d_pair_stride; }
+  __host__ __device__ size_t cidx(int i, int j) const { return ((size_t)(i + j) * RP + j) * 2; }
+  __host__ __device__ size_t didx(int i, int j) const { return (size_t)(i + j) * RPD + j; }
   __host__ __device__ float *single(int pair, int p) const { return base + (size_t)pair * pair_stride + (size_t)p * pl; }
   __host__ __device__ float *color(int pair, int p, int c) const {
     return base + (size_t)pair * pair_stride + (size_t)(P_NSINGLE + p * noc + c) * pl;
@@ -63,8 +81,6 @@ __global__ __launch_bounds__(256) void vr_prep_kernel(VrArgs a, const float *__r
   const float wx = f[0], wy = f[1];
   a.single(pair, P_WX)[o] = wx;
   a.single(pair, P_WY)[o] = wy;
-  a.single(pair, P_DU)[o] = 0.f;
-  a.single(pair, P_DV)[o] = 0.f;
   // image_warp (opticalflow_aux.c:18-60)
   const float xx = i + wx, yy = j + wy;
   const int x = (int)floorf(xx), y = (int)floorf(yy);
@@ -115,46 +131,57 @@ __global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
   }
 }
 
-// compute_smoothness, first half (opticalflow_aux.c:126-139); 3-tap {-0.5,-0,0.5} (image.c:376-399,436-464)
-__global__ __launch_bounds__(256) void vr_smooth_kernel(VrArgs a, float quarter_alpha)
+// smoothness weight from the 3x3 cross of (uu,vv): compute_smoothness first half (opticalflow_aux.c:126-139);
+// 3-tap {-0.5,-0,0.5} with the border rows of convolve_vert_fast_3 / replicate columns of convolve_horiz_fast_3
+// (image.c:376-399,436-464).  l,c,r = left/centre/right, t,b = top/bottom (t or b unused on the border rows).
+__device__ __forceinline__ float smooth_w(float2 l, float2 c, float2 r, float2 t, float2 b, int j, int h, float quarter_alpha)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.w * a.h) return;
-  const int pair = blockIdx.y, i = idx % a.w, j = idx / a.w, st = a.st, w = a.w, h = a.h;
-  const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY), *du = a.single(pair, P_DU), *dv = a.single(pair, P_DV);
-  auto UU = [&](int jj, int ii) { const int q = jj * st + ii; return wx[q] + du[q]; };   // refine_variational.cpp:208-214
-  auto VV = [&](int jj, int ii) { const int q = jj * st + ii; return wy[q] + dv[q]; };
   const float c0 = -0.5f, c1 = -0.0f, c2 = 0.5f;
-  const int im = clampi(i - 1, w), ip = clampi(i + 1, w);
-  const float ux = c0 * UU(j, im) + c1 * UU(j, i) + c2 * UU(j, ip);
-  const float vx = c0 * VV(j, im) + c1 * VV(j, i) + c2 * VV(j, ip);
+  const float ux = c0 * l.x + c1 * c.x + c2 * r.x;
+  const float vx = c0 * l.y + c1 * c.y + c2 * r.y;
   float uy, vy;
-  if (j == 0) { uy = (c0 + c1) * UU(0, i) + c2 * UU(1, i); vy = (c0 + c1) * VV(0, i) + c2 * VV(1, i); }
-  else if (j == h - 1) { uy = c0 * UU(j - 1, i) + (c1 + c2) * UU(j, i); vy = c0 * VV(j - 1, i) + (c1 + c2) * VV(j, i); }
-  else { uy = c0 * UU(j - 1, i) + c1 * UU(j, i) + c2 * UU(j + 1, i); vy = c0 * VV(j - 1, i) + c1 * VV(j, i) + c2 * VV(j + 1, i); }
+  if (j == 0) { uy = (c0 + c1) * c.x + c2 * b.x; vy = (c0 + c1) * c.y + c2 * b.y; }
+  else if (j == h - 1) { uy = c0 * t.x + (c1 + c2) * c.x; vy = c0 * t.y + (c1 + c2) * c.y; }
+  else { uy = c0 * t.x + c1 * c.x + c2 * b.x; vy = c0 * t.y + c1 * c.y + c2 * b.y; }
   const float eps = 0.001f * 0.001f;
-  a.single(pair, P_S)[j * st + i] = quarter_alpha / sqrtf(ux * ux + uy * uy + vx * vx + vy * vy + eps);
+  return quarter_alpha / sqrtf(ux * ux + uy * uy + vx * vx + vy * vy + eps);
 }
 
 template <int NOC>
-__global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float half_delta_over3, float half_gamma_over3)
+__global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_alpha, float half_delta_over3, float half_gamma_over3)
 {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.w * a.h) return;
   const int pair = blockIdx.y, i = idx % a.w, j = idx / a.w, st = a.st, w = a.w, h = a.h, o = j * st + i;
-  const float *s = a.single(pair, P_S);
-  // compute_smoothness second half (:141-163): horiz(i) = s(i)+s(i+1) (0 in the last column), vert likewise
-  const float s_o = s[o];
-  const float hr = (i < w - 1) ? s_o + s[o + 1] : 0.0f;
-  const float hl = (i > 0) ? s[o - 1] + s_o : 0.0f;
-  const float vb = (j < h - 1) ? s_o + s[o + st] : 0.0f;
-  const float vt = (j > 0) ? s[o - st] + s_o : 0.0f;
-  a.single(pair, P_SH)[o] = hr;
-  a.single(pair, P_SV)[o] = vb;
+  const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
+  const float2 *D = a.Dp(pair);
+  // (uu,vv) = (wx+du, wy+dv) (refine_variational.cpp:208-214) on the 13-point diamond around (i,j), clamped like the
+  // replicate borders of the 3-tap filters; du,dv come from the skewed D
+  auto UV = [&](int jj, int ii) {
+    jj = clampi(jj, h); ii = clampi(ii, w);
+    const int q = jj * st + ii;
+    const float2 d = D[a.didx(ii, jj)];
+    return make_float2(wx[q] + d.x, wy[q] + d.y);
+  };
+  const float2 cc = UV(j, i), l1 = UV(j, i - 1), l2 = UV(j, i - 2), r1 = UV(j, i + 1), r2 = UV(j, i + 2);
+  const float2 t1 = UV(j - 1, i), t2 = UV(j - 2, i), b1 = UV(j + 1, i), b2 = UV(j + 2, i);
+  const float2 tl = UV(j - 1, i - 1), tr = UV(j - 1, i + 1), bl = UV(j + 1, i - 1), br = UV(j + 1, i + 1);
+  // compute_smoothness (:123-163): horiz(i) = s(i)+s(i+1) (0 in the last column), vert likewise.
+  // Horizontal neighbours clamp the column (replicate), e.g. the left pixel's own left is column max(i-2,0).
+  const float s_o = smooth_w(l1, cc, r1, t1, b1, j, h, quarter_alpha);
+  const float s_r = smooth_w(cc, r1, r2, tr, br, j, h, quarter_alpha);           // pixel (i+1, j)
+  const float s_l = smooth_w(l2, l1, cc, tl, bl, j, h, quarter_alpha);           // pixel (i-1, j)
+  const float s_b = smooth_w(bl, b1, br, cc, b2, j + 1, h, quarter_alpha);       // pixel (i, j+1)
+  const float s_t = smooth_w(tl, t1, tr, t2, cc, j - 1, h, quarter_alpha);       // pixel (i, j-1)
+  const float hr = (i < w - 1) ? s_o + s_r : 0.0f;
+  const float hl = (i > 0) ? s_l + s_o : 0.0f;
+  const float vb = (j < h - 1) ? s_o + s_b : 0.0f;
+  const float vt = (j > 0) ? s_t + s_o : 0.0f;
 
   // compute_data (:310-438)
   const float dnorm = 0.1f * 0.1f, epsc = 0.001f * 0.001f, epsg = 0.001f * 0.001f;
-  const float u = a.single(pair, P_DU)[o], v = a.single(pair, P_DV)[o], m = a.single(pair, P_MASK)[o];
+  const float2 duv = D[a.didx(i, j)];
+  const float u = duv.x, v = duv.y, m = a.single(pair, P_MASK)[o];
   float A11 = 0, A12 = 0, A22 = 0, B1 = 0, B2 = 0;
   if constexpr (NOC == 1) {
     const float Ix = a.color(pair, C_IX, 0)[o], Iy = a.color(pair, C_IY, 0)[o], Iz = a.color(pair, C_IZ, 0)[o];
@@ -225,7 +252,6 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float half_delta
   }
 
   // sub_laplacian (:172-199) for b1 (src wx) and b2 (src wy): -left, +right, -top, +bottom
-  const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
   if (i > 0)     { B1 -= hl * (wx[o] - wx[o - 1]);  B2 -= hl * (wy[o] - wy[o - 1]); }
   if (i < w - 1) { B1 += hr * (wx[o + 1] - wx[o]);  B2 += hr * (wy[o + 1] - wy[o]); }
   if (j > 0)     { B1 -= vt * (wx[o] - wx[o - st]); B2 -= vt * (wy[o] - wy[o - st]); }
@@ -237,62 +263,103 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float half_delta
   if (j < h - 1) dps = dps + vb;
   const float M11 = A22 + dps, M22 = A11 + dps;
   const float det = M11 * M22 - A12 * A12;
-  a.single(pair, P_A11)[o] = M11 / det;
-  a.single(pair, P_A22)[o] = M22 / det;
-  a.single(pair, P_A12)[o] = A12 / -det;
-  a.single(pair, P_B1)[o] = B1;
-  a.single(pair, P_B2)[o] = B2;
+  float4 *C = a.Cp(pair) + a.cidx(i, j);
+  C[0] = make_float4(M11 / det, A12 / -det, M22 / det, B1);
+  C[1] = make_float4(B2, hr, vb, vt);
 }
 
-// one pixel update of sor_coupled (solver.c:122-130 etc.); du_l/du_t are the NEW left/top values
-__device__ __forceinline__ void sor_update(float &du, float &dv, float a11, float a12, float a22, float b1, float b2,
-                                           float hl, float hr, float vt, float vb, float du_l, float dv_l, float du_t,
-                                           float dv_t, float du_r, float dv_r, float du_b, float dv_b, bool has_l,
-                                           bool has_t, bool has_b, float omega)
+// one pixel update of sor_coupled (solver.c:122-130 etc.).  du_l/du_t are the NEW left/top values, du_r/du_b the OLD
+// right/bottom ones.  The reference skips the terms of missing neighbours; here their weights (psi) are exactly 0 and
+// the neighbour values finite, so the skipped terms add +-0 and the sums are the same floats.
+__device__ __forceinline__ float2 sor_update(float2 cur, float4 c0, float4 c1, float hl, float2 left, float2 top, float2 right, float2 bottom, float omega)
 {
-  float s1 = hr * du_r, s2 = hr * dv_r;
-  if (has_t) { s1 = s1 + vt * du_t; s2 = s2 + vt * dv_t; }
-  if (has_b) { s1 = s1 + vb * du_b; s2 = s2 + vb * dv_b; }
-  s1 = s1 + b1; s2 = s2 + b2;
-  float B1 = s1, B2 = s2;
-  if (has_l) { B1 = hl * du_l + s1; B2 = hl * dv_l + s2; }
-  du += omega * (a11 * B1 + a12 * B2 - du);
-  dv += omega * (a12 * B1 + a22 * B2 - dv);
+  const float a11 = c0.x, a12 = c0.y, a22 = c0.z, b1 = c0.w, b2 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
+  float s1 = hr * right.x, s2 = hr * right.y;
+  s1 = s1 + vt * top.x;    s2 = s2 + vt * top.y;
+  s1 = s1 + vb * bottom.x; s2 = s2 + vb * bottom.y;
+  s1 = s1 + b1;            s2 = s2 + b2;
+  const float B1 = hl * left.x + s1, B2 = hl * left.y + s2;
+  float2 r;
+  r.x = cur.x + omega * (a11 * B1 + a12 * B2 - cur.x);
+  r.y = cur.y + omega * (a12 * B1 + a22 * B2 - cur.y);
+  return r;
 }
 
-// Lexicographic sweeps as an anti-diagonal wavefront: pixel (i,j) runs at step i+j, after its NEW left
-// (i-1,j) and top (i,j-1) neighbours (step i+j-1) and before its OLD right/bottom neighbours (step
-// i+j+1) -- exactly the dependency order of the row-major loop of solver.c, hence bit-identical.
-// One workgroup per pair, thread r owns row r; the top neighbour's fresh value travels through LDS.
-__global__ __launch_bounds__(1024) void vr_sor_wavefront_kernel(VrArgs a, int iterations, float omega)
+__device__ __forceinline__ float dpp_wave_shr1(float v)
 {
-  __shared__ float xdu[2][1024], xdv[2][1024];
-  const int pair = blockIdx.x, r = threadIdx.x, w = a.w, h = a.h, st = a.st;
-  float *du = a.single(pair, P_DU), *dv = a.single(pair, P_DV);
-  const float *a11 = a.single(pair, P_A11), *a12 = a.single(pair, P_A12), *a22 = a.single(pair, P_A22);
-  const float *b1 = a.single(pair, P_B1), *b2 = a.single(pair, P_B2), *sh = a.single(pair, P_SH), *sv = a.single(pair, P_SV);
-  const bool row = r < h;
-  for (int it = 0; it < iterations; ++it) {
-    float du_l = 0.f, dv_l = 0.f;
-    for (int s = 0; s < w + h - 1; ++s) {
-      const int i = s - r;
-      float ndu = 0.f, ndv = 0.f;
-      if (row && i >= 0 && i < w) {
-        const int o = r * st + i;
-        float cu = du[o], cv = dv[o];
-        const bool has_r = i < w - 1, has_t = r > 0, has_b = r < h - 1;
-        const float du_r = has_r ? du[o + 1] : 0.f, dv_r = has_r ? dv[o + 1] : 0.f;
-        const float du_b = has_b ? du[o + st] : 0.f, dv_b = has_b ? dv[o + st] : 0.f;
-        const float du_t = has_t ? xdu[(s + 1) & 1][r - 1] : 0.f, dv_t = has_t ? xdv[(s + 1) & 1][r - 1] : 0.f;
-        const float hl = i > 0 ? sh[o - 1] : 0.f, vt = has_t ? sv[o - st] : 0.f;
-        sor_update(cu, cv, a11[o], a12[o], a22[o], b1[o], b2[o], hl, sh[o], vt, sv[o], du_l, dv_l, du_t, dv_t,
-                   du_r, dv_r, du_b, dv_b, i > 0, has_t, has_b, omega);
-        du[o] = cu; dv[o] = cv;
-        du_l = cu; dv_l = cv;
-        ndu = cu; ndv = cv;
-      }
-      if (r < 1024) { xdu[s & 1][r] = ndu; xdv[s & 1][r] = ndv; }
-      __syncthreads();
+  // lane L reads lane L-1 (wave_shr:1, GFX9 DPP); lane 0 gets 0 (bound_ctrl)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+
+// Lexicographic sweeps as an anti-diagonal wavefront: pixel (i,j) runs at step i+j, after its NEW left (i-1,j) and
+// top (i,j-1) neighbours (step i+j-1) and before its OLD right/bottom neighbours (step i+j+1) -- the dependency
+// order of the row-major loop of solver.c, hence bit-identical.
+// ONE WAVE PER PAIR, no barriers: lane L owns rows K*L..K*L+K-1.  The fresh top value of a lane's first row comes
+// from lane L-1 by DPP; left values stay in registers; everything else is old data streamed from the skewed arrays
+// P steps ahead through a register ring (coalesced 16-B/8-B loads), so the loop runs at the speed of its
+// ~10-instruction dependency chain, not at memory latency.
+template <int K, int P>
+__global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float omega)
+{
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  // lanes beyond the image own K padding rows (columns RP.. of D, all zero) and run with omega = 0: they read
+  // zeros, compute zeros and write zeros, so the loop body needs no exec-mask branches at all
+  const bool act = lane < a.nlanes;
+  const int r0 = act ? lane * K : a.RP;
+  const float om_lane = act ? omega : 0.f;
+  const float4 *__restrict__ C = a.Cp(pair);
+  float2 *D = a.Dp(pair);
+  const int S = a.S, RP = a.RP, RPD = a.RPD;
+  const int T = sweeps * S;
+  struct Stage { float4 c[K][2]; float2 own[K]; float2 nxt[K + 1]; };
+  Stage ring[P];
+  // wave-uniform row base (SGPR) + constant per-lane byte offset (VGPR): the loads use the saddr form and the
+  // per-step address arithmetic is scalar
+  const char *Cb = reinterpret_cast<const char *>(C);
+  char *Db = reinterpret_cast<char *>(D);
+  const unsigned c_lane = (unsigned)r0 * 32u, d_lane = (unsigned)r0 * 8u;
+  const unsigned c_row = (unsigned)RP * 32u, d_row = (unsigned)RPD * 8u;
+  auto issue = [&](Stage &st, int row) {
+    const float4 *cp = reinterpret_cast<const float4 *>(Cb + (size_t)((unsigned)row * c_row) + c_lane);
+#pragma unroll
+    for (int m = 0; m < K; ++m) { st.c[m][0] = cp[2 * m]; st.c[m][1] = cp[2 * m + 1]; }
+    const float2 *d0 = reinterpret_cast<const float2 *>(Db + (size_t)((unsigned)row * d_row) + d_lane);
+    const float2 *d1 = reinterpret_cast<const float2 *>(Db + (size_t)((unsigned)(row + 1) * d_row) + d_lane);
+#pragma unroll
+    for (int m = 0; m < K; ++m) st.own[m] = d0[m];
+#pragma unroll
+    for (int m = 0; m <= K; ++m) st.nxt[m] = d1[m];
+  };
+#pragma unroll
+  for (int p = 0; p < P; ++p) issue(ring[p], p);          // host guarantees S >= 2P+2
+  float2 prev[K];          // results of the previous step (new left / new top of the lane's own rows)
+  float hl[K];
+#pragma unroll
+  for (int m = 0; m < K; ++m) { prev[m] = make_float2(0.f, 0.f); hl[m] = 0.f; }
+  int s = 0, sp = P;       // row of the current step, row being prefetched
+  // Straight-line body, one back edge: steps past T (T rounded up to a multiple of P) run with omega = 0, i.e.
+  // rewrite the values they loaded, so no per-step bounds branch is needed and the compiler's s_waitcnt counting
+  // stays exact (each use waits only for its own stage, P steps old).
+  for (int t0 = 0; t0 < T; t0 += P) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      Stage &st = ring[p];
+      const float om = (t0 + p < T) ? om_lane : 0.f;
+      float2 top0;
+      top0.x = dpp_wave_shr1(prev[K - 1].x);
+      top0.y = dpp_wave_shr1(prev[K - 1].y);
+      float2 res[K];
+#pragma unroll
+      for (int m = 0; m < K; ++m)
+        res[m] = sor_update(st.own[m], st.c[m][0], st.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], st.nxt[m], st.nxt[m + 1], om);
+      float2 *dst = reinterpret_cast<float2 *>(Db + (size_t)((unsigned)s * d_row) + d_lane);
+#pragma unroll
+      for (int m = 0; m < K; ++m) dst[m] = res[m];
+#pragma unroll
+      for (int m = 0; m < K; ++m) { prev[m] = res[m]; hl[m] = st.c[m][1].y; }
+      issue(st, sp);
+      s = (s + 1 == S) ? 0 : s + 1;
+      sp = (sp + 1 == S) ? 0 : sp + 1;
     }
   }
 }
@@ -300,23 +367,19 @@ __global__ __launch_bounds__(1024) void vr_sor_wavefront_kernel(VrArgs a, int it
 // red-black ordering of the same block update (throughput mode; deviates from the reference by ~0.07 px)
 __global__ __launch_bounds__(1024) void vr_sor_redblack_kernel(VrArgs a, int iterations, float omega)
 {
-  const int pair = blockIdx.x, w = a.w, h = a.h, st = a.st;
-  float *du = a.single(pair, P_DU), *dv = a.single(pair, P_DV);
-  const float *a11 = a.single(pair, P_A11), *a12 = a.single(pair, P_A12), *a22 = a.single(pair, P_A22);
-  const float *b1 = a.single(pair, P_B1), *b2 = a.single(pair, P_B2), *sh = a.single(pair, P_SH), *sv = a.single(pair, P_SV);
+  const int pair = blockIdx.x, w = a.w, h = a.h;
+  const float4 *C = a.Cp(pair);
+  float2 *D = a.Dp(pair);
+  const float2 z = make_float2(0.f, 0.f);
   for (int it = 0; it < iterations; ++it)
     for (int col = 0; col < 2; ++col) {
       for (int idx = threadIdx.x; idx < w * h; idx += blockDim.x) {
         const int i = idx % w, j = idx / w;
         if (((i + j) & 1) != col) continue;
-        const int o = j * st + i;
-        float cu = du[o], cv = dv[o];
-        const bool has_l = i > 0, has_r = i < w - 1, has_t = j > 0, has_b = j < h - 1;
-        sor_update(cu, cv, a11[o], a12[o], a22[o], b1[o], b2[o], has_l ? sh[o - 1] : 0.f, sh[o], has_t ? sv[o - st] : 0.f, sv[o],
-                   has_l ? du[o - 1] : 0.f, has_l ? dv[o - 1] : 0.f, has_t ? du[o - st] : 0.f, has_t ? dv[o - st] : 0.f,
-                   has_r ? du[o + 1] : 0.f, has_r ? dv[o + 1] : 0.f, has_b ? du[o + st] : 0.f, has_b ? dv[o + st] : 0.f,
-                   has_l, has_t, has_b, omega);
-        du[o] = cu; dv[o] = cv;
+        const float4 *c = C + a.cidx(i, j);
+        const float hl = i > 0 ? C[a.cidx(i - 1, j) + 1].y : 0.f;
+        D[a.didx(i, j)] = sor_update(D[a.didx(i, j)], c[0], c[1], hl, i > 0 ? D[a.didx(i - 1, j)] : z, j > 0 ? D[a.didx(i, j - 1)] : z,
+                                     i < w - 1 ? D[a.didx(i + 1, j)] : z, j < h - 1 ? D[a.didx(i, j + 1)] : z, omega);
       }
       __syncthreads();
     }
@@ -328,8 +391,9 @@ __global__ __launch_bounds__(256) void vr_finish_kernel(VrArgs a, float *__restr
   if (idx >= a.w * a.h) return;
   const int pair = blockIdx.y, i = idx % a.w, j = idx / a.w, o = j * a.st + i;
   float *f = flow + (size_t)pair * flow_stride + 2 * (size_t)idx;
-  f[0] = a.single(pair, P_WX)[o] + a.single(pair, P_DU)[o];
-  f[1] = a.single(pair, P_WY)[o] + a.single(pair, P_DV)[o];
+  const float2 d = a.Dp(pair)[a.didx(i, j)];
+  f[0] = a.single(pair, P_WX)[o] + d.x;
+  f[1] = a.single(pair, P_WY)[o] + d.y;
 }
 
 }  // namespace fotg

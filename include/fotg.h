@@ -117,7 +117,7 @@ int fotg_grid_set_trace(fotg_ctx *ctx, int level, float *trace_host);
 int fotg_varref(fotg_ctx *ctx, int level, int n, const float *I0, const float *I1, long pair_stride,
                 float *flow, void *stream);
 /* test tap: copy one refinement workspace plane (stride-padded, FDF image_t layout) of pair `pair` to host.
- * name: "wx","wy","du","dv","mask","s","sh","sv","a11","a12","a22","b1","b2","avg","Iz","Ix","Iy","Ixx","Ixy","Iyy","Ixz","Iyz" */
+ * name: "wx","wy","mask","du","dv","sh","sv","a11","a12","a22" (block inverse),"b1","b2","avg","Iz","Ix","Iy","Ixx","Ixy","Iyy","Ixz","Iyz" */
 int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, float *host_out);
 
 const char *fotg_strerror(int status);
