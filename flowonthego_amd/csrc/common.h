@@ -27,19 +27,23 @@ struct LevelGeom {
 __host__ __device__ inline int clampi(int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); }
 __host__ __device__ inline int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-// Butterfly wave reduction: v[i] += v[i^1], ^2, ^4, ^8, ^16, ^32 -- the balanced tree the oracle's
-// dis_sum() defines.  a+b == b+a in IEEE, so every lane ends with the same bits.
-// xor 1,2: DPP quad_perm; xor 4: row_half_mirror (lanes of a quad already agree);
-// xor 8: row_mirror; xor 16 / 32: ds_swizzle / permlane-free fallback through __shfl_xor.
+// Wave reduction in the order of the oracle's dis_sum(): the balanced tree v[i] += v[i^1], ^2, ^4, ^8, ^16, ^32.
+// a+b == b+a in IEEE, so a lane may add its partner's partial on either side and get the same bits.
+//   xor 1, 2 : DPP quad_perm              xor 4 : row_half_mirror (the lanes of a quad already agree)
+//   xor 8    : row_mirror                 xor 16: row_bcast:15 into rows 1,3   xor 32: row_bcast:31 into rows 2,3
+// After the last step lane 63 holds ((r3+r2)+(r1+r0)) == the tree's value; it is returned wave-uniform (SGPR).
+// All six steps are VALU DPP operations -- no LDS round trips on the LK loop's critical path.
 __device__ __forceinline__ float wave_sum(float v)
 {
-  v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-  v = v + __shfl_xor(v, 16, 64);
-  v = v + __shfl_xor(v, 32, 64);
-  return v;
+#define FOTG_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rmask, 0xF, false))
+  v = v + FOTG_DPP(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+  v = v + FOTG_DPP(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+  v = v + FOTG_DPP(v, 0x141, 0xF);   // row_half_mirror
+  v = v + FOTG_DPP(v, 0x140, 0xF);   // row_mirror
+  v = v + FOTG_DPP(v, 0x142, 0xA);   // row_bcast:15 -> rows 1 and 3 (others add 0)
+  v = v + FOTG_DPP(v, 0x143, 0xC);   // row_bcast:31 -> rows 2 and 3
+#undef FOTG_DPP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 }  // namespace fotg

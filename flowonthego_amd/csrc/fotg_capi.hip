@@ -416,7 +416,8 @@ int fotg_grid_read(fotg_ctx *c, int l, int pair, float *p_iter, float *pweight, 
 template <int K, int P>
 static void launch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
-  vr_sor_kernel<K, P><<<n, 64, 0, s>>>(a, sweeps, omega);
+  constexpr int U = (K <= 2) ? (P >= 8 ? 64 : 8 * P) : (K <= 4 ? 4 * P : P);     // steps per loop trip
+  vr_sor_kernel<K, P, U><<<n, 64, 0, s>>>(a, sweeps, omega);
 }
 
 static void dispatch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
@@ -426,9 +427,9 @@ static void dispatch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStr
   const int cap = (a.S - 2) / 2;
   auto pick = [&](int pmax) { int p = pmax; while (p > 1 && p > cap) p >>= 1; return p; };
   switch (a.K) {
-    case 1: switch (pick(8)) { case 8: launch_sor<1, 8>(a, n, sweeps, omega, s); break; case 4: launch_sor<1, 4>(a, n, sweeps, omega, s); break;
+    case 1: switch (pick(16)) { case 16: launch_sor<1, 16>(a, n, sweeps, omega, s); break; case 8: launch_sor<1, 8>(a, n, sweeps, omega, s); break; case 4: launch_sor<1, 4>(a, n, sweeps, omega, s); break;
                                case 2: launch_sor<1, 2>(a, n, sweeps, omega, s); break; default: launch_sor<1, 1>(a, n, sweeps, omega, s); } break;
-    case 2: switch (pick(4)) { case 8: launch_sor<2, 8>(a, n, sweeps, omega, s); break; case 4: launch_sor<2, 4>(a, n, sweeps, omega, s); break;
+    case 2: switch (pick(8)) { case 8: launch_sor<2, 8>(a, n, sweeps, omega, s); break; case 4: launch_sor<2, 4>(a, n, sweeps, omega, s); break;
                                case 2: launch_sor<2, 2>(a, n, sweeps, omega, s); break; default: launch_sor<2, 1>(a, n, sweeps, omega, s); } break;
     case 3: switch (pick(4)) { case 4: launch_sor<3, 4>(a, n, sweeps, omega, s); break; case 2: launch_sor<3, 2>(a, n, sweeps, omega, s); break;
                                default: launch_sor<3, 1>(a, n, sweeps, omega, s); } break;

@@ -12,7 +12,9 @@
 // VGPRs for the whole loop; the three reductions per iteration (two projections, query mean, L1
 // residual) are wave butterflies (wave_sum) whose order is the oracle's dis_sum().  All lanes carry
 // the same scalar state, so the 2x2 Cholesky solve and the termination tests are computed redundantly
-// and the loop branch is wave-uniform.
+// and the loop branch is wave-uniform.  The part of I1 the patch can reach -- it may move at most ps/2 from its start
+// before it is reset (patch.cpp:199) -- is staged once into a wave-private LDS window of (2ps+4)^2 pixels, so the
+// loop reads no global memory.
 #pragma once
 #include "common.h"
 
@@ -42,6 +44,9 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
   constexpr int NSLOT = (NPIX + 63) / 64;
   constexpr int NV = NPIX * NOC;
   constexpr int PAD = PS;
+  constexpr int WIN = 2 * PS + 4;                    // window edge, see the column bound below
+  __shared__ float win_all[4][WIN * WIN * NOC];
+  float *win = win_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
   const int ip = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ip >= a.g.nop) return;                         // wave-uniform
@@ -109,6 +114,11 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
     h11 = (float)((double)h11 + 1e-10);
   }
 
+  // Cholesky factor of the (constant) Hessian, hoisted out of the loop: same values every iteration
+  const float l00 = sqrtf(h00);
+  const float l10 = h01 / l00;
+  const float l11 = sqrtf(h11 - l10 * l10);
+
   // ---- starting flow (patchgrid.cpp:195-211): nearest neighbour of the coarser flow, x2 ----
   float pin0 = 0.f, pin1 = 0.f;
   if (a.flow_prev) {
@@ -135,6 +145,18 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
   const bool start_ok = !(ptx < a.g.lb || pty < a.g.lb || ptx > a.g.ubw || pty > a.g.ubh);
   if (!start_ok) conv = true;                            // :135-141; pweight stays 0 (oracle definition D2)
 
+  // ---- stage the reachable window of I1 in LDS.  Every evaluated position is within ps/2 of the start in x and y,
+  // so the bilinear taps span columns floor(stx)-ps-1 .. floor(stx)+ps+2 (padded coordinates: + PAD); rows likewise.
+  const int wx0 = (int)floorf(stx) + PAD - PS - 1, wy0 = (int)floorf(sty) + PAD - PS - 1;
+  if (start_ok) {
+    for (int k = lane; k < WIN * WIN; k += 64) {
+      const int wy = k / WIN, wx = k % WIN;
+      const size_t src = ((size_t)clampi(wy0 + wy, a.g.th) * tw + clampi(wx0 + wx, tw)) * NOC;
+#pragma unroll
+      for (int c = 0; c < NOC; ++c) win[k * NOC + c] = I1[src + c];
+    }
+  }
+
   bool first = start_ok;
   while (first || !conv) {
     if (!first) {
@@ -142,9 +164,6 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
       // projection on the steepest-descent images (:178-179) and 2x2 LLT solve (:184)
       float b0 = wave_sum(lane_dot(Tx, r));
       float b1 = wave_sum(lane_dot(Ty, r));
-      const float l00 = sqrtf(h00);
-      const float l10 = h01 / l00;
-      const float l11 = sqrtf(h11 - l10 * l10);
       const float y0 = b0 / l00;
       const float y1 = (b1 - l10 * y0) / l11;
       const float x1 = y1 / l11;
@@ -168,16 +187,16 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
       const int pos2 = (int)floorf(ptx), pos3 = (int)floorf(pty);
       const float r0 = ptx - (float)pos2, r1 = pty - (float)pos3;
       const float we0 = r0 * r1, we1 = (1 - r0) * r1, we2 = r0 * (1 - r1), we3 = (1 - r0) * (1 - r1);
-      pos0 += PAD; pos1 += PAD;
+      pos0 += PAD - wx0; pos1 += PAD - wy0;             // window coordinates
       float q[NSLOT * NOC];
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s) {
-        const size_t ia = ((size_t)(pos1 + offy[s]) * tw + (pos0 + offx[s])) * NOC;
-        const size_t ic = ia - (size_t)tw * NOC;
+        const int ia = ((pos1 + offy[s]) * WIN + (pos0 + offx[s])) * NOC;
+        const int ic = ia - WIN * NOC;
 #pragma unroll
         for (int c = 0; c < NOC; ++c) {
           if (have[s]) {
-            const float va = I1[ia + c], vb = I1[ia - NOC + c], vc = I1[ic + c], vd = I1[ic - NOC + c];
+            const float va = win[ia + c], vb = win[ia - NOC + c], vc = win[ic + c], vd = win[ic - NOC + c];
             q[s * NOC + c] = we0 * va + we1 * vb + we2 * vc + we3 * vd;
           } else q[s * NOC + c] = 0.f;
         }
@@ -193,10 +212,10 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
       if (cnt == 1) dpn_init = dpn;
       mares_old = mares;
       mares = wave_sum(lane_sum(wabs)) / (float)NV;      // :278
-      if (!((cnt < a.max_iter) & (mares > a.res_thresh) &
-            ((cnt < a.min_iter) | (dpn / dpn_init >= a.dp_thresh_sq)) &
-            ((cnt < a.min_iter) | (mares / mares_old <= a.dr_thresh))))
-        conv = true;
+      // :279-282 (the two rate tests only matter once cnt >= min_iter; skip their divisions before that)
+      bool go = (cnt < a.max_iter) & (mares > a.res_thresh);
+      if (go && cnt >= a.min_iter) go = (dpn / dpn_init >= a.dp_thresh_sq) & (mares / mares_old <= a.dr_thresh);
+      if (!go) conv = true;
       if (trace && lane == 0 && cnt <= a.max_iter) {
         trace[cnt * 4 + 0] = p0; trace[cnt * 4 + 1] = p1; trace[cnt * 4 + 2] = mares; trace[cnt * 4 + 3] = (float)cnt;
       }

@@ -298,7 +298,7 @@ __device__ __forceinline__ float dpp_wave_shr1(float v)
 // from lane L-1 by DPP; left values stay in registers; everything else is old data streamed from the skewed arrays
 // P steps ahead through a register ring (coalesced 16-B/8-B loads), so the loop runs at the speed of its
 // ~10-instruction dependency chain, not at memory latency.
-template <int K, int P>
+template <int K, int P, int U>
 __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float omega)
 {
   const int pair = blockIdx.x, lane = threadIdx.x;
@@ -340,11 +340,13 @@ __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float 
   // Straight-line body, one back edge: steps past T (T rounded up to a multiple of P) run with omega = 0, i.e.
   // rewrite the values they loaded, so no per-step bounds branch is needed and the compiler's s_waitcnt counting
   // stays exact (each use waits only for its own stage, P steps old).
-  for (int t0 = 0; t0 < T; t0 += P) {
+  // U = steps per loop trip (multiple of P): the compiler drains all loads at the loop header (conservative
+  // s_waitcnt merge over the back edge), so a long body amortises that one exposed memory latency
+  for (int t0 = 0; t0 < T; t0 += U) {
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      Stage &st = ring[p];
-      const float om = (t0 + p < T) ? om_lane : 0.f;
+    for (int u = 0; u < U; ++u) {
+      Stage &st = ring[u % P];
+      const float om = (t0 + u < T) ? om_lane : 0.f;
       float2 top0;
       top0.x = dpp_wave_shr1(prev[K - 1].x);
       top0.y = dpp_wave_shr1(prev[K - 1].y);
