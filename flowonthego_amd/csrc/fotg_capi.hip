@@ -420,8 +420,40 @@ static void launch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStrea
   vr_sor_kernel<K, P, U><<<n, 64, 0, s>>>(a, sweeps, omega);
 }
 
+template <int K, int P>
+static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
+{
+  constexpr int U = (P >= 8) ? 32 : 8 * P;
+  static int max_set = 0;
+  const int lds = 64 + (a.S + 2) * a.RPD * (int)sizeof(float2);
+  if (lds > max_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_sor_pipe_kernel<K, P, U>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    max_set = lds;
+  }
+  vr_sor_pipe_kernel<K, P, U><<<n, sweeps * 64, lds, s>>>(a, omega);
+  return true;
+}
+
+// sweep-pipelined LDS solver when it applies: <= 4 sweeps (one wave each), (du,dv) of the level fit in LDS
+static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
+{
+  const int lds = 64 + (a.S + 2) * a.RPD * (int)sizeof(float2);
+  if (sweeps < 1 || sweeps > 4 || lds > 150 * 1024 || a.S < 24) return false;
+  switch (a.K) {
+    case 1: return launch_sor_pipe<1, 8>(a, n, sweeps, omega, s);
+    case 2: return launch_sor_pipe<2, 8>(a, n, sweeps, omega, s);
+    case 3: return launch_sor_pipe<3, 4>(a, n, sweeps, omega, s);
+    case 4: return launch_sor_pipe<4, 4>(a, n, sweeps, omega, s);
+    default: return false;
+  }
+}
+
 static void dispatch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
+  if (dispatch_sor_pipe(a, n, sweeps, omega, s)) return;
   // prefetch depth: as deep as the register budget of K rows per lane allows, and 2P+2 <= S (ring never
   // runs ahead into rows the current sweep has not rewritten yet)
   const int cap = (a.S - 2) / 2;

@@ -366,6 +366,125 @@ __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float 
   }
 }
 
+// Sweep-pipelined variant (the production path whenever D fits in LDS): the `sweeps` Gauss-Seidel sweeps of one
+// sor_coupled call run CONCURRENTLY, one wave per sweep, staggered along the anti-diagonals.  Sweep n+1 may process
+// diagonal s as soon as sweep n has finished diagonal s+1 (its "old" right/bottom neighbours are sweep n's values of
+// diagonal s+1, its own old value is sweep n's value of diagonal s) -- again exactly the data dependencies of the
+// sequential reference, so the result is bit-identical, but the dependent chain shrinks from sweeps*(w+h-1) steps to
+// (w+h-1) + a few.  (du,dv) live in LDS in the skewed layout for the whole kernel; waves hand over through it, gated
+// by per-wave progress counters (LDS executes a wave's accesses in order; all LDS traffic here is volatile so the
+// compiler keeps program order).  The system C is streamed from global memory through the register ring as before.
+template <int K, int P, int U>
+__global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
+{
+  // LDS: [0,64) 16 progress counters, then the float2 cells of D.  Plain (non-volatile) LDS accesses so they stay
+  // ds_read/ds_write; ordering against the progress counters is kept with compiler barriers (the LDS unit itself
+  // executes one wave's accesses in order) and relaxed atomics for the counters.
+  extern __shared__ unsigned long long lds64[];
+  int *progress = reinterpret_cast<int *>(lds64);
+#define FOTG_CBAR() asm volatile("" ::: "memory")
+  auto ldsld = [&](int idx) { return __builtin_bit_cast(float2, lds64[8 + idx]); };
+  auto ldsst = [&](int idx, float2 v) { lds64[8 + idx] = __builtin_bit_cast(unsigned long long, v); };
+  auto prog_load = [&](int i) { const int v = __hip_atomic_load(&progress[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); FOTG_CBAR(); return v; };
+  auto prog_store = [&](int i, int v) { FOTG_CBAR(); __hip_atomic_store(&progress[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool act = lane < a.nlanes;
+  const int r0 = act ? lane * K : a.RP;
+  const float om_lane = act ? omega : 0.f;
+  const float4 *__restrict__ C = a.Cp(pair);
+  float2 *Dg = a.Dp(pair);
+  const int S = a.S, RP = a.RP, RPD = a.RPD;
+  const int ncell = (S + 1) * RPD;                            // + one scratch row (S+1) that tail steps write to
+  for (int k = threadIdx.x; k < ncell; k += blockDim.x) ldsst(k, Dg[k]);
+  if (threadIdx.x < 16) progress[threadIdx.x] = threadIdx.x == 15 ? 0x7fffffff : -1;   // slot 15: always-ready dummy leader of wave 0
+  __syncthreads();
+  const int lead = wv > 0 ? wv - 1 : 15;
+  const unsigned lead_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long *)lds64 + 4u * (unsigned)lead;
+
+  struct Stage { float4 c[K][2]; };
+  Stage ring[P];
+  const char *Cb = reinterpret_cast<const char *>(C);
+  const unsigned c_lane = (unsigned)r0 * 32u, c_row = (unsigned)RP * 32u;
+  auto issue = [&](Stage &st, int row) {
+    row = row < S ? row : S;                                   // row S is the spare all-zero row
+    const float4 *cp = reinterpret_cast<const float4 *>(Cb + (size_t)((unsigned)row * c_row) + c_lane);
+#pragma unroll
+    for (int m = 0; m < K; ++m) { st.c[m][0] = cp[2 * m]; st.c[m][1] = cp[2 * m + 1]; }
+  };
+  struct Old { float2 own[K]; float2 nxt[K + 1]; };
+  Old oldq[2];
+  auto fetch_old = [&](Old &o, int row) {                      // LDS reads of diagonals row, row+1
+    row = row < S ? row : S - 1;
+    const int d0 = row * RPD + r0, d1 = d0 + RPD;
+#pragma unroll
+    for (int m = 0; m < K; ++m) o.own[m] = ldsld(d0 + m);
+#pragma unroll
+    for (int m = 0; m <= K; ++m) o.nxt[m] = ldsld(d1 + m);
+  };
+  // a follower may touch diagonal d (it reads d and d+1) once its leader has completed diagonal d+1
+  // The spin is inline asm on purpose: a C loop here makes the compiler flush vmcnt (drain the C prefetch ring)
+  // in front of it on every step.
+  auto wait_leader = [&](int d, int &seen) {
+    const int need = (d + 1 < S - 1) ? d + 1 : S - 1;
+    if (seen < need) {
+      int v;
+      asm volatile("L_fotg_spin_%=:\n\t"
+                   "ds_read_b32 %0, %1\n\t"
+                   "s_waitcnt lgkmcnt(0)\n\t"
+                   "v_cmp_lt_i32 vcc, %0, %2\n\t"
+                   "s_cbranch_vccz L_fotg_done_%=\n\t"
+                   "s_sleep 1\n\t"
+                   "s_branch L_fotg_spin_%=\n\t"
+                   "L_fotg_done_%=:"
+                   : "=&v"(v) : "v"(lead_addr), "v"(need) : "vcc", "memory");
+      seen = v;
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < P; ++p) issue(ring[p], p);
+  int seen = -1;
+  wait_leader(8, seen);                                        // start with slack so the steady-state checks pass
+  fetch_old(oldq[0], 0);
+  fetch_old(oldq[1], 1);
+  float2 prev[K];
+  float hl[K];
+#pragma unroll
+  for (int m = 0; m < K; ++m) { prev[m] = make_float2(0.f, 0.f); hl[m] = 0.f; }
+  for (int t0 = 0; t0 < S; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = t0 + u;
+      Stage &st = ring[u % P];
+      Old &od = oldq[u & 1];
+      const float om = (s < S) ? om_lane : 0.f;
+      float2 top0;
+      top0.x = dpp_wave_shr1(prev[K - 1].x);
+      top0.y = dpp_wave_shr1(prev[K - 1].y);
+      float2 res[K];
+#pragma unroll
+      for (int m = 0; m < K; ++m)
+        res[m] = sor_update(od.own[m], st.c[m][0], st.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], od.nxt[m], od.nxt[m + 1], om);
+      {                                                        // tail steps (s >= S) write the scratch row
+        const int dst = (s < S ? s : S + 1) * RPD + r0;
+#pragma unroll
+        for (int m = 0; m < K; ++m) ldsst(dst + m, res[m]);
+        prog_store(wv, s < S ? s : S - 1);                     // after the data: LDS keeps a wave's order
+      }
+#pragma unroll
+      for (int m = 0; m < K; ++m) { prev[m] = res[m]; hl[m] = st.c[m][1].y; }
+      issue(st, s + P);
+      // refill this slot with diagonals s+2, s+3 (consumed two steps from now: LDS latency is off the chain);
+      // `seen` comes from the poll issued one step ago, so in steady state nothing waits here
+      wait_leader(s + 2, seen);
+      fetch_old(od, s + 2);
+      seen = prog_load(lead);
+    }
+  }
+#undef FOTG_CBAR
+  __syncthreads();
+  for (int k = threadIdx.x; k < ncell; k += blockDim.x) Dg[k] = ldsld(k);
+}
+
 // red-black ordering of the same block update (throughput mode; deviates from the reference by ~0.07 px)
 __global__ __launch_bounds__(1024) void vr_sor_redblack_kernel(VrArgs a, int iterations, float omega)
 {
