@@ -433,7 +433,9 @@ static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hip
     }
     max_set = lds;
   }
-  vr_sor_pipe_kernel<K, P, U><<<n, sweeps * 64, lds, s>>>(a, omega);
+  VrArgs b = a;
+  b.nsweeps = sweeps;
+  vr_sor_pipe_kernel<K, P, U><<<n, 256, lds, s>>>(b, omega);
   return true;
 }
 

@@ -38,7 +38,7 @@ struct VrArgs {
   float2 *D;             // [pair][SC+1][RPD] float2
   long c_pair_stride;    // in float4
   long d_pair_stride;    // in float2
-  int S, SC, RP, RPD, K, nlanes;
+  int S, SC, RP, RPD, K, nlanes, nsweeps;
   __host__ __device__ float4 *Cp(int pair) const { return C + (size_t)pair * c_pair_stride; }
   __host__ __device__ float2 *Dp(int pair) const { return D + (size_t)pair * d_pair_stride; }
   __host__ __device__ size_t cidx(int i, int j) const { return ((size_t)(i + j) * RP + j) * 2; }
@@ -395,7 +395,21 @@ __global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
   float2 *Dg = a.Dp(pair);
   const int S = a.S, RP = a.RP, RPD = a.RPD;
   const int ncell = (S + 1) * RPD;                            // + one scratch row (S+1) that tail steps write to
-  for (int k = threadIdx.x; k < ncell; k += blockDim.x) ldsst(k, Dg[k]);
+  // global -> LDS, 16 B per lane and 4 loads in flight per lane (RPD is even, so cells pair up)
+  {
+    const float4 *g4 = reinterpret_cast<const float4 *>(Dg);
+    const int n2 = ncell >> 1;
+    for (int k = threadIdx.x; k < n2; k += 4 * blockDim.x) {
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int kk = k + q * blockDim.x; v[q] = kk < n2 ? g4[kk] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kk = k + q * blockDim.x;
+        if (kk < n2) { ldsst(2 * kk, make_float2(v[q].x, v[q].y)); ldsst(2 * kk + 1, make_float2(v[q].z, v[q].w)); }
+      }
+    }
+  }
   if (threadIdx.x < 16) progress[threadIdx.x] = threadIdx.x == 15 ? 0x7fffffff : -1;   // slot 15: always-ready dummy leader of wave 0
   __syncthreads();
   const int lead = wv > 0 ? wv - 1 : 15;
@@ -440,6 +454,7 @@ __global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
       seen = v;
     }
   };
+  if (wv < a.nsweeps) {
 #pragma unroll
   for (int p = 0; p < P; ++p) issue(ring[p], p);
   int seen = -1;
@@ -480,9 +495,17 @@ __global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
       seen = prog_load(lead);
     }
   }
+  }
 #undef FOTG_CBAR
   __syncthreads();
-  for (int k = threadIdx.x; k < ncell; k += blockDim.x) Dg[k] = ldsld(k);
+  {
+    float4 *g4 = reinterpret_cast<float4 *>(Dg);
+    const int n2 = ncell >> 1;
+    for (int k = threadIdx.x; k < n2; k += blockDim.x) {
+      const float2 a0 = ldsld(2 * k), a1 = ldsld(2 * k + 1);
+      g4[k] = make_float4(a0.x, a0.y, a1.x, a1.y);
+    }
+  }
 }
 
 // red-black ordering of the same block update (throughput mode; deviates from the reference by ~0.07 px)
