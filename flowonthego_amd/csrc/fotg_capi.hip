@@ -496,7 +496,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   vr_deriv2_kernel<NOC><<<grid, block, 0, s>>>(a);
   LAUNCHCHK();
   for (int it = 0; it < inner; ++it) {
-    vr_data_kernel<NOC><<<grid, block, 0, s>>>(a, quarter_alpha, half_delta_over3, half_gamma_over3);
+    vr_data_kernel<NOC><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(a, quarter_alpha, half_delta_over3, half_gamma_over3);
     LAUNCHCHK();
     if (c->p.tv_solverit > 0) {
       if (c->p.sor_mode == FOTG_SOR_REDBLACK) vr_sor_redblack_kernel<<<n, 1024, 0, s>>>(a, c->p.tv_solverit, c->p.tv_sor);

@@ -147,36 +147,48 @@ __device__ __forceinline__ float smooth_w(float2 l, float2 c, float2 r, float2 t
   return quarter_alpha / sqrtf(ux * ux + uy * uy + vx * vx + vy * vy + eps);
 }
 
+// One workgroup = one 32x8 pixel tile.  (uu,vv) of the tile + 2-pixel halo and the smoothness weight s of the tile +
+// 1-pixel halo are staged in LDS, so each s is computed once (not once per neighbour) and the skewed D is read ~1.7x
+// per pixel instead of 13x.
+#define FOTG_TW 32
+#define FOTG_TH 8
 template <int NOC>
 __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_alpha, float half_delta_over3, float half_gamma_over3)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.w * a.h) return;
-  const int pair = blockIdx.y, i = idx % a.w, j = idx / a.w, st = a.st, w = a.w, h = a.h, o = j * st + i;
+  constexpr int UW = FOTG_TW + 4, UH = FOTG_TH + 4, SW = FOTG_TW + 2, SH = FOTG_TH + 2;
+  __shared__ float2 uv[UW * UH];
+  __shared__ float sm[SW * SH];
+  const int pair = blockIdx.y, st = a.st, w = a.w, h = a.h;
+  const int tiles_x = (w + FOTG_TW - 1) / FOTG_TW;
+  const int x0 = (blockIdx.x % tiles_x) * FOTG_TW, y0 = (blockIdx.x / tiles_x) * FOTG_TH;
+  const int lx = threadIdx.x % FOTG_TW, ly = threadIdx.x / FOTG_TW;
+  const int i = x0 + lx, j = y0 + ly, o = j * st + i;
   const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
   const float2 *D = a.Dp(pair);
-  // (uu,vv) = (wx+du, wy+dv) (refine_variational.cpp:208-214) on the 13-point diamond around (i,j), clamped like the
-  // replicate borders of the 3-tap filters; du,dv come from the skewed D
-  auto UV = [&](int jj, int ii) {
-    jj = clampi(jj, h); ii = clampi(ii, w);
+  // (uu,vv) = (wx+du, wy+dv) (refine_variational.cpp:208-214), coordinates clamped like the replicate borders of the
+  // 3-tap filters (image.c:436-464); du,dv come from the skewed D
+  for (int k = threadIdx.x; k < UW * UH; k += 256) {
+    const int jj = clampi(y0 - 2 + k / UW, h), ii = clampi(x0 - 2 + k % UW, w);
     const int q = jj * st + ii;
     const float2 d = D[a.didx(ii, jj)];
-    return make_float2(wx[q] + d.x, wy[q] + d.y);
-  };
-  const float2 cc = UV(j, i), l1 = UV(j, i - 1), l2 = UV(j, i - 2), r1 = UV(j, i + 1), r2 = UV(j, i + 2);
-  const float2 t1 = UV(j - 1, i), t2 = UV(j - 2, i), b1 = UV(j + 1, i), b2 = UV(j + 2, i);
-  const float2 tl = UV(j - 1, i - 1), tr = UV(j - 1, i + 1), bl = UV(j + 1, i - 1), br = UV(j + 1, i + 1);
-  // compute_smoothness (:123-163): horiz(i) = s(i)+s(i+1) (0 in the last column), vert likewise.
-  // Horizontal neighbours clamp the column (replicate), e.g. the left pixel's own left is column max(i-2,0).
-  const float s_o = smooth_w(l1, cc, r1, t1, b1, j, h, quarter_alpha);
-  const float s_r = smooth_w(cc, r1, r2, tr, br, j, h, quarter_alpha);           // pixel (i+1, j)
-  const float s_l = smooth_w(l2, l1, cc, tl, bl, j, h, quarter_alpha);           // pixel (i-1, j)
-  const float s_b = smooth_w(bl, b1, br, cc, b2, j + 1, h, quarter_alpha);       // pixel (i, j+1)
-  const float s_t = smooth_w(tl, t1, tr, t2, cc, j - 1, h, quarter_alpha);       // pixel (i, j-1)
-  const float hr = (i < w - 1) ? s_o + s_r : 0.0f;
-  const float hl = (i > 0) ? s_l + s_o : 0.0f;
-  const float vb = (j < h - 1) ? s_o + s_b : 0.0f;
-  const float vt = (j > 0) ? s_t + s_o : 0.0f;
+    uv[k] = make_float2(wx[q] + d.x, wy[q] + d.y);
+  }
+  __syncthreads();
+  // compute_smoothness first half (opticalflow_aux.c:126-139) for the tile + 1 halo
+  for (int k = threadIdx.x; k < SW * SH; k += 256) {
+    const int sy = k / SW, sx = k % SW;
+    const int c = (sy + 1) * UW + (sx + 1);
+    sm[k] = smooth_w(uv[c - 1], uv[c], uv[c + 1], uv[c - UW], uv[c + UW], y0 - 1 + sy, h, quarter_alpha);
+  }
+  __syncthreads();
+  if (i >= w || j >= h) return;
+  // second half (:141-163): horiz(i) = s(i)+s(i+1) (0 in the last column), vert likewise
+  const int sc = (ly + 1) * SW + (lx + 1);
+  const float s_o = sm[sc];
+  const float hr = (i < w - 1) ? s_o + sm[sc + 1] : 0.0f;
+  const float hl = (i > 0) ? sm[sc - 1] + s_o : 0.0f;
+  const float vb = (j < h - 1) ? s_o + sm[sc + SW] : 0.0f;
+  const float vt = (j > 0) ? sm[sc - SW] + s_o : 0.0f;
 
   // compute_data (:310-438)
   const float dnorm = 0.1f * 0.1f, epsc = 0.001f * 0.001f, epsg = 0.001f * 0.001f;
