@@ -237,17 +237,20 @@ int fotg_num_patches(const fotg_ctx *c, int l, int *nopw, int *noph)
 /* pyramid                                                                                          */
 /* ------------------------------------------------------------------------------------------------ */
 }  // extern "C"
+// I0 and/or I1 may be given; both frames of a batch share the launches
 template <int NOC>
-static int pyramid_impl(fotg_ctx *c, int n, const float *I, int which, hipStream_t s)
+static int pyramid_impl(fotg_ctx *c, int n, const float *I0, const float *I1, hipStream_t s)
 {
   const int lv = c->base_lv, ps = c->ps;
   const LevelGeom &g0 = c->geom[lv];
   const int strips = (c->Wp + 255) >> 8, tiles = strips * (c->Hp >> lv);
   const long fstride = (long)c->w_org * c->h_org * NOC;
-  const int fast = (c->padw == 0) && ((c->w_org * NOC) % 4 == 0) && (((uintptr_t)I & 15) == 0) && ((fstride % 4) == 0);
-  dim3 grid((tiles + 3) / 4, n), block(256);
-  float *dst = c->im[which][lv];
-#define BASE(LV) pyr_base_kernel<NOC, LV><<<grid, block, 0, s>>>(I, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dst, c->lev_stride[lv], g0.tw, ps, fast)
+  const float *A = I0 ? I0 : I1, *B = (I0 && I1) ? I1 : nullptr;
+  float *dA = c->im[I0 ? 0 : 1][lv], *dB = c->im[1][lv];
+  const int nimg = B ? 2 * n : n;
+  const int fast = (c->padw == 0) && ((c->w_org * NOC) % 4 == 0) && (((uintptr_t)A & 15) == 0) && (!B || ((uintptr_t)B & 15) == 0) && ((fstride % 4) == 0);
+  dim3 grid((tiles + 3) / 4, nimg), block(256);
+#define BASE(LV) pyr_base_kernel<NOC, LV><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, fast)
   switch (lv) {
     case 0: BASE(0); break;
     case 1: BASE(1); break;
@@ -257,19 +260,40 @@ static int pyramid_impl(fotg_ctx *c, int n, const float *I, int which, hipStream
   }
 #undef BASE
   LAUNCHCHK();
-  for (int l = lv + 1; l <= c->p.sc_f; ++l) {
-    const LevelGeom &gs = c->geom[l - 1], &gd = c->geom[l];
-    const int tot = gd.w * gd.h * NOC;
-    pyr_halve_kernel<NOC><<<dim3((tot + 255) / 256, n), 256, 0, s>>>(c->im[which][l - 1], c->lev_stride[l - 1], gs.tw,
-                                                                     c->im[which][l], c->lev_stride[l], gd.tw, gd.w, gd.h, ps);
+  const int nlev = c->p.sc_f - lv + 1;
+  if ((long)c->geom[c->p.sc_l].tw * c->geom[c->p.sc_l].th * NOC <= 32768 && (long)g0.w * g0.h * NOC <= 32768) {
+    // small levels: one fused launch, one workgroup per image
+    PyrFinishArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    for (int k = 0; k < nlev; ++k) {
+      const int l = lv + k;
+      fa.im[0][k] = c->im[0][l]; fa.im[1][k] = c->im[1][l]; fa.dx[k] = c->dx0[l]; fa.dy[k] = c->dy0[l];
+      fa.stride[k] = c->lev_stride[l]; fa.w[k] = c->geom[l].w; fa.h[k] = c->geom[l].h;
+    }
+    fa.nlev = nlev; fa.first_used = c->p.sc_l - lv; fa.ps = ps;
+    if (I0 && I1) { fa.n_per_src = n; }
+    else if (I0) { fa.n_per_src = n; }                       // only `which` 0 blocks exist
+    else { fa.n_per_src = 0; }                               // every block is `which` 1
+    pyr_finish_kernel<NOC><<<nimg, 1024, 0, s>>>(fa);
     LAUNCHCHK();
+    return FOTG_OK;
   }
-  for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) {
-    const LevelGeom &g = c->geom[l];
-    const int tot = g.tw * g.th * NOC;
-    pyr_border_grad_kernel<NOC><<<dim3((tot + 255) / 256, n), 256, 0, s>>>(
-        c->im[which][l], which == 0 ? c->dx0[l] : nullptr, which == 0 ? c->dy0[l] : nullptr, c->lev_stride[l], g.w, g.h, ps);
-    LAUNCHCHK();
+  for (int which = 0; which < 2; ++which) {
+    if (!(which == 0 ? I0 : I1)) continue;
+    for (int l = lv + 1; l <= c->p.sc_f; ++l) {
+      const LevelGeom &gs = c->geom[l - 1], &gd = c->geom[l];
+      const int tot = gd.w * gd.h * NOC;
+      pyr_halve_kernel<NOC><<<dim3((tot + 255) / 256, n), 256, 0, s>>>(c->im[which][l - 1], c->lev_stride[l - 1], gs.tw,
+                                                                       c->im[which][l], c->lev_stride[l], gd.tw, gd.w, gd.h, ps);
+      LAUNCHCHK();
+    }
+    for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) {
+      const LevelGeom &g = c->geom[l];
+      const int tot = g.tw * g.th * NOC;
+      pyr_border_grad_kernel<NOC><<<dim3((tot + 255) / 256, n), 256, 0, s>>>(
+          c->im[which][l], which == 0 ? c->dx0[l] : nullptr, which == 0 ? c->dy0[l] : nullptr, c->lev_stride[l], g.w, g.h, ps);
+      LAUNCHCHK();
+    }
   }
   return FOTG_OK;
 }
@@ -279,7 +303,8 @@ int fotg_pyramid(fotg_ctx *c, int n, const float *I, int which, void *stream)
 {
   if (!c || !I || (which != 0 && which != 1)) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
-  return c->noc == 1 ? pyramid_impl<1>(c, n, I, which, (hipStream_t)stream) : pyramid_impl<3>(c, n, I, which, (hipStream_t)stream);
+  const float *I0 = which == 0 ? I : nullptr, *I1 = which == 1 ? I : nullptr;
+  return c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, (hipStream_t)stream) : pyramid_impl<3>(c, n, I0, I1, (hipStream_t)stream);
 }
 
 int fotg_level_ptr(fotg_ctx *c, int which, int l, int kind, float **ptr, long *pair_stride)
@@ -575,8 +600,7 @@ int fotg_calc_batch(fotg_ctx *c, int n, const float *I0, const float *I1, const 
   if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
   int st;
-  if ((st = fotg_pyramid(c, n, I0, 0, stream))) return st;
-  if ((st = fotg_pyramid(c, n, I1, 1, stream))) return st;
+  if ((st = c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, (hipStream_t)stream) : pyramid_impl<3>(c, n, I0, I1, (hipStream_t)stream))) return st;
   for (int l = c->p.sc_f; l >= c->p.sc_l; --l) {
     if ((st = fotg_grid_init(c, l, n, c->im[0][l], c->dx0[l], c->dy0[l], c->lev_stride[l], stream))) return st;
     if ((st = fotg_grid_set_target(c, l, c->im[1][l], c->lev_stride[l]))) return st;

@@ -8,12 +8,25 @@ ownership as the reference; PyTorch is used only to hold device memory and strea
 Numerics are those of the reference's kroeger/ CPU implementation, evaluated by hand-written HIP
 kernels; nothing here computes on the CPU and there is no fallback path.
 """
+import atexit
 import ctypes as C
+import sys
+import weakref
 
 import torch
 
 from ._lib import FotgError, check, lib
 from .params import img_params, opt_params, padded_size
+
+
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    # destroy contexts while the HIP runtime is still alive (not from __del__ during interpreter shutdown)
+    for o in list(_LIVE):
+        o.close()
 
 
 def _ptr(t):
@@ -50,6 +63,7 @@ class OFClass:
         cp = self.op.to_c()
         check(lib().fotg_create(cp, self.width_org, self.height_org, device, self.max_batch, h))
         self._h = h
+        _LIVE.add(self)
         # per-scale img_params exactly as src/oflow.cpp:84-95
         self.iparams = []
         ps = self.op.patch_size
@@ -129,14 +143,19 @@ class OFClass:
         check(lib().fotg_level_ptr(self._h, which, sl, kind, p, stride))
         return p.value, stride.value
 
-    def __del__(self):
+    def close(self):
+        """OFClass::~OFClass (src/oflow.cpp:147-179)"""
         h = getattr(self, "_h", None)
         if h:
+            self._h = None
+            lib().fotg_destroy(h)
+
+    def __del__(self):
+        if not sys.is_finalizing():
             try:
-                lib().fotg_destroy(h)
+                self.close()
             except Exception:
                 pass
-            self._h = None
 
 
 def _hip_copy(dst_tensor, src_ptr):
