@@ -250,7 +250,8 @@ static int pyramid_impl(fotg_ctx *c, int n, const float *I0, const float *I1, hi
   const int nimg = B ? 2 * n : n;
   const int fast = (c->padw == 0) && ((c->w_org * NOC) % 4 == 0) && (((uintptr_t)A & 15) == 0) && (!B || ((uintptr_t)B & 15) == 0) && ((fstride % 4) == 0);
   dim3 grid((tiles + 3) / 4, nimg), block(256);
-#define BASE(LV) pyr_base_kernel<NOC, LV><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, fast)
+#define BASE(LV) do { if (fast) pyr_base_kernel<NOC, LV, true><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps); \
+    else pyr_base_kernel<NOC, LV, false><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps); } while (0)
   switch (lv) {
     case 0: BASE(0); break;
     case 1: BASE(1); break;

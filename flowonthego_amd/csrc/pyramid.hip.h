@@ -14,13 +14,13 @@
 
 namespace fotg {
 
-template <int NOC, int LV>
+template <int NOC, int LV, bool FAST>
 __global__ __launch_bounds__(256) void pyr_base_kernel(
     const float *__restrict__ frames0, const float *__restrict__ frames1, int n_per_src, long frame_stride,  // 2 x n frames, h_org x w_org x NOC
     int w_org, int h_org, int left, int top,               // padding offsets (floor(pad/2))
     int Wp, int Hp,                                        // padded frame size
-    float *__restrict__ dst0, float *__restrict__ dst1, long dst_stride, int tw, int ps,  // level LV padded buffers
-    int fast)                                              // 1: 16-B loads legal (no horizontal pad, aligned rows)
+    float *__restrict__ dst0, float *__restrict__ dst1, long dst_stride, int tw, int ps)  // level LV padded buffers
+    // FAST: 16-B loads legal (no horizontal pad, 16-B aligned rows)
 {
   constexpr int R = 1 << LV;                 // source rows per output row
   constexpr int C = 4 * NOC;                 // floats per lane per row
@@ -42,11 +42,13 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
     for (int r = 0; r < R; ++r) {
       const int sy = clampi(oy * R + r - top, h_org);
       const float *row = src + (size_t)sy * w_org * NOC;
-      if (fast) {
-        const float4 *p4 = reinterpret_cast<const float4 *>(row + (size_t)x0 * NOC);
+      if constexpr (FAST) {
+        // streamed once, never re-read: nontemporal 16-B loads keep the frames out of L2/MALL
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        const vf4 *p4 = reinterpret_cast<const vf4 *>(row + (size_t)x0 * NOC);
 #pragma unroll
         for (int k = 0; k < NOC; ++k) {
-          float4 t = p4[k];
+          const vf4 t = __builtin_nontemporal_load(p4 + k);
           v[r][4 * k] = t.x; v[r][4 * k + 1] = t.y; v[r][4 * k + 2] = t.z; v[r][4 * k + 3] = t.w;
         }
       } else {
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
 #pragma unroll
           for (int c = 0; c < NOC; ++c) {
             const float s = cur[2 * y][c] + cur[2 * y + 1][c];     // (a+c) of this column
-            const float t = __shfl_xor(s, xm, 64);                   // (b+d) of the partner column
+            // (b+d) of the partner column: lane^1 / lane^2 by DPP quad_perm (no LDS round trip)
+            const float t = __builtin_bit_cast(float, xm == 1 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true)
+                                                                : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));
             cur[y][c] = (s + t) * 0.25f;
           }
         rows >>= 1;
