@@ -479,9 +479,49 @@ static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, h
   }
 }
 
+template <int NOC, int K, int P>
+static bool launch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s)
+{
+  constexpr int U = (P >= 8) ? 32 : 8 * P;
+  static int max_set = 0;
+  const int lds = 64 + (a.S + 2) * a.RPD * (int)sizeof(float2) + a.w * a.h * (int)sizeof(float);
+  if (lds > max_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, K, P, U>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    max_set = lds;
+  }
+  VrArgs b = a;
+  b.nsweeps = sweeps;
+  vr_inner_fused_kernel<NOC, K, P, U><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs);
+  return true;
+}
+
+// whole fixed-point loop in one launch when (du,dv) + the smoothness plane fit in LDS and sweeps <= 4
+template <int NOC>
+static bool dispatch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s)
+{
+  const int lds = 64 + (a.S + 2) * a.RPD * (int)sizeof(float2) + a.w * a.h * (int)sizeof(float);
+  // one workgroup does the per-pixel phases of its pair: only worth it for small levels (measured: 60x34 yes, 120x68 no)
+  if (sweeps < 1 || sweeps > 4 || inner < 1 || lds > 156 * 1024 || a.S < 24 || a.w * a.h > 3000) return false;
+  switch (a.K) {
+    case 1: return launch_inner_fused<NOC, 1, 8>(a, n, sweeps, inner, qa, hd, hg, omega, flow, fs, s);
+    case 2: return launch_inner_fused<NOC, 2, 4>(a, n, sweeps, inner, qa, hd, hg, omega, flow, fs, s);
+    default: return false;
+  }
+}
+
+// FOTG_VR_PATH (tests): 0/unset = automatic, 1 = single-wave global-memory solver only, 2 = no fused inner loop
+static int vr_path_override()
+{
+  const char *e = getenv("FOTG_VR_PATH");
+  return e ? atoi(e) : 0;
+}
+
 static void dispatch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
-  if (dispatch_sor_pipe(a, n, sweeps, omega, s)) return;
+  if (vr_path_override() != 1 && dispatch_sor_pipe(a, n, sweeps, omega, s)) return;
   // prefetch depth: as deep as the register budget of K rows per lane allows, and 2P+2 <= S (ring never
   // runs ahead into rows the current sweep has not rewritten yet)
   const int cap = (a.S - 2) / 2;
@@ -521,6 +561,11 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   LAUNCHCHK();
   vr_deriv2_kernel<NOC><<<grid, block, 0, s>>>(a);
   LAUNCHCHK();
+  if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && vr_path_override() == 0 &&
+      dispatch_inner_fused<NOC>(a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s)) {
+    LAUNCHCHK();
+    return FOTG_OK;
+  }
   for (int it = 0; it < inner; ++it) {
     vr_data_kernel<NOC><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(a, quarter_alpha, half_delta_over3, half_gamma_over3);
     LAUNCHCHK();

@@ -147,6 +147,134 @@ __device__ __forceinline__ float smooth_w(float2 l, float2 c, float2 r, float2 t
   return quarter_alpha / sqrtf(ux * ux + uy * uy + vx * vx + vy * vy + eps);
 }
 
+// Everything compute_data / sub_laplacian read from global memory for one pixel, gathered up front so callers can
+// put the loads of several pixels in flight before computing (the fused kernel batches 4 pixels per thread).
+template <int NOC>
+struct PixIn {
+  float Ix[NOC], Iy[NOC], Iz[NOC], Ixx[NOC], Ixy[NOC], Iyy[NOC], Ixz[NOC], Iyz[NOC];
+  float m, wxc, wxl, wxr, wxt, wxb, wyc, wyl, wyr, wyt, wyb;
+};
+
+template <int NOC>
+__device__ __forceinline__ PixIn<NOC> data_load(const VrArgs &a, int pair, int i, int j)
+{
+  const int st = a.st, w = a.w, h = a.h, o = j * st + i;
+  const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
+  PixIn<NOC> p;
+#pragma unroll
+  for (int c = 0; c < NOC; ++c) {
+    p.Ix[c] = a.color(pair, C_IX, c)[o]; p.Iy[c] = a.color(pair, C_IY, c)[o]; p.Iz[c] = a.color(pair, C_IZ, c)[o];
+    p.Ixx[c] = a.color(pair, C_IXX, c)[o]; p.Ixy[c] = a.color(pair, C_IXY, c)[o]; p.Iyy[c] = a.color(pair, C_IYY, c)[o];
+    p.Ixz[c] = a.color(pair, C_IXZ, c)[o]; p.Iyz[c] = a.color(pair, C_IYZ, c)[o];
+  }
+  p.m = a.single(pair, P_MASK)[o];
+  const int ol = i > 0 ? o - 1 : o, orr = i < w - 1 ? o + 1 : o, ot = j > 0 ? o - st : o, ob = j < h - 1 ? o + st : o;
+  p.wxc = wx[o]; p.wxl = wx[ol]; p.wxr = wx[orr]; p.wxt = wx[ot]; p.wxb = wx[ob];
+  p.wyc = wy[o]; p.wyl = wy[ol]; p.wyr = wy[orr]; p.wyt = wy[ot]; p.wyb = wy[ob];
+  return p;
+}
+
+// compute_data (:310-438) + sub_laplacian (:172-199) + the 2x2 block inverse of sor_coupled's first sweep
+// (solver.c:115-120) for pixel (i,j), given the four smoothness pair sums and (du,dv); writes the skewed system cell.
+template <int NOC>
+__device__ __forceinline__ void data_term_compute(const VrArgs &a, int pair, int i, int j, const PixIn<NOC> &p, float hr, float hl,
+                                                  float vb, float vt, float u, float v, float half_delta_over3, float half_gamma_over3)
+{
+  const int w = a.w, h = a.h;
+  // compute_data (:310-438)
+  const float dnorm = 0.1f * 0.1f, epsc = 0.001f * 0.001f, epsg = 0.001f * 0.001f;
+  const float m = p.m;
+  float A11 = 0, A12 = 0, A22 = 0, B1 = 0, B2 = 0;
+  if constexpr (NOC == 1) {
+    const float Ix = p.Ix[0], Iy = p.Iy[0], Iz = p.Iz[0], Ixx = p.Ixx[0], Ixy = p.Ixy[0], Iyy = p.Iyy[0], Ixz = p.Ixz[0], Iyz = p.Iyz[0];
+    float tmp, tmp2, n1, n2;
+    if (half_delta_over3) {
+      tmp = Iz + Ix * u + Iy * v;
+      n1 = Ix * Ix + Iy * Iy + dnorm;
+      tmp = m * half_delta_over3 / sqrtf(3 * tmp * tmp / n1 + epsc);
+      tmp /= n1;
+      A11 += tmp * Ix * Ix;
+      A12 += tmp * Ix * Iy;
+      A22 += tmp * Iy * Iy;
+      B1 -= tmp * Iz * Ix;
+      B2 -= tmp * Iz * Iy;
+    }
+    n1 = Ixx * Ixx + Ixy * Ixy + dnorm;
+    n2 = Iyy * Iyy + Ixy * Ixy + dnorm;
+    tmp = Ixz + Ixx * u + Ixy * v;
+    tmp2 = Iyz + Ixy * u + Iyy * v;
+    tmp = m * half_gamma_over3 / sqrtf(3 * tmp * tmp / n1 + 3 * tmp2 * tmp2 / n2 + epsg);
+    tmp2 = tmp / n2; tmp /= n1;
+    A11 += tmp * Ixx * Ixx + tmp2 * Ixy * Ixy;
+    A12 += tmp * Ixx * Ixy + tmp2 * Ixy * Iyy;
+    A22 += tmp2 * Iyy * Iyy + tmp * Ixy * Ixy;
+    B1 -= tmp * Ixx * Ixz + tmp2 * Ixy * Iyz;
+    B2 -= tmp2 * Iyy * Iyz + tmp * Ixy * Ixz;
+    A11 *= 3; A12 *= 3; A22 *= 3; B1 *= 3; B2 *= 3;       // :420-426
+  } else {
+    float ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ix[c] = p.Ix[c]; iy[c] = p.Iy[c]; iz[c] = p.Iz[c]; ixx[c] = p.Ixx[c]; ixy[c] = p.Ixy[c]; iyy[c] = p.Iyy[c];
+      ixz[c] = p.Ixz[c]; iyz[c] = p.Iyz[c];
+    }
+    if (half_delta_over3) {
+      float t[3], n[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { t[c] = iz[c] + ix[c] * u + iy[c] * v; n[c] = ix[c] * ix[c] + iy[c] * iy[c] + dnorm; }
+      float tmp = m * half_delta_over3 / sqrtf(t[0] * t[0] / n[0] + t[1] * t[1] / n[1] + t[2] * t[2] / n[2] + epsc);
+      const float k2 = tmp / n[2], k1 = tmp / n[1], k0 = tmp / n[0];
+      const float k[3] = {k0, k1, k2};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        A11 += k[c] * ix[c] * ix[c]; A12 += k[c] * ix[c] * iy[c]; A22 += k[c] * iy[c] * iy[c];
+        B1 -= k[c] * iz[c] * ix[c];  B2 -= k[c] * iz[c] * iy[c];
+      }
+    }
+    float n1[3], n2[3], t1[3], t2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      n1[c] = ixx[c] * ixx[c] + ixy[c] * ixy[c] + dnorm; n2[c] = iyy[c] * iyy[c] + ixy[c] * ixy[c] + dnorm;
+      t1[c] = ixz[c] + ixx[c] * u + ixy[c] * v;           t2[c] = iyz[c] + ixy[c] * u + iyy[c] * v;
+    }
+    const float tmp = m * half_gamma_over3 / sqrtf(t1[0] * t1[0] / n1[0] + t2[0] * t2[0] / n2[0] + t1[1] * t1[1] / n1[1] +
+                                                   t2[1] * t2[1] / n2[1] + t1[2] * t1[2] / n1[2] + t2[2] * t2[2] / n2[2] + epsg);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float ka = tmp / n1[c], kb = tmp / n2[c];
+      A11 += ka * ixx[c] * ixx[c] + kb * ixy[c] * ixy[c];
+      A12 += ka * ixx[c] * ixy[c] + kb * ixy[c] * iyy[c];
+      A22 += kb * iyy[c] * iyy[c] + ka * ixy[c] * ixy[c];
+      B1 -= ka * ixx[c] * ixz[c] + kb * ixy[c] * iyz[c];
+      B2 -= kb * iyy[c] * iyz[c] + ka * ixy[c] * ixz[c];
+    }
+  }
+
+  // sub_laplacian (:172-199) for b1 (src wx) and b2 (src wy): -left, +right, -top, +bottom
+  if (i > 0)     { B1 -= hl * (p.wxc - p.wxl); B2 -= hl * (p.wyc - p.wyl); }
+  if (i < w - 1) { B1 += hr * (p.wxr - p.wxc); B2 += hr * (p.wyr - p.wyc); }
+  if (j > 0)     { B1 -= vt * (p.wxc - p.wxt); B2 -= vt * (p.wyc - p.wyt); }
+  if (j < h - 1) { B1 += vb * (p.wxb - p.wxc); B2 += vb * (p.wyb - p.wyc); }
+
+  // first sweep of sor_coupled inverts the 2x2 block (solver.c:115-120): dpsis = hl+hr(+vt)(+vb)
+  float dps = hl + hr;
+  if (j > 0) dps = dps + vt;
+  if (j < h - 1) dps = dps + vb;
+  const float M11 = A22 + dps, M22 = A11 + dps;
+  const float det = M11 * M22 - A12 * A12;
+  float4 *C = a.Cp(pair) + a.cidx(i, j);
+  C[0] = make_float4(M11 / det, A12 / -det, M22 / det, B1);
+  C[1] = make_float4(B2, hr, vb, vt);
+}
+
+template <int NOC>
+__device__ __forceinline__ void data_term_pixel(const VrArgs &a, int pair, int i, int j, float hr, float hl, float vb, float vt,
+                                                float u, float v, float half_delta_over3, float half_gamma_over3)
+{
+  const PixIn<NOC> p = data_load<NOC>(a, pair, i, j);
+  data_term_compute<NOC>(a, pair, i, j, p, hr, hl, vb, vt, u, v, half_delta_over3, half_gamma_over3);
+}
+
 // One workgroup = one 32x8 pixel tile.  (uu,vv) of the tile + 2-pixel halo and the smoothness weight s of the tile +
 // 1-pixel halo are staged in LDS, so each s is computed once (not once per neighbour) and the skewed D is read ~1.7x
 // per pixel instead of 13x.
@@ -190,94 +318,8 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_al
   const float vb = (j < h - 1) ? s_o + sm[sc + SW] : 0.0f;
   const float vt = (j > 0) ? sm[sc - SW] + s_o : 0.0f;
 
-  // compute_data (:310-438)
-  const float dnorm = 0.1f * 0.1f, epsc = 0.001f * 0.001f, epsg = 0.001f * 0.001f;
   const float2 duv = D[a.didx(i, j)];
-  const float u = duv.x, v = duv.y, m = a.single(pair, P_MASK)[o];
-  float A11 = 0, A12 = 0, A22 = 0, B1 = 0, B2 = 0;
-  if constexpr (NOC == 1) {
-    const float Ix = a.color(pair, C_IX, 0)[o], Iy = a.color(pair, C_IY, 0)[o], Iz = a.color(pair, C_IZ, 0)[o];
-    const float Ixx = a.color(pair, C_IXX, 0)[o], Ixy = a.color(pair, C_IXY, 0)[o], Iyy = a.color(pair, C_IYY, 0)[o];
-    const float Ixz = a.color(pair, C_IXZ, 0)[o], Iyz = a.color(pair, C_IYZ, 0)[o];
-    float tmp, tmp2, n1, n2;
-    if (half_delta_over3) {
-      tmp = Iz + Ix * u + Iy * v;
-      n1 = Ix * Ix + Iy * Iy + dnorm;
-      tmp = m * half_delta_over3 / sqrtf(3 * tmp * tmp / n1 + epsc);
-      tmp /= n1;
-      A11 += tmp * Ix * Ix;
-      A12 += tmp * Ix * Iy;
-      A22 += tmp * Iy * Iy;
-      B1 -= tmp * Iz * Ix;
-      B2 -= tmp * Iz * Iy;
-    }
-    n1 = Ixx * Ixx + Ixy * Ixy + dnorm;
-    n2 = Iyy * Iyy + Ixy * Ixy + dnorm;
-    tmp = Ixz + Ixx * u + Ixy * v;
-    tmp2 = Iyz + Ixy * u + Iyy * v;
-    tmp = m * half_gamma_over3 / sqrtf(3 * tmp * tmp / n1 + 3 * tmp2 * tmp2 / n2 + epsg);
-    tmp2 = tmp / n2; tmp /= n1;
-    A11 += tmp * Ixx * Ixx + tmp2 * Ixy * Ixy;
-    A12 += tmp * Ixx * Ixy + tmp2 * Ixy * Iyy;
-    A22 += tmp2 * Iyy * Iyy + tmp * Ixy * Ixy;
-    B1 -= tmp * Ixx * Ixz + tmp2 * Ixy * Iyz;
-    B2 -= tmp2 * Iyy * Iyz + tmp * Ixy * Ixz;
-    A11 *= 3; A12 *= 3; A22 *= 3; B1 *= 3; B2 *= 3;       // :420-426
-  } else {
-    float ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      ix[c] = a.color(pair, C_IX, c)[o]; iy[c] = a.color(pair, C_IY, c)[o]; iz[c] = a.color(pair, C_IZ, c)[o];
-      ixx[c] = a.color(pair, C_IXX, c)[o]; ixy[c] = a.color(pair, C_IXY, c)[o]; iyy[c] = a.color(pair, C_IYY, c)[o];
-      ixz[c] = a.color(pair, C_IXZ, c)[o]; iyz[c] = a.color(pair, C_IYZ, c)[o];
-    }
-    if (half_delta_over3) {
-      float t[3], n[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { t[c] = iz[c] + ix[c] * u + iy[c] * v; n[c] = ix[c] * ix[c] + iy[c] * iy[c] + dnorm; }
-      float tmp = m * half_delta_over3 / sqrtf(t[0] * t[0] / n[0] + t[1] * t[1] / n[1] + t[2] * t[2] / n[2] + epsc);
-      const float k2 = tmp / n[2], k1 = tmp / n[1], k0 = tmp / n[0];
-      const float k[3] = {k0, k1, k2};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        A11 += k[c] * ix[c] * ix[c]; A12 += k[c] * ix[c] * iy[c]; A22 += k[c] * iy[c] * iy[c];
-        B1 -= k[c] * iz[c] * ix[c];  B2 -= k[c] * iz[c] * iy[c];
-      }
-    }
-    float n1[3], n2[3], t1[3], t2[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      n1[c] = ixx[c] * ixx[c] + ixy[c] * ixy[c] + dnorm; n2[c] = iyy[c] * iyy[c] + ixy[c] * ixy[c] + dnorm;
-      t1[c] = ixz[c] + ixx[c] * u + ixy[c] * v;           t2[c] = iyz[c] + ixy[c] * u + iyy[c] * v;
-    }
-    const float tmp = m * half_gamma_over3 / sqrtf(t1[0] * t1[0] / n1[0] + t2[0] * t2[0] / n2[0] + t1[1] * t1[1] / n1[1] +
-                                                   t2[1] * t2[1] / n2[1] + t1[2] * t1[2] / n1[2] + t2[2] * t2[2] / n2[2] + epsg);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float ka = tmp / n1[c], kb = tmp / n2[c];
-      A11 += ka * ixx[c] * ixx[c] + kb * ixy[c] * ixy[c];
-      A12 += ka * ixx[c] * ixy[c] + kb * ixy[c] * iyy[c];
-      A22 += kb * iyy[c] * iyy[c] + ka * ixy[c] * ixy[c];
-      B1 -= ka * ixx[c] * ixz[c] + kb * ixy[c] * iyz[c];
-      B2 -= kb * iyy[c] * iyz[c] + ka * ixy[c] * ixz[c];
-    }
-  }
-
-  // sub_laplacian (:172-199) for b1 (src wx) and b2 (src wy): -left, +right, -top, +bottom
-  if (i > 0)     { B1 -= hl * (wx[o] - wx[o - 1]);  B2 -= hl * (wy[o] - wy[o - 1]); }
-  if (i < w - 1) { B1 += hr * (wx[o + 1] - wx[o]);  B2 += hr * (wy[o + 1] - wy[o]); }
-  if (j > 0)     { B1 -= vt * (wx[o] - wx[o - st]); B2 -= vt * (wy[o] - wy[o - st]); }
-  if (j < h - 1) { B1 += vb * (wx[o + st] - wx[o]); B2 += vb * (wy[o + st] - wy[o]); }
-
-  // first sweep of sor_coupled inverts the 2x2 block (solver.c:115-120): dpsis = hl+hr(+vt)(+vb)
-  float dps = hl + hr;
-  if (j > 0) dps = dps + vt;
-  if (j < h - 1) dps = dps + vb;
-  const float M11 = A22 + dps, M22 = A11 + dps;
-  const float det = M11 * M22 - A12 * A12;
-  float4 *C = a.Cp(pair) + a.cidx(i, j);
-  C[0] = make_float4(M11 / det, A12 / -det, M22 / det, B1);
-  C[1] = make_float4(B2, hr, vb, vt);
+  data_term_pixel<NOC>(a, pair, i, j, hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
 }
 
 // one pixel update of sor_coupled (solver.c:122-130 etc.).  du_l/du_t are the NEW left/top values, du_r/du_b the OLD
@@ -383,59 +425,55 @@ __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float 
 // diagonal s as soon as sweep n has finished diagonal s+1 (its "old" right/bottom neighbours are sweep n's values of
 // diagonal s+1, its own old value is sweep n's value of diagonal s) -- again exactly the data dependencies of the
 // sequential reference, so the result is bit-identical, but the dependent chain shrinks from sweeps*(w+h-1) steps to
-// (w+h-1) + a few.  (du,dv) live in LDS in the skewed layout for the whole kernel; waves hand over through it, gated
-// by per-wave progress counters (LDS executes a wave's accesses in order; all LDS traffic here is volatile so the
-// compiler keeps program order).  The system C is streamed from global memory through the register ring as before.
-template <int K, int P, int U>
-__global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
-{
-  // LDS: [0,64) 16 progress counters, then the float2 cells of D.  Plain (non-volatile) LDS accesses so they stay
-  // ds_read/ds_write; ordering against the progress counters is kept with compiler barriers (the LDS unit itself
-  // executes one wave's accesses in order) and relaxed atomics for the counters.
-  extern __shared__ unsigned long long lds64[];
-  int *progress = reinterpret_cast<int *>(lds64);
+// (w+h-1) + a few.  (du,dv) live in LDS in the skewed layout; waves hand over through it, gated by per-wave progress
+// counters (the LDS unit executes one wave's accesses in order; compiler barriers keep program order, the counters
+// are relaxed atomics).  The system C is streamed from global memory (nontemporal: L2-served, never stale in L1)
+// through the register ring.
+//
+// LDS map (dynamic): u64[0..8) = 16 int progress counters, u64[8 ..) = float2 cells of D ((S+2) rows of RPD cells:
+// row S stays zero, row S+1 is scratch for the tail steps), then whatever the calling kernel appends.
+extern __shared__ unsigned long long fotg_lds64[];
+
+__device__ __forceinline__ float2 lds_d_ld(int idx) { return __builtin_bit_cast(float2, fotg_lds64[8 + idx]); }
+__device__ __forceinline__ void lds_d_st(int idx, float2 v) { fotg_lds64[8 + idx] = __builtin_bit_cast(unsigned long long, v); }
 #define FOTG_CBAR() asm volatile("" ::: "memory")
-  auto ldsld = [&](int idx) { return __builtin_bit_cast(float2, lds64[8 + idx]); };
-  auto ldsst = [&](int idx, float2 v) { lds64[8 + idx] = __builtin_bit_cast(unsigned long long, v); };
+
+// call with all threads of the block, then __syncthreads()
+__device__ __forceinline__ void sor_pipe_reset_progress()
+{
+  int *progress = reinterpret_cast<int *>(fotg_lds64);
+  if (threadIdx.x < 16) progress[threadIdx.x] = threadIdx.x == 15 ? 0x7fffffff : -1;   // slot 15: always-ready dummy leader of wave 0
+}
+
+// one sweep by the calling wave `wv` (0 <= wv < nsweeps)
+template <int K, int P, int U>
+__device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float omega, int wv, int lane)
+{
+  int *progress = reinterpret_cast<int *>(fotg_lds64);
   auto prog_load = [&](int i) { const int v = __hip_atomic_load(&progress[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); FOTG_CBAR(); return v; };
   auto prog_store = [&](int i, int v) { FOTG_CBAR(); __hip_atomic_store(&progress[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // lanes beyond the image own K padding rows (columns RP.. of D, all zero) and run with omega = 0: they read zeros,
+  // compute zeros and write zeros, so the loop body needs no exec-mask branches
   const bool act = lane < a.nlanes;
   const int r0 = act ? lane * K : a.RP;
   const float om_lane = act ? omega : 0.f;
-  const float4 *__restrict__ C = a.Cp(pair);
-  float2 *Dg = a.Dp(pair);
   const int S = a.S, RP = a.RP, RPD = a.RPD;
-  const int ncell = (S + 1) * RPD;                            // + one scratch row (S+1) that tail steps write to
-  // global -> LDS, 16 B per lane and 4 loads in flight per lane (RPD is even, so cells pair up)
-  {
-    const float4 *g4 = reinterpret_cast<const float4 *>(Dg);
-    const int n2 = ncell >> 1;
-    for (int k = threadIdx.x; k < n2; k += 4 * blockDim.x) {
-      float4 v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const int kk = k + q * blockDim.x; v[q] = kk < n2 ? g4[kk] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kk = k + q * blockDim.x;
-        if (kk < n2) { ldsst(2 * kk, make_float2(v[q].x, v[q].y)); ldsst(2 * kk + 1, make_float2(v[q].z, v[q].w)); }
-      }
-    }
-  }
-  if (threadIdx.x < 16) progress[threadIdx.x] = threadIdx.x == 15 ? 0x7fffffff : -1;   // slot 15: always-ready dummy leader of wave 0
-  __syncthreads();
   const int lead = wv > 0 ? wv - 1 : 15;
-  const unsigned lead_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long *)lds64 + 4u * (unsigned)lead;
+  const unsigned lead_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long *)fotg_lds64 + 4u * (unsigned)lead;
 
   struct Stage { float4 c[K][2]; };
   Stage ring[P];
-  const char *Cb = reinterpret_cast<const char *>(C);
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  const char *Cb = reinterpret_cast<const char *>(a.Cp(pair));
   const unsigned c_lane = (unsigned)r0 * 32u, c_row = (unsigned)RP * 32u;
   auto issue = [&](Stage &st, int row) {
     row = row < S ? row : S;                                   // row S is the spare all-zero row
-    const float4 *cp = reinterpret_cast<const float4 *>(Cb + (size_t)((unsigned)row * c_row) + c_lane);
+    const vf4 *cp = reinterpret_cast<const vf4 *>(Cb + (size_t)((unsigned)row * c_row) + c_lane);
 #pragma unroll
-    for (int m = 0; m < K; ++m) { st.c[m][0] = cp[2 * m]; st.c[m][1] = cp[2 * m + 1]; }
+    for (int m = 0; m < K; ++m) {
+      const vf4 x = __builtin_nontemporal_load(cp + 2 * m), y = __builtin_nontemporal_load(cp + 2 * m + 1);
+      st.c[m][0] = make_float4(x.x, x.y, x.z, x.w); st.c[m][1] = make_float4(y.x, y.y, y.z, y.w);
+    }
   };
   struct Old { float2 own[K]; float2 nxt[K + 1]; };
   Old oldq[2];
@@ -443,13 +481,12 @@ __global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
     row = row < S ? row : S - 1;
     const int d0 = row * RPD + r0, d1 = d0 + RPD;
 #pragma unroll
-    for (int m = 0; m < K; ++m) o.own[m] = ldsld(d0 + m);
+    for (int m = 0; m < K; ++m) o.own[m] = lds_d_ld(d0 + m);
 #pragma unroll
-    for (int m = 0; m <= K; ++m) o.nxt[m] = ldsld(d1 + m);
+    for (int m = 0; m <= K; ++m) o.nxt[m] = lds_d_ld(d1 + m);
   };
-  // a follower may touch diagonal d (it reads d and d+1) once its leader has completed diagonal d+1
-  // The spin is inline asm on purpose: a C loop here makes the compiler flush vmcnt (drain the C prefetch ring)
-  // in front of it on every step.
+  // A follower may touch diagonal d (it reads d and d+1) once its leader has completed diagonal d+1.  The spin is
+  // inline asm on purpose: a C loop here makes the compiler flush vmcnt (drain the C prefetch ring) in front of it.
   auto wait_leader = [&](int d, int &seen) {
     const int need = (d + 1 < S - 1) ? d + 1 : S - 1;
     if (seen < need) {
@@ -466,7 +503,6 @@ __global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
       seen = v;
     }
   };
-  if (wv < a.nsweeps) {
 #pragma unroll
   for (int p = 0; p < P; ++p) issue(ring[p], p);
   int seen = -1;
@@ -494,7 +530,7 @@ __global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
       {                                                        // tail steps (s >= S) write the scratch row
         const int dst = (s < S ? s : S + 1) * RPD + r0;
 #pragma unroll
-        for (int m = 0; m < K; ++m) ldsst(dst + m, res[m]);
+        for (int m = 0; m < K; ++m) lds_d_st(dst + m, res[m]);
         prog_store(wv, s < S ? s : S - 1);                     // after the data: LDS keeps a wave's order
       }
 #pragma unroll
@@ -507,18 +543,126 @@ __global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
       seen = prog_load(lead);
     }
   }
+}
+
+// stand-alone launch of one sor_coupled call: D global -> LDS, sweeps, LDS -> global
+template <int K, int P, int U>
+__global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
+{
+  const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float2 *Dg = a.Dp(pair);
+  const int ncell = (a.S + 1) * a.RPD;
+  // global -> LDS, 16 B per lane and 4 loads in flight per lane (RPD is even, so cells pair up)
+  {
+    const float4 *g4 = reinterpret_cast<const float4 *>(Dg);
+    const int n2 = ncell >> 1;
+    for (int k = threadIdx.x; k < n2; k += 4 * blockDim.x) {
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int kk = k + q * blockDim.x; v[q] = kk < n2 ? g4[kk] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kk = k + q * blockDim.x;
+        if (kk < n2) { lds_d_st(2 * kk, make_float2(v[q].x, v[q].y)); lds_d_st(2 * kk + 1, make_float2(v[q].z, v[q].w)); }
+      }
+    }
   }
-#undef FOTG_CBAR
+  sor_pipe_reset_progress();
+  __syncthreads();
+  if (wv < a.nsweeps) sor_pipe_wave<K, P, U>(a, pair, omega, wv, lane);
   __syncthreads();
   {
     float4 *g4 = reinterpret_cast<float4 *>(Dg);
     const int n2 = ncell >> 1;
     for (int k = threadIdx.x; k < n2; k += blockDim.x) {
-      const float2 a0 = ldsld(2 * k), a1 = ldsld(2 * k + 1);
+      const float2 a0 = lds_d_ld(2 * k), a1 = lds_d_ld(2 * k + 1);
       g4[k] = make_float4(a0.x, a0.y, a1.x, a1.y);
     }
   }
 }
+
+// The whole fixed-point loop of one level in ONE launch, one workgroup per pair (refine_variational.cpp:182-221):
+//   repeat inner times { smoothness, data term + sub_laplacian + block inverse -> system C ; sor_coupled } ; flow = w + d.
+// (du,dv) never leave LDS; the smoothness weights live in an LDS plane; C goes through global memory (L2) to the
+// solver waves of the same workgroup.  Replaces 2*inner + 2 launches (and the LDS copy-in/out of D) per level.
+template <int NOC, int K, int P, int U>
+__global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
+                                                             float half_gamma_over3, float omega, float *__restrict__ flow, long flow_stride)
+{
+  const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = a.w, h = a.h, st = a.st, S = a.S, RPD = a.RPD;
+  const int ncell = (S + 2) * RPD;
+  float *sm = reinterpret_cast<float *>(fotg_lds64 + 8 + ncell);            // smoothness plane [h][w]
+  const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
+  for (int k = threadIdx.x; k < ncell; k += blockDim.x) lds_d_st(k, make_float2(0.f, 0.f));     // image_erase(du), (dv) (:185-186)
+  __syncthreads();
+  constexpr int B = 4;                                           // pixels per thread whose global loads are in flight together
+  const int npx = w * h, nth = blockDim.x;
+  for (int it = 0; it < inner; ++it) {
+    for (int k0 = threadIdx.x; k0 < npx; k0 += B * nth) {        // compute_smoothness first half (:126-139)
+      float gx[B][5], gy[B][5];                                  // wx, wy at centre, left, right, top, bottom (clamped)
+      int qi[B], qj[B];
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const int px = k0 + q * nth < npx ? k0 + q * nth : npx - 1;
+        const int i = px % w, j = px / w;
+        qi[q] = i; qj[q] = j;
+        const int jc[5] = {j, j, j, clampi(j - 1, h), clampi(j + 1, h)}, ic[5] = {i, clampi(i - 1, w), clampi(i + 1, w), i, i};
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { gx[q][t] = wx[jc[t] * st + ic[t]]; gy[q][t] = wy[jc[t] * st + ic[t]]; }
+      }
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        if (k0 + q * nth >= npx) continue;
+        const int i = qi[q], j = qj[q];
+        const int jc[5] = {j, j, j, clampi(j - 1, h), clampi(j + 1, h)}, ic[5] = {i, clampi(i - 1, w), clampi(i + 1, w), i, i};
+        float2 uvv[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          const float2 d = lds_d_ld((ic[t] + jc[t]) * RPD + jc[t]);
+          uvv[t] = make_float2(gx[q][t] + d.x, gy[q][t] + d.y);  // (uu,vv) = (wx+du, wy+dv)
+        }
+        sm[j * w + i] = smooth_w(uvv[1], uvv[0], uvv[2], uvv[3], uvv[4], j, h, quarter_alpha);
+      }
+    }
+    __syncthreads();
+    for (int k0 = threadIdx.x; k0 < npx; k0 += B * nth) {        // second half (:141-163) + data term + laplacian + inverse
+      PixIn<NOC> pin[B];
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const int px = k0 + q * nth < npx ? k0 + q * nth : npx - 1;
+        pin[q] = data_load<NOC>(a, pair, px % w, px / w);
+      }
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const int px = k0 + q * nth;
+        if (px >= npx) continue;
+        const int i = px % w, j = px / w;
+        const float s_o = sm[px];
+        const float hr = (i < w - 1) ? s_o + sm[px + 1] : 0.0f;
+        const float hl = (i > 0) ? sm[px - 1] + s_o : 0.0f;
+        const float vb = (j < h - 1) ? s_o + sm[px + w] : 0.0f;
+        const float vt = (j > 0) ? sm[px - w] + s_o : 0.0f;
+        const float2 duv = lds_d_ld((i + j) * RPD + j);
+        data_term_compute<NOC>(a, pair, i, j, pin[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
+      }
+    }
+    sor_pipe_reset_progress();
+    __syncthreads();                                             // also drains the C stores (vmcnt(0)) before the solver reads them
+    if (wv < a.nsweeps) sor_pipe_wave<K, P, U>(a, pair, omega, wv, lane);
+    __syncthreads();
+  }
+  float *f = flow + (size_t)pair * flow_stride;                  // refine_variational.cpp:208-221
+  for (int px = threadIdx.x; px < w * h; px += blockDim.x) {
+    const int i = px % w, j = px / w, o = j * st + i;
+    const float2 d = lds_d_ld((i + j) * RPD + j);
+    f[2 * px] = wx[o] + d.x;
+    f[2 * px + 1] = wy[o] + d.y;
+  }
+  float2 *Dg = a.Dp(pair);                                       // keep the global copy of (du,dv) current (test taps)
+  for (int k = threadIdx.x; k < (S + 1) * RPD; k += blockDim.x) Dg[k] = lds_d_ld(k);
+}
+#undef FOTG_CBAR
 
 // red-black ordering of the same block update (throughput mode; deviates from the reference by ~0.07 px)
 __global__ __launch_bounds__(1024) void vr_sor_redblack_kernel(VrArgs a, int iterations, float omega)

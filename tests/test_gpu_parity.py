@@ -173,6 +173,37 @@ def test_end_to_end_parity(case, op_point, sor_mode, alley):
     assert np.array_equal(ofc.calc(dev(f0), dev(f1)).cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("path", ["1", "2"])
+def test_solver_fallback_paths(path, alley, monkeypatch):
+    """the automatic dispatch picks the fused / sweep-pipelined LDS solvers at these sizes; force the single-wave
+    global-memory solver (1) and the unfused pipelined solver (2) and require the same bits"""
+    F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_PATH", path)
+    for case, op_point in (("alley", 2), ("synth_rgb", 2), ("synth_odd", 3)):
+        f0, f1, noc = frames(case, alley)
+        h, w = f0.shape[:2]
+        op = F.operating_point(op_point, w, noc)
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        p = oracle_params(O, op)
+        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (path, case)
+
+
+def test_4k_quality_preset(monkeypatch):
+    """BASELINE configs[3]: 3840x2160, op-pt 4 (ps=12, stride 3, scales 7..2 = 6 levels, 128 LK iterations, refinement
+    on a 960x544 finest level whose (du,dv) do not fit LDS -> K=12 rows per lane global-memory solver)"""
+    F, OFClass, _, O = _mods()
+    f0, f1 = synth_pair(2160, 3840, seed=99)
+    op = F.operating_point(4, 3840, 1)
+    assert (op.coarsest_scale, op.finest_scale) == (7, 2)
+    ofc = OFClass(op, F.img_params(width=3840, height=2160, padding=12))
+    got = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+    assert got.shape == (544, 960, 2)
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    assert np.array_equal(got, ref)
+
+
 def test_golden_flo(alley, alley_golden_flow):
     """the reference's only golden output (kroeger/flows/alley_0001.flo): mean EPE <= 0.03 px, the same distance the
     unmodified kroeger build has to it (0.026 / 0.17 / 0.50)"""
