@@ -76,25 +76,52 @@ class HipEvents:
         return ms.value / reps
 
 
-def kernel_breakdown(ofc, I0, I1, out, lib, stream_ptr, reps=5):
+def stage_breakdown(ofc, I0, I1, out, lib, stream_ptr, reps=5):
     """per-stage GPU time of one step, each stage launched alone between HIP events on the launch stream"""
     from flowonthego_amd._lib import check
     ev = HipEvents()
     op, n, h = ofc.op, I0.shape[0], ofc._h
     p = lambda t: C.c_void_p(t.data_ptr())
     st = {}
-    st["pyramid(I0)+pyramid(I1)"] = ev.time_ms(lambda: (check(lib.fotg_pyramid(h, n, p(I0), 0, stream_ptr)),
-                                                        check(lib.fotg_pyramid(h, n, p(I1), 1, stream_ptr))), stream_ptr, reps)
+    st["pyramid(I0,I1)"] = ev.time_ms(lambda: check(lib.fotg_pyramid_pair(h, n, p(I0), p(I1), 3, stream_ptr)), stream_ptr, reps)
     check(lib.fotg_calc_batch(h, n, p(I0), p(I1), None, p(out), stream_ptr))      # leaves every level's state valid
     for sl in range(op.coarsest_scale, op.finest_scale - 1, -1):
-        i0, s0 = ofc.level_ptr(0, sl, 0); ix, _ = ofc.level_ptr(0, sl, 1); iy, _ = ofc.level_ptr(0, sl, 2)
+        i0, s0 = ofc.level_ptr(0, sl, 0)
         i1, _ = ofc.level_ptr(1, sl, 0)
+        ip = ofc.iparams[sl - op.finest_scale]
         st["lk[%d]" % sl] = ev.time_ms(lambda: check(lib.fotg_grid_optimize(h, sl, n, stream_ptr)), stream_ptr, reps)
-        fl = torch.empty((n, ofc.iparams[sl - op.finest_scale].height, ofc.iparams[sl - op.finest_scale].width, 2), device=I0.device)
+        fl = torch.empty((n, ip.height, ip.width, 2), device=I0.device)
         st["densify[%d]" % sl] = ev.time_ms(lambda: check(lib.fotg_grid_aggregate(h, sl, n, p(fl), stream_ptr)), stream_ptr, reps)
         if op.use_var_ref:
             st["varref[%d]" % sl] = ev.time_ms(lambda: check(lib.fotg_varref(h, sl, n, C.c_void_p(i0), C.c_void_p(i1), s0, p(fl), stream_ptr)), stream_ptr, reps)
     return st
+
+
+def roofline(ofc, I0, I1, lib, stream_ptr, batch):
+    """HBM roofline of the kernel that moves the path's algorithmic bytes: pyr_base_kernel reads every input frame
+    exactly once (one launch = both frames of `batch` pairs) and writes level 4.  Algorithmic bytes per launch =
+    SURVEY.md 8(d)'s 2*W*H*4 B per pair x batch (+ the level-4 pixels it writes).  Duration: HIP events around that
+    kernel alone on the launch stream.  traffic: PMC-measured HBM bytes per launch from profiles/ (separate
+    rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction), same workload."""
+    from flowonthego_amd._lib import check
+    ev = HipEvents()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ms = ev.time_ms(lambda: check(lib.fotg_pyramid_pair(ofc._h, batch, p(I0), p(I1), 1, stream_ptr)), stream_ptr, 20)
+    lw, lh = ofc.width >> 4, ofc.height >> 4
+    alg = batch * (2 * W * H * 4 + 2 * lw * lh * 4)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+        key = [x for x in k if "pyr_base_kernel<1, 4, true>" in x]
+        if key and batch == 64:
+            traffic = k[key[0]]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<1,4,true> (frames -> pyramid level 4, both frames of the batch in one launch)",
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms}
 
 
 def cpu_baseline(I0, I1, budget_s=15.0):
@@ -177,20 +204,12 @@ def main():
     if rank == 0:
         stream_ptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if not a.no_breakdown:
-            st = kernel_breakdown(ofc, I0, I1, out, lib, stream_ptr)
+            st = stage_breakdown(ofc, I0, I1, out, lib, stream_ptr)
             res["stage_ms"] = {k: round(v, 4) for k, v in st.items()}
-            # dominant kernel for the roofline: the pyramid base kernel is the only HBM-streaming kernel; it reads every
-            # input byte exactly once.  Algorithmic bytes per pair = 2*W*H*4 + 2*120*68*4.
-            from flowonthego_amd._lib import check
-            ev = HipEvents()
-            pI0 = C.c_void_p(I0.data_ptr())
-            ms = ev.time_ms(lambda: check(lib.fotg_pyramid(ofc._h, a.batch, pI0, 1, stream_ptr)), stream_ptr, 10)
-            alg = a.batch * (W * H * 4)                     # one launch = one frame of each of `batch` pairs
-            res["roofline"] = {"bound": "hbm", "kernel": "pyr_base_kernel<1,4> (+2 halve, +3 border launches, timed together)",
-                               "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                               "bytes_per_launch": alg, "ms_per_launch": ms}
+            res["roofline"] = roofline(ofc, I0, I1, lib, stream_ptr, a.batch)
+            # the whole path against the same roof: pairs/s x 16 654 080 B / 8 TB/s
             res["whole_path_hbm_frac"] = value / world * (2 * W * H * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS
+            res["time_dominant_stage"] = max(st, key=st.get)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(I0, I1)
         print(json.dumps(res))

@@ -33,6 +33,7 @@ SYMBOLS = [
     ("fotg_out_size", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("fotg_num_patches", C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("fotg_pyramid", C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
+    ("fotg_pyramid_pair", C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp]),
     ("fotg_level_ptr", C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_long)]),
     ("fotg_grid_init", C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_long, vp]),
     ("fotg_grid_set_target", C.c_int, [vp, C.c_int, vp, C.c_long]),

@@ -239,7 +239,7 @@ int fotg_num_patches(const fotg_ctx *c, int l, int *nopw, int *noph)
 }  // extern "C"
 // I0 and/or I1 may be given; both frames of a batch share the launches
 template <int NOC>
-static int pyramid_impl(fotg_ctx *c, int n, const float *I0, const float *I1, hipStream_t s)
+static int pyramid_impl(fotg_ctx *c, int n, const float *I0, const float *I1, hipStream_t s, int stages = 3)
 {
   const int lv = c->base_lv, ps = c->ps;
   const LevelGeom &g0 = c->geom[lv];
@@ -252,15 +252,18 @@ static int pyramid_impl(fotg_ctx *c, int n, const float *I0, const float *I1, hi
   dim3 grid((tiles + 3) / 4, nimg), block(256);
 #define BASE(LV) do { if (fast) pyr_base_kernel<NOC, LV, true><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps); \
     else pyr_base_kernel<NOC, LV, false><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps); } while (0)
-  switch (lv) {
-    case 0: BASE(0); break;
-    case 1: BASE(1); break;
-    case 2: BASE(2); break;
-    case 3: BASE(3); break;
-    default: BASE(4); break;
+  if (stages & 1) {
+    switch (lv) {
+      case 0: BASE(0); break;
+      case 1: BASE(1); break;
+      case 2: BASE(2); break;
+      case 3: BASE(3); break;
+      default: BASE(4); break;
+    }
+    LAUNCHCHK();
   }
 #undef BASE
-  LAUNCHCHK();
+  if (!(stages & 2)) return FOTG_OK;
   const int nlev = c->p.sc_f - lv + 1;
   if ((long)c->geom[c->p.sc_l].tw * c->geom[c->p.sc_l].th * NOC <= 32768 && (long)g0.w * g0.h * NOC <= 32768) {
     // small levels: one fused launch, one workgroup per image
@@ -306,6 +309,13 @@ int fotg_pyramid(fotg_ctx *c, int n, const float *I, int which, void *stream)
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
   const float *I0 = which == 0 ? I : nullptr, *I1 = which == 1 ? I : nullptr;
   return c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, (hipStream_t)stream) : pyramid_impl<3>(c, n, I0, I1, (hipStream_t)stream);
+}
+
+int fotg_pyramid_pair(fotg_ctx *c, int n, const float *I0, const float *I1, int stages, void *stream)
+{
+  if (!c || !I0 || !I1 || !(stages & 3)) return FOTG_ERR_ARG;
+  if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  return c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, (hipStream_t)stream, stages) : pyramid_impl<3>(c, n, I0, I1, (hipStream_t)stream, stages);
 }
 
 int fotg_level_ptr(fotg_ctx *c, int which, int l, int kind, float **ptr, long *pair_stride)

@@ -433,6 +433,9 @@ __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float 
 // LDS map (dynamic): u64[0..8) = 16 int progress counters, u64[8 ..) = float2 cells of D ((S+2) rows of RPD cells:
 // row S stays zero, row S+1 is scratch for the tail steps), then whatever the calling kernel appends.
 extern __shared__ unsigned long long fotg_lds64[];
+#ifndef FOTG_FUSED_NT
+#define FOTG_FUSED_NT false
+#endif
 
 __device__ __forceinline__ float2 lds_d_ld(int idx) { return __builtin_bit_cast(float2, fotg_lds64[8 + idx]); }
 __device__ __forceinline__ void lds_d_st(int idx, float2 v) { fotg_lds64[8 + idx] = __builtin_bit_cast(unsigned long long, v); }
@@ -446,7 +449,7 @@ __device__ __forceinline__ void sor_pipe_reset_progress()
 }
 
 // one sweep by the calling wave `wv` (0 <= wv < nsweeps)
-template <int K, int P, int U>
+template <int K, int P, int U, bool NT>
 __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float omega, int wv, int lane)
 {
   int *progress = reinterpret_cast<int *>(fotg_lds64);
@@ -471,7 +474,7 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
     const vf4 *cp = reinterpret_cast<const vf4 *>(Cb + (size_t)((unsigned)row * c_row) + c_lane);
 #pragma unroll
     for (int m = 0; m < K; ++m) {
-      const vf4 x = __builtin_nontemporal_load(cp + 2 * m), y = __builtin_nontemporal_load(cp + 2 * m + 1);
+      const vf4 x = NT ? __builtin_nontemporal_load(cp + 2 * m) : cp[2 * m], y = NT ? __builtin_nontemporal_load(cp + 2 * m + 1) : cp[2 * m + 1];
       st.c[m][0] = make_float4(x.x, x.y, x.z, x.w); st.c[m][1] = make_float4(y.x, y.y, y.z, y.w);
     }
   };
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
   }
   sor_pipe_reset_progress();
   __syncthreads();
-  if (wv < a.nsweeps) sor_pipe_wave<K, P, U>(a, pair, omega, wv, lane);
+  if (wv < a.nsweeps) sor_pipe_wave<K, P, U, false>(a, pair, omega, wv, lane);
   __syncthreads();
   {
     float4 *g4 = reinterpret_cast<float4 *>(Dg);
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
     }
     sor_pipe_reset_progress();
     __syncthreads();                                             // also drains the C stores (vmcnt(0)) before the solver reads them
-    if (wv < a.nsweeps) sor_pipe_wave<K, P, U>(a, pair, omega, wv, lane);
+    if (wv < a.nsweeps) sor_pipe_wave<K, P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane);
     __syncthreads();
   }
   float *f = flow + (size_t)pair * flow_stride;                  // refine_variational.cpp:208-221

@@ -89,6 +89,9 @@ int fotg_num_patches(const fotg_ctx *ctx, int level, int *nopw, int *noph); /* P
 /* cu::constructImgPyramids (src/kernels/pyramid.cpp:32-223) with kroeger semantics (run_dense.cpp:130-178).
  * which: 0 -> I0 (image + gradients), 1 -> I1 (image only; its gradients are never read, patch.cpp:266). */
 int fotg_pyramid(fotg_ctx *ctx, int n, const float *I, int which, void *stream);
+/* both frames of n pairs in shared launches (what fotg_calc_batch does).  stages: bit 0 = the HBM-streaming base
+ * kernel (frames -> level min(sc_l,4)), bit 1 = coarser levels + borders + gradients; 3 = everything. */
+int fotg_pyramid_pair(fotg_ctx *ctx, int n, const float *I0, const float *I1, int stages, void *stream);
 /* device pointer of a pyramid plane of pair 0 (pairs are `*pair_stride` floats apart).
  * kind: 0 image, 1 dx, 2 dy.  Layout (h_l+2ps) x (w_l+2ps) x noc, like the reference's padded levels. */
 int fotg_level_ptr(fotg_ctx *ctx, int which, int level, int kind, float **ptr, long *pair_stride);
