@@ -470,7 +470,7 @@ static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hip
     max_set = lds;
   }
   VrArgs b = a;
-  b.nsweeps = sweeps;
+  b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
   vr_sor_pipe_kernel<K, P, U><<<n, 256, lds, s>>>(b, omega);
   return true;
 }
@@ -503,7 +503,7 @@ static bool launch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, fl
     max_set = lds;
   }
   VrArgs b = a;
-  b.nsweeps = sweeps;
+  b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
   vr_inner_fused_kernel<NOC, K, P, U><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs);
   return true;
 }

@@ -15,6 +15,7 @@
 //   vr_sor      the sweeps of sor_coupled (solver.c:77-421) as a register-pipelined single-wave wavefront
 //   vr_finish   flow = (wx+du, wy+dv) (refine_variational.cpp:208-221)
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace fotg {
@@ -466,23 +467,24 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
 
   struct Stage { float4 c[K][2]; };
   Stage ring[P];
+  struct Old { float2 own[K]; float2 nxt[K + 1]; };
+  Old oldq[2];
   typedef float vf4 __attribute__((ext_vector_type(4)));
-  const char *Cb = reinterpret_cast<const char *>(a.Cp(pair));
-  const unsigned c_lane = (unsigned)r0 * 32u, c_row = (unsigned)RP * 32u;
-  auto issue = [&](Stage &st, int row) {
-    row = row < S ? row : S;                                   // row S is the spare all-zero row
-    const vf4 *cp = reinterpret_cast<const vf4 *>(Cb + (size_t)((unsigned)row * c_row) + c_lane);
+  // Running addresses instead of per-step products: every issue slot of this single wave is on the critical path.
+  const unsigned c_row = (unsigned)RP * 32u;
+  const char *cptr = reinterpret_cast<const char *>(a.Cp(pair)) + (size_t)r0 * 32u;   // row of C to prefetch next
+  const char *cend = cptr + (size_t)S * c_row;                                          // the spare all-zero row S
+  int lrow = r0;                                                                        // LDS cell of (diagonal s, first own row)
+  auto load_c = [&](Stage &st, const char *ptr) {
+    const vf4 *cp = reinterpret_cast<const vf4 *>(ptr);
 #pragma unroll
     for (int m = 0; m < K; ++m) {
       const vf4 x = NT ? __builtin_nontemporal_load(cp + 2 * m) : cp[2 * m], y = NT ? __builtin_nontemporal_load(cp + 2 * m + 1) : cp[2 * m + 1];
       st.c[m][0] = make_float4(x.x, x.y, x.z, x.w); st.c[m][1] = make_float4(y.x, y.y, y.z, y.w);
     }
   };
-  struct Old { float2 own[K]; float2 nxt[K + 1]; };
-  Old oldq[2];
-  auto fetch_old = [&](Old &o, int row) {                      // LDS reads of diagonals row, row+1
-    row = row < S ? row : S - 1;
-    const int d0 = row * RPD + r0, d1 = d0 + RPD;
+  auto fetch_old = [&](Old &o, int d0) {                       // LDS reads of one diagonal (own) and the next (nxt)
+    const int d1 = d0 + RPD;
 #pragma unroll
     for (int m = 0; m < K; ++m) o.own[m] = lds_d_ld(d0 + m);
 #pragma unroll
@@ -490,8 +492,7 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
   };
   // A follower may touch diagonal d (it reads d and d+1) once its leader has completed diagonal d+1.  The spin is
   // inline asm on purpose: a C loop here makes the compiler flush vmcnt (drain the C prefetch ring) in front of it.
-  auto wait_leader = [&](int d, int &seen) {
-    const int need = (d + 1 < S - 1) ? d + 1 : S - 1;
+  auto wait_need = [&](int need, int &seen) {
     if (seen < need) {
       int v;
       asm volatile("L_fotg_spin_%=:\n\t"
@@ -507,44 +508,61 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
     }
   };
 #pragma unroll
-  for (int p = 0; p < P; ++p) issue(ring[p], p);
+  for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }      // host guarantees S > P + 16
   int seen = -1;
-  wait_leader(8, seen);                                        // start with slack so the steady-state checks pass
-  fetch_old(oldq[0], 0);
-  fetch_old(oldq[1], 1);
+  wait_need(9 < S - 1 ? 9 : S - 1, seen);                      // start with slack so the steady-state checks pass
+  fetch_old(oldq[0], lrow);
+  fetch_old(oldq[1], lrow + RPD);
   float2 prev[K];
   float hl[K];
 #pragma unroll
   for (int m = 0; m < K; ++m) { prev[m] = make_float2(0.f, 0.f); hl[m] = 0.f; }
-  for (int t0 = 0; t0 < S; t0 += U) {
+  const int rpd2 = 2 * RPD;
+  // one step = one anti-diagonal.  TAIL = false: every row it touches (s .. s+P, s+3) is inside the image, so no
+  // clamps, no omega select; TAIL = true: the last chunks, where prefetches clamp to the spare rows and steps
+  // beyond S-1 run with omega = 0 into the scratch row.
+  auto step = [&](auto tail_tag, int u, int s) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    Stage &st = ring[u % P];
+    Old &od = oldq[u & 1];
+    const float om = (!TAIL || s < S) ? om_lane : 0.f;
+    float2 top0;
+    top0.x = dpp_wave_shr1(prev[K - 1].x);
+    top0.y = dpp_wave_shr1(prev[K - 1].y);
+    float2 res[K];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = t0 + u;
-      Stage &st = ring[u % P];
-      Old &od = oldq[u & 1];
-      const float om = (s < S) ? om_lane : 0.f;
-      float2 top0;
-      top0.x = dpp_wave_shr1(prev[K - 1].x);
-      top0.y = dpp_wave_shr1(prev[K - 1].y);
-      float2 res[K];
+    for (int m = 0; m < K; ++m)
+      res[m] = sor_update(od.own[m], st.c[m][0], st.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], od.nxt[m], od.nxt[m + 1], om);
+    {
+      const int dst = (!TAIL || s < S) ? lrow : (S + 1) * RPD + r0;          // tail steps write the scratch row
 #pragma unroll
-      for (int m = 0; m < K; ++m)
-        res[m] = sor_update(od.own[m], st.c[m][0], st.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], od.nxt[m], od.nxt[m + 1], om);
-      {                                                        // tail steps (s >= S) write the scratch row
-        const int dst = (s < S ? s : S + 1) * RPD + r0;
-#pragma unroll
-        for (int m = 0; m < K; ++m) lds_d_st(dst + m, res[m]);
-        prog_store(wv, s < S ? s : S - 1);                     // after the data: LDS keeps a wave's order
-      }
-#pragma unroll
-      for (int m = 0; m < K; ++m) { prev[m] = res[m]; hl[m] = st.c[m][1].y; }
-      issue(st, s + P);
-      // refill this slot with diagonals s+2, s+3 (consumed two steps from now: LDS latency is off the chain);
-      // `seen` comes from the poll issued one step ago, so in steady state nothing waits here
-      wait_leader(s + 2, seen);
-      fetch_old(od, s + 2);
-      seen = prog_load(lead);
+      for (int m = 0; m < K; ++m) lds_d_st(dst + m, res[m]);
+      prog_store(wv, (!TAIL || s < S) ? s : S - 1);              // after the data: LDS keeps a wave's order
     }
+#pragma unroll
+    for (int m = 0; m < K; ++m) { prev[m] = res[m]; hl[m] = st.c[m][1].y; }
+    load_c(st, cptr);                                            // row s+P
+    if (!TAIL || cptr < cend) cptr += c_row;                     // (clamped at the spare zero row S)
+    // refill this slot with diagonals s+2, s+3 (consumed two steps from now: LDS latency is off the chain); `seen`
+    // comes from the poll issued one step ago, so in steady state nothing waits here
+    if (!TAIL) {
+      wait_need(s + 3, seen);
+      fetch_old(od, lrow + rpd2);
+    } else {
+      wait_need(s + 3 < S - 1 ? s + 3 : S - 1, seen);
+      fetch_old(od, (s + 2 < S ? s + 2 : S - 1) * RPD + r0);
+    }
+    seen = prog_load(lead);
+    lrow += RPD;
+  };
+  int t0 = 0;
+  for (; t0 + U + P + 3 <= S; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(std::false_type{}, u, t0 + u);
+  }
+  for (; t0 < S; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(std::true_type{}, u, t0 + u);
   }
 }
 
