@@ -191,9 +191,12 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       a.S = gl.w + gl.h - 1; a.SC = a.S + 1;        // one spare (zero) row: idle lanes read past the last row
       a.c_pair_stride = (long)a.SC * a.RP * 2;
       a.d_pair_stride = (long)(a.S + 1) * a.RPD;
-      ALLOC(c->vrC[l], B * a.c_pair_stride * sizeof(float4));
-      ALLOC(c->vrD[l], B * a.d_pair_stride * sizeof(float2));
-      if (hipMemset(c->vrC[l], 0, B * a.c_pair_stride * sizeof(float4)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+      // + slack: idle lanes of the solver read K cells past the row they are parked on, i.e. past the last pair's
+      // last (spare) row
+      const size_t cbytes = B * a.c_pair_stride * sizeof(float4) + 64 * 16 * 2 * sizeof(float4);
+      ALLOC(c->vrC[l], cbytes);
+      ALLOC(c->vrD[l], B * a.d_pair_stride * sizeof(float2) + 4096);
+      if (hipMemset(c->vrC[l], 0, cbytes) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       a.C = c->vrC[l]; a.D = c->vrD[l];
     }
   }

@@ -294,6 +294,11 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_al
   const int i = x0 + lx, j = y0 + ly, o = j * st + i;
   const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
   const float2 *D = a.Dp(pair);
+  // this pixel's own inputs first: their global-load latency overlaps the two LDS staging phases below
+  const bool inimg = i < w && j < h;
+  const int ic0 = inimg ? i : 0, jc0 = inimg ? j : 0;
+  const PixIn<NOC> pin = data_load<NOC>(a, pair, ic0, jc0);
+  const float2 duv = D[a.didx(ic0, jc0)];
   // (uu,vv) = (wx+du, wy+dv) (refine_variational.cpp:208-214), coordinates clamped like the replicate borders of the
   // 3-tap filters (image.c:436-464); du,dv come from the skewed D
   for (int k = threadIdx.x; k < UW * UH; k += 256) {
@@ -319,8 +324,7 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_al
   const float vb = (j < h - 1) ? s_o + sm[sc + SW] : 0.0f;
   const float vt = (j > 0) ? sm[sc - SW] + s_o : 0.0f;
 
-  const float2 duv = D[a.didx(i, j)];
-  data_term_pixel<NOC>(a, pair, i, j, hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
+  data_term_compute<NOC>(a, pair, i, j, pin, hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
 }
 
 // one pixel update of sor_coupled (solver.c:122-130 etc.).  du_l/du_t are the NEW left/top values, du_r/du_b the OLD

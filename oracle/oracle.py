@@ -194,15 +194,19 @@ def varref(I0_lvl, I1_lvl, w, h, lvl, params, flow, sor_mode=0):
     return flow
 
 
-def flow_pyr(P0, P1, params, sor_mode=0, dump=False):
-    """OFClass ctor on prebuilt pyramids -> finest-scale flow (h_l, w_l, 2) [+ per-level dump list]"""
+def flow_pyr(P0, P1, params, sor_mode=0, dump=False, initflow=None):
+    """OFClass ctor on prebuilt pyramids -> finest-scale flow (h_l, w_l, 2) [+ per-level dump list]
+    initflow: optional (h/2^(sc_f+1), w/2^(sc_f+1), 2) warm start (kroeger/oflow.cpp:217-220)"""
     w, h = P0.level_wh(params.sc_l)
+    if initflow is not None:
+        initflow = f32(initflow)
     out = np.zeros((h, w, 2), np.float32)
     d = None
     if dump:
         tot = sum(2 * 2 * (P0.w0 >> l) * (P0.h0 >> l) for l in range(params.sc_l, params.sc_f + 1))
         d = np.zeros(tot, np.float32)
-    lib().dis_flow_pyr(P0.ptr, P1.ptr, C.byref(params), None, P(out), int(sor_mode), P(d) if dump else None)
+    lib().dis_flow_pyr(P0.ptr, P1.ptr, C.byref(params), P(initflow) if initflow is not None else None, P(out), int(sor_mode),
+                       P(d) if dump else None)
     if not dump:
         return out
     lv, off = {}, 0

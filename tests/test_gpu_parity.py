@@ -204,6 +204,24 @@ def test_4k_quality_preset(monkeypatch):
     assert np.array_equal(got, ref)
 
 
+def test_initflow_warm_start(alley):
+    """initflow (kroeger/oflow.h:91, oflow.cpp:217-220; src/oflow.cpp:268-271): coarsest-scale patches start from 2 x the
+    given flow, sampled nearest-neighbour like a coarser scale"""
+    F, OFClass, _, O = _mods()
+    f0, f1, _ = frames("alley", alley)
+    op = F.operating_point(2, 1024, 1)
+    p = oracle_params(O, op)
+    rng = np.random.default_rng(3)
+    ih, iw = 448 >> (p.sc_f + 1), 1024 >> (p.sc_f + 1)
+    init = (rng.standard_normal((ih, iw, 2)) * 0.5).astype(np.float32)
+    P0 = O.Pyramid(O.pad_frame(f0, p.sc_f), p.sc_f, p.ps); P1 = O.Pyramid(O.pad_frame(f1, p.sc_f), p.sc_f, p.ps)
+    ref = O.flow_pyr(P0, P1, p, initflow=init)
+    ofc = OFClass(op, F.img_params(width=1024, height=436, padding=8))
+    got = ofc.calc(dev(f0), dev(f1), None, dev(init)[None], None).cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert not np.array_equal(got, ofc.calc(dev(f0), dev(f1)).cpu().numpy())      # and it does change the result
+
+
 def test_golden_flo(alley, alley_golden_flow):
     """the reference's only golden output (kroeger/flows/alley_0001.flo): mean EPE <= 0.03 px, the same distance the
     unmodified kroeger build has to it (0.026 / 0.17 / 0.50)"""
