@@ -53,6 +53,20 @@ struct fotg_ctx {
   float2 *vrD[FOTG_MAXLEV];          // skewed (du,dv) per level
   VrArgs vra[FOTG_MAXLEV];
   GridState gs[FOTG_MAXLEV];
+  // sub-batch pipelining (fotg_calc_batch): the solver's dependent chain has a latency that does not depend on the
+  // batch size while every other stage is throughput bound, so a batch is cut into sub-batches on internal streams
+  // and one sub-batch's solver latency hides behind the others' throughput work
+  int nsub;
+  hipStream_t sub_stream[8];
+  hipEvent_t ev_fork, ev_join[8];
+  // The sub-batched launch sequence (a few hundred launches on several streams) is host-bound when issued eagerly,
+  // so it is captured once into a hipGraph and replayed while the call's arguments stay the same.
+  int use_graph;
+  hipStream_t cap_stream;
+  hipGraphExec_t gexec;
+  int g_n, g_seen;
+  const float *g_I0, *g_I1, *g_init;
+  float *g_out;
 };
 
 static void fill_geom(const fotg_params &p, int Wp, int Hp, int l, LevelGeom &g)
@@ -136,6 +150,13 @@ void fotg_destroy(fotg_ctx *c)
     (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]);
   }
   (void)hipFree(c->vr);
+  for (int i = 0; i < 8; ++i) {
+    if (c->sub_stream[i]) (void)hipStreamDestroy(c->sub_stream[i]);
+    if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+  if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   delete c;
 }
 
@@ -201,6 +222,21 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
     }
   }
 #undef ALLOC
+  {
+    const char *e = getenv("FOTG_SUBBATCH");
+    c->nsub = e ? atoi(e) : 1;     // measured on MI355X, 64 x 1080p: no gain (every stage is latency-, not throughput-bound at this batch), so off by default
+    if (c->nsub < 1) c->nsub = 1;
+    if (c->nsub > 8) c->nsub = 8;
+    const char *g = getenv("FOTG_GRAPH");
+    c->use_graph = g ? atoi(g) : 1;
+    if (hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+    if (c->nsub > 1) {
+      if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+      for (int i = 0; i < c->nsub; ++i)
+        if (hipStreamCreateWithFlags(&c->sub_stream[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+    }
+  }
   *out = c;
   return FOTG_OK;
 }
@@ -654,12 +690,11 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
 /* ------------------------------------------------------------------------------------------------ */
 /* whole flow: OFClass::calc (src/oflow.cpp:211-368) with kroeger numerics (kroeger/oflow.cpp:184-337)   */
 /* ------------------------------------------------------------------------------------------------ */
-int fotg_calc_batch(fotg_ctx *c, int n, const float *I0, const float *I1, const float *initflow, float *outflow, void *stream)
+// the scale loop for pairs [0, n) of context (view) c on one stream
+static int calc_range(fotg_ctx *c, int n, const float *I0, const float *I1, const float *initflow, float *outflow, hipStream_t stream)
 {
-  if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
-  if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
   int st;
-  if ((st = c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, (hipStream_t)stream) : pyramid_impl<3>(c, n, I0, I1, (hipStream_t)stream))) return st;
+  if ((st = c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, stream) : pyramid_impl<3>(c, n, I0, I1, stream))) return st;
   for (int l = c->p.sc_f; l >= c->p.sc_l; --l) {
     if ((st = fotg_grid_init(c, l, n, c->im[0][l], c->dx0[l], c->dy0[l], c->lev_stride[l], stream))) return st;
     if ((st = fotg_grid_set_target(c, l, c->im[1][l], c->lev_stride[l]))) return st;
@@ -671,6 +706,99 @@ int fotg_calc_batch(fotg_ctx *c, int n, const float *I0, const float *I1, const 
     if (c->p.usetvref)
       if ((st = fotg_varref(c, l, n, c->im[0][l], c->im[1][l], c->lev_stride[l], out, stream))) return st;
   }
+  return FOTG_OK;
+}
+
+// a copy of the context whose per-pair arenas start at pair `p0` (nothing is owned by the copy)
+static void make_view(const fotg_ctx *c, int p0, fotg_ctx *v)
+{
+  *v = *c;
+  const size_t nv = (size_t)c->ps * c->ps * c->noc;
+  for (int l = c->base_lv; l <= c->p.sc_f; ++l) {
+    const size_t ls = (size_t)c->lev_stride[l] * p0;
+    v->im[0][l] += ls; v->im[1][l] += ls;
+    if (l < c->p.sc_l) continue;
+    const LevelGeom &g = c->geom[l];
+    v->dx0[l] += ls; v->dy0[l] += ls;
+    v->flow[l] += (size_t)p0 * g.w * g.h * 2;
+    v->p_iter[l] += (size_t)p0 * g.nop * 2;
+    v->pweight[l] += (size_t)p0 * g.nop * nv;
+    if (c->taps) {
+      v->tap_t[l] += (size_t)p0 * g.nop * nv; v->tap_tx[l] += (size_t)p0 * g.nop * nv; v->tap_ty[l] += (size_t)p0 * g.nop * nv;
+      v->tap_hes[l] += (size_t)p0 * g.nop * 3; v->tap_cnt[l] += (size_t)p0 * g.nop;
+    }
+    if (c->vr) {
+      VrArgs &a = v->vra[l];
+      a.base += (size_t)p0 * a.pair_stride; a.C += (size_t)p0 * a.c_pair_stride; a.D += (size_t)p0 * a.d_pair_stride;
+    }
+    if (p0 != 0) v->gs[l].trace_host = nullptr;
+  }
+  if (c->vr) v->vr += (size_t)p0 * c->vr_pair_stride;
+}
+
+// enqueue the whole batch on stream s (forking to the internal sub-batch streams and joining back)
+static int calc_enqueue(fotg_ctx *c, int n, const float *I0, const float *I1, const float *initflow, float *outflow, hipStream_t s)
+{
+  const int nsub = (c->nsub > 1 && n >= 4 * c->nsub) ? c->nsub : 1;    // >= 4 pairs per sub-batch
+  if (nsub == 1) return calc_range(c, n, I0, I1, initflow, outflow, s);
+  const LevelGeom &gf = c->geom[c->p.sc_l], &gc = c->geom[c->p.sc_f];
+  const size_t frame = (size_t)c->w_org * c->h_org * c->noc, oflow = (size_t)gf.w * gf.h * 2;
+  const size_t iflow = (size_t)(gc.w / 2) * (gc.h / 2) * 2;
+  HIPCHK(hipEventRecord(c->ev_fork, s));
+  int status = FOTG_OK;
+  for (int k = 0; k < nsub; ++k) {
+    const int p0 = (int)((long)n * k / nsub), p1 = (int)((long)n * (k + 1) / nsub);
+    HIPCHK(hipStreamWaitEvent(c->sub_stream[k], c->ev_fork, 0));
+    fotg_ctx v;
+    make_view(c, p0, &v);
+    const int st = calc_range(&v, p1 - p0, I0 + frame * p0, I1 + frame * p0, initflow ? initflow + iflow * p0 : nullptr,
+                              outflow + oflow * p0, c->sub_stream[k]);
+    if (st && !status) status = st;
+    for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) c->gs[l] = v.gs[l];      // keep the last grid state observable (taps)
+    HIPCHK(hipEventRecord(c->ev_join[k], c->sub_stream[k]));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
+  }
+  return status;
+}
+
+int fotg_calc_batch(fotg_ctx *c, int n, const float *I0, const float *I1, const float *initflow, float *outflow, void *stream)
+{
+  if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
+  if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  hipStream_t s = (hipStream_t)stream;
+  bool tracing = false;
+  for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) tracing |= c->gs[l].trace_host != nullptr;
+  const bool graphable = c->use_graph && !tracing && c->nsub > 1 && n >= 4 * c->nsub;
+  if (!graphable) return calc_enqueue(c, n, I0, I1, initflow, outflow, s);
+  const bool same = c->g_n == n && c->g_I0 == I0 && c->g_I1 == I1 && c->g_init == initflow && c->g_out == outflow;
+  if (same && c->gexec) {                                       // replay
+    HIPCHK(hipGraphLaunch(c->gexec, s));
+    return FOTG_OK;
+  }
+  if (!same) {                                                  // new arguments: run eagerly, remember them
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    c->g_n = n; c->g_I0 = I0; c->g_I1 = I1; c->g_init = initflow; c->g_out = outflow; c->g_seen = 1;
+    return calc_enqueue(c, n, I0, I1, initflow, outflow, s);
+  }
+  // second call with the same arguments: capture on the internal stream, instantiate, launch
+  hipGraph_t graph = nullptr;
+  HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+  const int st = calc_enqueue(c, n, I0, I1, initflow, outflow, c->cap_stream);
+  const hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
+  if (st != FOTG_OK || e != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    c->use_graph = 0;                                           // fall back to eager launches for good
+    return st != FOTG_OK ? st : calc_enqueue(c, n, I0, I1, initflow, outflow, s);
+  }
+  const hipError_t ei = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess) {
+    (void)hipGetLastError();
+    c->gexec = nullptr; c->use_graph = 0;
+    return calc_enqueue(c, n, I0, I1, initflow, outflow, s);
+  }
+  HIPCHK(hipGraphLaunch(c->gexec, s));
   return FOTG_OK;
 }
 

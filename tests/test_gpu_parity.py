@@ -189,6 +189,34 @@ def test_solver_fallback_paths(path, alley, monkeypatch):
         assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (path, case)
 
 
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_subbatch_streams_and_graph(graph, monkeypatch):
+    """optional sub-batch pipelining on internal streams (FOTG_SUBBATCH) with and without hipGraph capture: same bits,
+    also on replay and after the arguments change"""
+    F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_SUBBATCH", "2")
+    monkeypatch.setenv("FOTG_GRAPH", graph)
+    n = 8
+    pairs = [synth_pair(270, 500, seed=50 + k) for k in range(n)]
+    I0 = dev(np.stack([p[0] for p in pairs])); I1 = dev(np.stack([p[1] for p in pairs]))
+    op = F.operating_point(2, 500, 1)
+    ofc = OFClass(op, F.img_params(width=500, height=270, padding=8), max_batch=n)
+    p = oracle_params(O, op)
+    refs = [O.flow(O.pad_frame(a, p.sc_f), O.pad_frame(b, p.sc_f), p, 0) for a, b in pairs]
+    out = ofc.new_outflow(n)
+    for _ in range(4):                       # eager, capture+launch, replay, replay
+        out.zero_()
+        ofc.calc_batch(I0, I1, None, out)
+        got = out.cpu().numpy()
+        for k in range(n):
+            assert np.array_equal(got[k], refs[k]), k
+    J0 = I0.flip(0).contiguous(); J1 = I1.flip(0).contiguous()      # new arguments -> graph is dropped and rebuilt
+    for _ in range(3):
+        got = ofc.calc_batch(J0, J1).cpu().numpy()
+        for k in range(n):
+            assert np.array_equal(got[k], refs[n - 1 - k]), k
+
+
 def test_4k_quality_preset(monkeypatch):
     """BASELINE configs[3]: 3840x2160, op-pt 4 (ps=12, stride 3, scales 7..2 = 6 levels, 128 LK iterations, refinement
     on a 960x544 finest level whose (du,dv) do not fit LDS -> K=12 rows per lane global-memory solver)"""
