@@ -471,7 +471,7 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
 
   struct Stage { float4 c[K][2]; };
   Stage ring[P];
-  struct Old { float2 own[K]; float2 nxt[K + 1]; };
+  struct Old { float2 nxt[K + 1]; };                             // (du,dv) of the NEXT diagonal at rows r0 .. r0+K
   Old oldq[2];
   typedef float vf4 __attribute__((ext_vector_type(4)));
   // Running addresses instead of per-step products: every issue slot of this single wave is on the critical path.
@@ -487,15 +487,12 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
       st.c[m][0] = make_float4(x.x, x.y, x.z, x.w); st.c[m][1] = make_float4(y.x, y.y, y.z, y.w);
     }
   };
-  auto fetch_old = [&](Old &o, int d0) {                       // LDS reads of one diagonal (own) and the next (nxt)
-    const int d1 = d0 + RPD;
-#pragma unroll
-    for (int m = 0; m < K; ++m) o.own[m] = lds_d_ld(d0 + m);
+  auto fetch_nxt = [&](Old &o, int d1) {                       // LDS reads of one diagonal
 #pragma unroll
     for (int m = 0; m <= K; ++m) o.nxt[m] = lds_d_ld(d1 + m);
   };
-  // A follower may touch diagonal d (it reads d and d+1) once its leader has completed diagonal d+1.  The spin is
-  // inline asm on purpose: a C loop here makes the compiler flush vmcnt (drain the C prefetch ring) in front of it.
+  // A follower may read diagonal d once its leader has completed it.  The spin is inline asm on purpose: a C loop
+  // here makes the compiler flush vmcnt (drain the C prefetch ring) in front of it.
   auto wait_need = [&](int need, int &seen) {
     if (seen < need) {
       int v;
@@ -511,24 +508,29 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
       seen = v;
     }
   };
+  constexpr int CHK = 4;                                         // progress is published / checked every CHK steps
 #pragma unroll
-  for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }      // host guarantees S > P + 16
+  for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }      // host guarantees S >= 24
   int seen = -1;
-  wait_need(9 < S - 1 ? 9 : S - 1, seen);                      // start with slack so the steady-state checks pass
-  fetch_old(oldq[0], lrow);
-  fetch_old(oldq[1], lrow + RPD);
+  // start with slack: the steady-state check at step s (s % CHK == 0) wants the leader CHK+3 diagonals ahead
+  wait_need(2 * CHK + 4 < S - 1 ? 2 * CHK + 4 : S - 1, seen);
+  float2 own[K];                                                 // old values of the current diagonal = last step's nxt[0..K-1]
+#pragma unroll
+  for (int m = 0; m < K; ++m) own[m] = lds_d_ld(lrow + m);
+  fetch_nxt(oldq[0], lrow + RPD);
+  fetch_nxt(oldq[1], lrow + 2 * RPD);
   float2 prev[K];
   float hl[K];
 #pragma unroll
   for (int m = 0; m < K; ++m) { prev[m] = make_float2(0.f, 0.f); hl[m] = 0.f; }
-  const int rpd2 = 2 * RPD;
+  const int rpd3 = 3 * RPD;
   // one step = one anti-diagonal.  TAIL = false: every row it touches (s .. s+P, s+3) is inside the image, so no
   // clamps, no omega select; TAIL = true: the last chunks, where prefetches clamp to the spare rows and steps
   // beyond S-1 run with omega = 0 into the scratch row.
   auto step = [&](auto tail_tag, int u, int s) {
     constexpr bool TAIL = decltype(tail_tag)::value;
     Stage &st = ring[u % P];
-    Old &od = oldq[u & 1];
+    Old &od = oldq[u & 1];                                       // diagonal s+1
     const float om = (!TAIL || s < S) ? om_lane : 0.f;
     float2 top0;
     top0.x = dpp_wave_shr1(prev[K - 1].x);
@@ -536,31 +538,32 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
     float2 res[K];
 #pragma unroll
     for (int m = 0; m < K; ++m)
-      res[m] = sor_update(od.own[m], st.c[m][0], st.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], od.nxt[m], od.nxt[m + 1], om);
+      res[m] = sor_update(own[m], st.c[m][0], st.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], od.nxt[m], od.nxt[m + 1], om);
     {
       const int dst = (!TAIL || s < S) ? lrow : (S + 1) * RPD + r0;          // tail steps write the scratch row
 #pragma unroll
       for (int m = 0; m < K; ++m) lds_d_st(dst + m, res[m]);
-      prog_store(wv, (!TAIL || s < S) ? s : S - 1);              // after the data: LDS keeps a wave's order
+      if (TAIL || (u % CHK) == CHK - 1) prog_store(wv, (!TAIL || s < S) ? s : S - 1);   // after the data: LDS keeps a wave's order
     }
 #pragma unroll
-    for (int m = 0; m < K; ++m) { prev[m] = res[m]; hl[m] = st.c[m][1].y; }
+    for (int m = 0; m < K; ++m) { prev[m] = res[m]; hl[m] = st.c[m][1].y; own[m] = od.nxt[m]; }
     load_c(st, cptr);                                            // row s+P
     if (!TAIL || cptr < cend) cptr += c_row;                     // (clamped at the spare zero row S)
-    // refill this slot with diagonals s+2, s+3 (consumed two steps from now: LDS latency is off the chain); `seen`
-    // comes from the poll issued one step ago, so in steady state nothing waits here
+    // refill this slot with diagonal s+3 (consumed two steps from now: LDS latency is off the chain).  Every CHK
+    // steps make sure the leader is far enough ahead for the next CHK refills; `seen` comes from a poll issued
+    // CHK steps ago, so in steady state nothing waits here.
     if (!TAIL) {
-      wait_need(s + 3, seen);
-      fetch_old(od, lrow + rpd2);
+      if ((u % CHK) == 0) { wait_need(s + 3 + CHK - 1, seen); seen = prog_load(lead); }
+      fetch_nxt(od, lrow + rpd3);
     } else {
       wait_need(s + 3 < S - 1 ? s + 3 : S - 1, seen);
-      fetch_old(od, (s + 2 < S ? s + 2 : S - 1) * RPD + r0);
+      fetch_nxt(od, (s + 3 < S ? s + 3 : S) * RPD + r0);
+      seen = prog_load(lead);
     }
-    seen = prog_load(lead);
     lrow += RPD;
   };
   int t0 = 0;
-  for (; t0 + U + P + 3 <= S; t0 += U) {
+  for (; t0 + U + P + CHK + 3 <= S; t0 += U) {
 #pragma unroll
     for (int u = 0; u < U; ++u) step(std::false_type{}, u, t0 + u);
   }
