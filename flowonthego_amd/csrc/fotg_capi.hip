@@ -435,11 +435,17 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   a.dp_thresh_sq = c->p.dp_thresh * c->p.dp_thresh;                 // kroeger/oflow.cpp:88
   a.dr_thresh = c->p.dr_thresh; a.res_thresh = c->p.res_thresh;
   a.outlier = (float)c->ps / 2;                                     // :82
-  dim3 grid((g.nop + 3) / 4, n), block(256);
-  if (c->ps == 8 && c->noc == 1) lk_kernel<8, 1><<<grid, block, 0, s>>>(a);
-  else if (c->ps == 8) lk_kernel<8, 3><<<grid, block, 0, s>>>(a);
-  else if (c->noc == 1) lk_kernel<12, 1><<<grid, block, 0, s>>>(a);
-  else lk_kernel<12, 3><<<grid, block, 0, s>>>(a);
+  // Patches per wave (packed scalar domain).  More patches per wave = fewer wave instructions per patch but a longer
+  // wave, so only when the launch is throughput bound (enough patches to fill the GPU several times over).
+  dim3 block(256);
+  int np = ((long)n * g.nop >= 4096) ? 2 : 1;          // measured (MI355X, 64 x 1080p): NP 2 beats 1 and 4 at 8.6k and 32k patches, NP 1 wins at 2.5k
+  if (const char *e = getenv("FOTG_LK_NP")) np = atoi(e);
+#define LK(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
+  if (c->ps == 8 && c->noc == 1) { if (np >= 4) LK(8, 1, 4); else if (np == 2) LK(8, 1, 2); else LK(8, 1, 1); }
+  else if (c->ps == 8) { if (np >= 2) LK(8, 3, 2); else LK(8, 3, 1); }
+  else if (c->noc == 1) { if (np >= 2) LK(12, 1, 2); else LK(12, 1, 1); }
+  else LK(12, 3, 1);
+#undef LK
   LAUNCHCHK();
   if (gs.trace_host) {
     HIPCHK(hipStreamSynchronize(s));

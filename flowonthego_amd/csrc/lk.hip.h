@@ -37,19 +37,28 @@ struct LkArgs {
   float dp_thresh_sq, dr_thresh, res_thresh, outlier;
 };
 
-template <int PS, int NOC>
+// NP patches per wave.  The per-pixel work (template, bilinear query patch, residual, wave reductions) runs patch
+// after patch with one pixel per lane as described above.  Everything that is a per-patch SCALAR in the reference --
+// the 2x2 Cholesky solve, the position update, the outlier / border tests, the termination tests -- would cost the
+// same wave instructions whether one lane or 64 need the result, and it is most of the loop (four IEEE divisions and
+// a square root are ~60 instructions).  So the scalars of the NP patches are PACKED: lanes [k*64/NP, (k+1)*64/NP)
+// carry the state of patch k, the scalar code runs once per iteration for all NP patches, and only the five values
+// the pixel work needs (window index, four bilinear weights) are read back per patch with v_readlane.
+template <int PS, int NOC, int NP>
 __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
 {
   constexpr int NPIX = PS * PS;
   constexpr int NSLOT = (NPIX + 63) / 64;
+  constexpr int NE = NSLOT * NOC;
   constexpr int NV = NPIX * NOC;
   constexpr int PAD = PS;
   constexpr int WIN = 2 * PS + 4;                    // window edge, see the column bound below
-  __shared__ float win_all[4][WIN * WIN * NOC];
-  float *win = win_all[threadIdx.x >> 6];
-  const int lane = threadIdx.x & 63;
-  const int ip = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ip >= a.g.nop) return;                         // wave-uniform
+  constexpr int G = 64 / NP;                         // lanes per patch in the packed domain
+  __shared__ float win_all[4][NP][WIN * WIN * NOC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gid = lane / G;
+  const int ipw = (blockIdx.x * 4 + wave) * NP;      // first patch of this wave
+  if (ipw >= a.g.nop) return;                        // wave-uniform
   const int pair = blockIdx.y;
   const int tw = a.g.tw;
   const float *I0 = a.I0 + (size_t)pair * a.img_stride;
@@ -57,12 +66,8 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
   const float *I0y = a.I0y + (size_t)pair * a.img_stride;
   const float *I1 = a.I1 + (size_t)pair * a.img_stride;
 
-  // patch id -> reference position (patchgrid.cpp:57-66: i = x*noph + y)
-  const int gx = ip / a.g.noph, gy = ip % a.g.noph;
-  const float rx = (float)(gx * a.g.steps + a.g.offw), ry = (float)(gy * a.g.steps + a.g.offh);
-
-  // per-lane pixel offsets inside the patch
-  int offx[NSLOT], offy[NSLOT];
+  // per-lane pixel offsets inside the patch (the same for every patch)
+  int offx[NSLOT], offy[NSLOT], poff[NSLOT];
   bool have[NSLOT];
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
@@ -70,176 +75,233 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
     have[s] = q < NPIX;
     offy[s] = q / PS - PS / 2;
     offx[s] = q % PS - PS / 2;
-  }
-
-  // ---- template + gradients at round(pt_ref)+pad (patch.cpp:287-332) ----
-  float T[NSLOT * NOC], Tx[NSLOT * NOC], Ty[NSLOT * NOC];
-  {
-    const int px = (int)rx + PAD, py = (int)ry + PAD;    // pt_ref is integer valued: round() is exact
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-      const size_t idx = ((size_t)(px + offx[s]) + (size_t)(py + offy[s]) * tw) * NOC;
-#pragma unroll
-      for (int c = 0; c < NOC; ++c) {
-        T[s * NOC + c] = have[s] ? I0[idx + c] : 0.f;
-        Tx[s * NOC + c] = have[s] ? I0x[idx + c] : 0.f;
-        Ty[s * NOC + c] = have[s] ? I0y[idx + c] : 0.f;
-      }
-    }
+    poff[s] = (offy[s] * WIN + offx[s]) * NOC;
   }
   auto lane_sum = [&](const float *v) {
     float acc = v[0];
 #pragma unroll
-    for (int k = 1; k < NSLOT * NOC; ++k)
+    for (int k = 1; k < NE; ++k)
       if (have[k / NOC]) acc = acc + v[k];
     return acc;
   };
   auto lane_dot = [&](const float *x, const float *y) {
     float acc = x[0] * y[0];
 #pragma unroll
-    for (int k = 1; k < NSLOT * NOC; ++k)
+    for (int k = 1; k < NE; ++k)
       if (have[k / NOC]) acc = acc + x[k] * y[k];
     return acc;
   };
-  if (a.patnorm > 0) {                                   // patch.cpp:330-331
-    const float m = wave_sum(lane_sum(T)) / (float)NV;
+  auto packf = [&](const float (&v)[NP]) {
+    float x = v[0];
 #pragma unroll
-    for (int k = 0; k < NSLOT * NOC; ++k) T[k] -= m;
-  }
-  float h00 = wave_sum(lane_dot(Tx, Tx));                // patch.cpp:74-77
-  float h01 = wave_sum(lane_dot(Tx, Ty));
-  float h11 = wave_sum(lane_dot(Ty, Ty));
-  if (h00 * h11 - h01 * h01 == 0.f) {                    // :78-82  (float += 1e-10 in double, like the reference)
-    h00 = (float)((double)h00 + 1e-10);
-    h11 = (float)((double)h11 + 1e-10);
-  }
-
-  // Cholesky factor of the (constant) Hessian, hoisted out of the loop: same values every iteration
-  const float l00 = sqrtf(h00);
-  const float l10 = h01 / l00;
-  const float l11 = sqrtf(h11 - l10 * l10);
-
-  // ---- starting flow (patchgrid.cpp:195-211): nearest neighbour of the coarser flow, x2 ----
-  float pin0 = 0.f, pin1 = 0.f;
-  if (a.flow_prev) {
-    const int fx = (int)floorf(rx / 2), fy = (int)floorf(ry / 2);
-    const float *fp = a.flow_prev + (size_t)pair * a.flow_prev_stride + 2 * (size_t)(fy * (a.g.w / 2) + fx);
-    pin0 = fp[0] * 2;
-    pin1 = fp[1] * 2;
-  }
-
-  // ---- OptimizeStart (patch.cpp:120-156) ----
-  float p0 = pin0, p1 = pin1;
-  float ptx = rx + p0, pty = ry + p1;
-  const float stx = ptx, sty = pty;
-  bool conv = false;
-  int cnt = 0;
-  float dp0 = 0.f, dp1 = 0.f, dpn_init = 1e-10f, mares = 1e5f, mares_old = 1e20f;
-  float r[NSLOT * NOC], wabs[NSLOT * NOC];
+    for (int k = 1; k < NP; ++k) x = gid == k ? v[k] : x;
+    return x;
+  };
+  auto packi = [&](const int (&v)[NP]) {
+    int x = v[0];
 #pragma unroll
-  for (int k = 0; k < NSLOT * NOC; ++k) { r[k] = 0.f; wabs[k] = 0.f; }
-  float *trace = (a.trace && pair == 0) ? a.trace + (size_t)ip * (a.max_iter + 1) * 4 : nullptr;
-  if (trace && lane < 4)
-    for (int t = 0; t <= a.max_iter; ++t) trace[t * 4 + lane] = 0.f;
+    for (int k = 1; k < NP; ++k) x = gid == k ? v[k] : x;
+    return x;
+  };
+  auto getf = [&](float x, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), k * G)); };
+  auto geti = [&](int x, int k) { return __builtin_amdgcn_readlane(x, k * G); };
 
-  const bool start_ok = !(ptx < a.g.lb || pty < a.g.lb || ptx > a.g.ubw || pty > a.g.ubh);
-  if (!start_ok) conv = true;                            // :135-141; pweight stays 0 (oracle definition D2)
-
-  // ---- stage the reachable window of I1 in LDS.  Every evaluated position is within ps/2 of the start in x and y,
-  // so the bilinear taps span columns floor(stx)-ps-1 .. floor(stx)+ps+2 (padded coordinates: + PAD); rows likewise.
-  const int wx0 = (int)floorf(stx) + PAD - PS - 1, wy0 = (int)floorf(sty) + PAD - PS - 1;
-  if (start_ok) {
-    for (int k = lane; k < WIN * WIN; k += 64) {
-      const int wy = k / WIN, wx = k % WIN;
-      const size_t src = ((size_t)clampi(wy0 + wy, a.g.th) * tw + clampi(wx0 + wx, tw)) * NOC;
+  // ---- per patch: template + gradients at round(pt_ref)+pad (patch.cpp:287-332), Hessian sums (:74-77),
+  //      starting flow (patchgrid.cpp:195-211), I1 window -> LDS
+  float T[NP][NE], Tx[NP][NE], Ty[NP][NE], r[NP][NE], wabs[NP][NE];
+  float h00u[NP], h01u[NP], h11u[NP], rxu[NP], ryu[NP], pin0u[NP], pin1u[NP];
+  int validu[NP], wx0u[NP], wy0u[NP], ipu[NP];
 #pragma unroll
-      for (int c = 0; c < NOC; ++c) win[k * NOC + c] = I1[src + c];
+  for (int k = 0; k < NP; ++k) {
+    const int ip = (ipw + k < a.g.nop) ? ipw + k : a.g.nop - 1;     // surplus slots of the last wave shadow the last patch
+    validu[k] = ipw + k < a.g.nop;
+    ipu[k] = ip;
+    // patch id -> reference position (patchgrid.cpp:57-66: i = x*noph + y)
+    const int gx = ip / a.g.noph, gy = ip % a.g.noph;
+    const float rx = (float)(gx * a.g.steps + a.g.offw), ry = (float)(gy * a.g.steps + a.g.offh);
+    rxu[k] = rx; ryu[k] = ry;
+    const int px = (int)rx + PAD, py = (int)ry + PAD;              // pt_ref is integer valued: round() is exact
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const size_t idx = ((size_t)(px + offx[s]) + (size_t)(py + offy[s]) * tw) * NOC;
+#pragma unroll
+      for (int c = 0; c < NOC; ++c) {
+        T[k][s * NOC + c] = have[s] ? I0[idx + c] : 0.f;
+        Tx[k][s * NOC + c] = have[s] ? I0x[idx + c] : 0.f;
+        Ty[k][s * NOC + c] = have[s] ? I0y[idx + c] : 0.f;
+        r[k][s * NOC + c] = 0.f; wabs[k][s * NOC + c] = 0.f;
+      }
+    }
+    if (a.patnorm > 0) {                                           // patch.cpp:330-331
+      const float m = wave_sum(lane_sum(T[k])) / (float)NV;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) T[k][e] -= m;
+    }
+    h00u[k] = wave_sum(lane_dot(Tx[k], Tx[k]));
+    h01u[k] = wave_sum(lane_dot(Tx[k], Ty[k]));
+    h11u[k] = wave_sum(lane_dot(Ty[k], Ty[k]));
+    float pin0 = 0.f, pin1 = 0.f;
+    if (a.flow_prev) {
+      const int fx = (int)floorf(rx / 2), fy = (int)floorf(ry / 2);
+      const float *fp = a.flow_prev + (size_t)pair * a.flow_prev_stride + 2 * (size_t)(fy * (a.g.w / 2) + fx);
+      pin0 = fp[0] * 2;
+      pin1 = fp[1] * 2;
+    }
+    pin0u[k] = pin0; pin1u[k] = pin1;
+    // Stage the reachable window of I1 in LDS.  Every evaluated position is within ps/2 of the start in x and y, so
+    // the bilinear taps span columns floor(stx)-ps-1 .. floor(stx)+ps+2 (padded coordinates: + PAD); rows likewise.
+    const float stx = rx + pin0, sty = ry + pin1;
+    const bool ok = !(stx < a.g.lb || sty < a.g.lb || stx > a.g.ubw || sty > a.g.ubh);
+    wx0u[k] = (int)floorf(stx) + PAD - PS - 1; wy0u[k] = (int)floorf(sty) + PAD - PS - 1;
+    if (ok) {
+      float *win = win_all[wave][k];
+      for (int t = lane; t < WIN * WIN; t += 64) {
+        const int wy = t / WIN, wx = t % WIN;
+        const size_t src = ((size_t)clampi(wy0u[k] + wy, a.g.th) * tw + clampi(wx0u[k] + wx, tw)) * NOC;
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) win[t * NOC + c] = I1[src + c];
+      }
     }
   }
 
-  bool first = start_ok;
-  while (first || !conv) {
+  // ---- packed per-patch state ----
+  float H00 = packf(h00u), H11 = packf(h11u);
+  const float H01 = packf(h01u);
+  if (H00 * H11 - H01 * H01 == 0.f) {                    // :78-82  (float += 1e-10 in double, like the reference)
+    H00 = (float)((double)H00 + 1e-10);
+    H11 = (float)((double)H11 + 1e-10);
+  }
+  // Cholesky factor of the (constant) Hessian, hoisted out of the loop: same values every iteration
+  const float L00 = sqrtf(H00);
+  const float L10 = H01 / L00;
+  const float L11 = sqrtf(H11 - L10 * L10);
+  const float RX = packf(rxu), RY = packf(ryu), PIN0 = packf(pin0u), PIN1 = packf(pin1u);
+  const int WX0 = packi(wx0u), WY0 = packi(wy0u), IP = packi(ipu);
+  const bool VALID = packi(validu) != 0;
+  // OptimizeStart (patch.cpp:120-156)
+  float P0 = PIN0, P1 = PIN1, PTX = RX + P0, PTY = RY + P1;
+  const float STX = PTX, STY = PTY;
+  const bool START_OK = VALID && !(PTX < a.g.lb || PTY < a.g.lb || PTX > a.g.ubw || PTY > a.g.ubh);
+  bool CONV = !START_OK;                                 // :135-141; pweight stays 0 (oracle definition D2)
+  int CNT = 0;
+  float DP0 = 0.f, DP1 = 0.f, DPN_INIT = 1e-10f, MARES = 1e5f, MARES_OLD = 1e20f;
+  const int trow = (a.max_iter + 1) * 4;
+  float *trace = (a.trace && pair == 0) ? a.trace : nullptr;
+  if (trace && VALID && (lane % G) < 4)
+    for (int t = 0; t <= a.max_iter; ++t) trace[(size_t)IP * trow + t * 4 + (lane % G)] = 0.f;
+
+  bool first = true;
+  while (first || __builtin_amdgcn_ballot_w64(!CONV) != 0) {
+    const bool ACT = first ? START_OK : !CONV;           // patches that run this iteration
     if (!first) {
-      cnt++;
-      // projection on the steepest-descent images (:178-179) and 2x2 LLT solve (:184)
-      float b0 = wave_sum(lane_dot(Tx, r));
-      float b1 = wave_sum(lane_dot(Ty, r));
-      const float y0 = b0 / l00;
-      const float y1 = (b1 - l10 * y0) / l11;
-      const float x1 = y1 / l11;
-      const float x0 = (y0 - l10 * x1) / l00;
-      dp0 = x0; dp1 = x1;
-      p0 -= dp0; p1 -= dp1;                              // :186
-      ptx = rx + p0; pty = ry + p1;
-      const float ddx = stx - ptx, ddy = sty - pty;
-      const bool bad = !(isfinite(dp0) && isfinite(dp1));  // oracle definition D3
-      if (bad || sqrtf(ddx * ddx + ddy * ddy) > a.outlier ||   // :199-208
-          ptx < a.g.lb || pty < a.g.lb || ptx > a.g.ubw || pty > a.g.ubh) {
-        p0 = pin0; p1 = pin1; ptx = rx + p0; pty = ry + p1;
-        conv = true;
-        if (bad) { dp0 = 0.f; dp1 = 0.f; }
+      // projection on the steepest-descent images (:178-179), per patch
+      float b0u[NP], b1u[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        b0u[k] = wave_sum(lane_dot(Tx[k], r[k]));
+        b1u[k] = wave_sum(lane_dot(Ty[k], r[k]));
+      }
+      const float B0 = packf(b0u), B1 = packf(b1u);
+      // 2x2 LLT solve (:184), packed
+      const float y0 = B0 / L00;
+      const float y1 = (B1 - L10 * y0) / L11;
+      const float x1 = y1 / L11;
+      const float x0 = (y0 - L10 * x1) / L00;
+      float nP0 = P0 - x0, nP1 = P1 - x1;                // :186
+      float nPTX = RX + nP0, nPTY = RY + nP1;
+      const float ddx = STX - nPTX, ddy = STY - nPTY;
+      const bool bad = !(isfinite(x0) && isfinite(x1));  // oracle definition D3
+      const bool reset = bad || sqrtf(ddx * ddx + ddy * ddy) > a.outlier ||   // :199-208
+                         nPTX < a.g.lb || nPTY < a.g.lb || nPTX > a.g.ubw || nPTY > a.g.ubh;
+      if (reset) { nP0 = PIN0; nP1 = PIN1; nPTX = RX + PIN0; nPTY = RY + PIN1; }
+      if (ACT) {
+        CNT++;
+        DP0 = (reset && bad) ? 0.f : x0; DP1 = (reset && bad) ? 0.f : x1;
+        P0 = nP0; P1 = nP1; PTX = nPTX; PTY = nPTY;
+        if (reset) CONV = true;
+      }
+    }
+    // ---- OptimizeComputeErrImg (:264-284): bilinear query patch (:335-402), mean, residual ----
+    {
+      const int pos2 = (int)floorf(PTX), pos3 = (int)floorf(PTY);
+      const int pos0 = (int)ceilf(PTX + .00001f) + PAD - WX0, pos1 = (int)ceilf(PTY + .00001f) + PAD - WY0;   // window coordinates
+      const float r0 = PTX - (float)pos2, r1 = PTY - (float)pos3;
+      const float WE0 = r0 * r1, WE1 = (1 - r0) * r1, WE2 = r0 * (1 - r1), WE3 = (1 - r0) * (1 - r1);
+      const int IA = (pos1 * WIN + pos0) * NOC;
+      const int ACTI = ACT ? 1 : 0;
+      float maresu[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        maresu[k] = 0.f;
+        if (geti(ACTI, k)) {                             // wave-uniform
+          const float *win = win_all[wave][k];
+          const int iab = geti(IA, k);
+          const float we0 = getf(WE0, k), we1 = getf(WE1, k), we2 = getf(WE2, k), we3 = getf(WE3, k);
+          float q[NE];
+#pragma unroll
+          for (int s = 0; s < NSLOT; ++s) {
+            const int ia = iab + poff[s];
+            const int ic = ia - WIN * NOC;
+#pragma unroll
+            for (int c = 0; c < NOC; ++c) {
+              if (have[s]) {
+                const float va = win[ia + c], vb = win[ia - NOC + c], vc = win[ic + c], vd = win[ic - NOC + c];
+                q[s * NOC + c] = we0 * va + we1 * vb + we2 * vc + we3 * vd;
+              } else q[s * NOC + c] = 0.f;
+            }
+          }
+          if (a.patnorm > 0) {
+            const float m = wave_sum(lane_sum(q)) / (float)NV;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) q[e] -= m;
+          }
+#pragma unroll
+          for (int e = 0; e < NE; ++e) { r[k][e] = q[e] - T[k][e]; wabs[k][e] = fabsf(r[k][e]); }   // :230-236
+          maresu[k] = wave_sum(lane_sum(wabs[k])) / (float)NV;   // :278
+        }
+      }
+      const float MN = packf(maresu);
+      if (ACT) {
+        const float dpn = DP0 * DP0 + DP1 * DP1;           // :272
+        if (CNT == 1) DPN_INIT = dpn;
+        MARES_OLD = MARES;
+        MARES = MN;
+        // :279-282 (the two rate tests only matter once cnt >= min_iter)
+        bool go = (CNT < a.max_iter) & (MARES > a.res_thresh);
+        if (go && CNT >= a.min_iter) go = (dpn / DPN_INIT >= a.dp_thresh_sq) & (MARES / MARES_OLD <= a.dr_thresh);
+        if (!go) CONV = true;
+        if (trace && (lane % G) == 0 && CNT <= a.max_iter) {
+          float *tr = trace + (size_t)IP * trow + CNT * 4;
+          tr[0] = P0; tr[1] = P1; tr[2] = MARES; tr[3] = (float)CNT;
+        }
       }
     }
     first = false;
-    // ---- OptimizeComputeErrImg (:264-284): bilinear query patch (:335-402), mean, residual ----
-    {
-      int pos0 = (int)ceilf(ptx + .00001f), pos1 = (int)ceilf(pty + .00001f);
-      const int pos2 = (int)floorf(ptx), pos3 = (int)floorf(pty);
-      const float r0 = ptx - (float)pos2, r1 = pty - (float)pos3;
-      const float we0 = r0 * r1, we1 = (1 - r0) * r1, we2 = r0 * (1 - r1), we3 = (1 - r0) * (1 - r1);
-      pos0 += PAD - wx0; pos1 += PAD - wy0;             // window coordinates
-      float q[NSLOT * NOC];
-#pragma unroll
-      for (int s = 0; s < NSLOT; ++s) {
-        const int ia = ((pos1 + offy[s]) * WIN + (pos0 + offx[s])) * NOC;
-        const int ic = ia - WIN * NOC;
-#pragma unroll
-        for (int c = 0; c < NOC; ++c) {
-          if (have[s]) {
-            const float va = win[ia + c], vb = win[ia - NOC + c], vc = win[ic + c], vd = win[ic - NOC + c];
-            q[s * NOC + c] = we0 * va + we1 * vb + we2 * vc + we3 * vd;
-          } else q[s * NOC + c] = 0.f;
-        }
-      }
-      if (a.patnorm > 0) {
-        const float m = wave_sum(lane_sum(q)) / (float)NV;
-#pragma unroll
-        for (int k = 0; k < NSLOT * NOC; ++k) q[k] -= m;
-      }
-#pragma unroll
-      for (int k = 0; k < NSLOT * NOC; ++k) { r[k] = q[k] - T[k]; wabs[k] = fabsf(r[k]); }   // :230-236
-      const float dpn = dp0 * dp0 + dp1 * dp1;           // :272
-      if (cnt == 1) dpn_init = dpn;
-      mares_old = mares;
-      mares = wave_sum(lane_sum(wabs)) / (float)NV;      // :278
-      // :279-282 (the two rate tests only matter once cnt >= min_iter; skip their divisions before that)
-      bool go = (cnt < a.max_iter) & (mares > a.res_thresh);
-      if (go && cnt >= a.min_iter) go = (dpn / dpn_init >= a.dp_thresh_sq) & (mares / mares_old <= a.dr_thresh);
-      if (!go) conv = true;
-      if (trace && lane == 0 && cnt <= a.max_iter) {
-        trace[cnt * 4 + 0] = p0; trace[cnt * 4 + 1] = p1; trace[cnt * 4 + 2] = mares; trace[cnt * 4 + 3] = (float)cnt;
-      }
-    }
   }
 
   // ---- results ----
-  const size_t pbase = (size_t)pair * a.g.nop + ip;
-  if (lane == 0) {
-    a.p_iter[pbase * 2] = p0;
-    a.p_iter[pbase * 2 + 1] = p1;
-    if (a.cnt) a.cnt[pbase] = cnt;
-    if (a.hes) { a.hes[pbase * 3] = h00; a.hes[pbase * 3 + 1] = h01; a.hes[pbase * 3 + 2] = h11; }
+  if (VALID && (lane % G) == 0) {
+    const size_t pb = (size_t)pair * a.g.nop + IP;
+    a.p_iter[pb * 2] = P0;
+    a.p_iter[pb * 2 + 1] = P1;
+    if (a.cnt) a.cnt[pb] = CNT;
+    if (a.hes) { a.hes[pb * 3] = H00; a.hes[pb * 3 + 1] = H01; a.hes[pb * 3 + 2] = H11; }
   }
 #pragma unroll
-  for (int s = 0; s < NSLOT; ++s)
-    if (have[s]) {
-      const size_t e = pbase * NV + (size_t)(s * 64 + lane) * NOC;
+  for (int k = 0; k < NP; ++k) {
+    if (!validu[k]) continue;
+    const size_t pbase = (size_t)pair * a.g.nop + ipu[k];
 #pragma unroll
-      for (int c = 0; c < NOC; ++c) {
-        a.pweight[e + c] = wabs[s * NOC + c];
-        if (a.tmpl) { a.tmpl[e + c] = T[s * NOC + c]; a.tdx[e + c] = Tx[s * NOC + c]; a.tdy[e + c] = Ty[s * NOC + c]; }
+    for (int s = 0; s < NSLOT; ++s)
+      if (have[s]) {
+        const size_t e = pbase * NV + (size_t)(s * 64 + lane) * NOC;
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) {
+          a.pweight[e + c] = wabs[k][s * NOC + c];
+          if (a.tmpl) { a.tmpl[e + c] = T[k][s * NOC + c]; a.tdx[e + c] = Tx[k][s * NOC + c]; a.tdy[e + c] = Ty[k][s * NOC + c]; }
+        }
       }
-    }
+  }
 }
 
 }  // namespace fotg
