@@ -10,7 +10,10 @@ op-pt 2 + refinement on).  Frame pairs are independent, so N ranks each process 
 data-path collective); value = pairs all ranks processed / max-over-ranks time.
 
 Extra objects in the JSON line:
-  roofline      for the dominant kernel of the step (by GPU time, measured live with HIP events on the launch stream)
+  roofline      HBM roofline of the kernel that moves the path's algorithmic bytes (pyr_base_kernel: every input byte
+                exactly once), duration measured live with HIP events on the launch stream
+  stage_ms      per-stage GPU time of one step (each stage alone between HIP events); time_dominant_stage names the
+                largest
   cpu_baseline  the CPU oracle (oracle/, a scalar port of the reference's kroeger/ path) timed on this box's host
                 cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -214,6 +217,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(I0, I1)
         print(json.dumps(res))
     if dist:
+        td.barrier()
         td.destroy_process_group()
 
 
