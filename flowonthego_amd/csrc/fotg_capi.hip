@@ -501,55 +501,71 @@ static void launch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStrea
   vr_sor_kernel<K, P, U><<<n, 64, 0, s>>>(a, sweeps, omega);
 }
 
-template <int K, int P>
-static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
+// Banded two-lanes-per-row solver waves (sor_band_wave).  Measured on MI355X (64 x 1080p): they lose to the
+// one-lane-per-row waves when the level fits one wave with K = 1 (the two interleaved (du,dv) chains of a lane give
+// the single in-order wave more independent work than one longer chain per lane) and win slightly when K >= 2
+// (68 rows: 3 bands of 23 rows instead of 2 rows per lane), so that is the default.  FOTG_VR_BANDS=0/1 forces (tests).
+static void set_bands(VrArgs &b, int sweeps, int max_waves)
+{
+  b.nbands = 0; b.band_rows = 0;
+  const char *e = getenv("FOTG_VR_BANDS");
+  const int force = e ? atoi(e) : -1;
+  if (force == 0 || (force < 0 && b.h <= 64)) return;
+  const int nb = (b.h + 31) / 32;
+  if (nb > 5 || sweeps * nb > max_waves || sweeps > 4) return;
+  b.nbands = nb;
+  b.band_rows = (b.h + nb - 1) / nb;
+}
+
+template <int K, int P, bool BANDED>
+static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s, const VrArgs &b, int threads)
 {
   constexpr int U = (P >= 8) ? 32 : 8 * P;
   static int max_set = 0;
-  const int lds = 64 + (a.S + 2) * a.RPD * (int)sizeof(float2);
+  const int lds = 128 + (a.S + 2) * a.RPD * (int)sizeof(float2);
   if (lds > max_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_sor_pipe_kernel<K, P, U>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_sor_pipe_kernel<K, P, U, BANDED>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
     max_set = lds;
   }
-  VrArgs b = a;
-  b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
-  vr_sor_pipe_kernel<K, P, U><<<n, 256, lds, s>>>(b, omega);
+  vr_sor_pipe_kernel<K, P, U, BANDED><<<n, threads, lds, s>>>(b, omega);
   return true;
 }
 
 // sweep-pipelined LDS solver when it applies: <= 4 sweeps (one wave each), (du,dv) of the level fit in LDS
 static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
-  const int lds = 64 + (a.S + 2) * a.RPD * (int)sizeof(float2);
+  const int lds = 128 + (a.S + 2) * a.RPD * (int)sizeof(float2);
   if (sweeps < 1 || sweeps > 4 || lds > 150 * 1024 || a.S < 24) return false;
+  VrArgs b = a;
+  b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
+  set_bands(b, sweeps, 16);
+  if (b.nbands > 0) return launch_sor_pipe<1, 8, true>(a, n, sweeps, omega, s, b, sweeps * b.nbands * 64);
   switch (a.K) {
-    case 1: return launch_sor_pipe<1, 8>(a, n, sweeps, omega, s);
-    case 2: return launch_sor_pipe<2, 8>(a, n, sweeps, omega, s);
-    case 3: return launch_sor_pipe<3, 4>(a, n, sweeps, omega, s);
-    case 4: return launch_sor_pipe<4, 4>(a, n, sweeps, omega, s);
+    case 1: return launch_sor_pipe<1, 8, false>(a, n, sweeps, omega, s, b, 256);
+    case 2: return launch_sor_pipe<2, 8, false>(a, n, sweeps, omega, s, b, 256);
+    case 3: return launch_sor_pipe<3, 4, false>(a, n, sweeps, omega, s, b, 256);
+    case 4: return launch_sor_pipe<4, 4, false>(a, n, sweeps, omega, s, b, 256);
     default: return false;
   }
 }
 
-template <int NOC, int K, int P>
-static bool launch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s)
+template <int NOC, int K, int P, bool BANDED>
+static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s)
 {
   constexpr int U = (P >= 8) ? 32 : 8 * P;
   static int max_set = 0;
-  const int lds = 64 + (a.S + 2) * a.RPD * (int)sizeof(float2) + a.w * a.h * (int)sizeof(float);
+  const int lds = 128 + (b.S + 2) * b.RPD * (int)sizeof(float2) + b.w * b.h * (int)sizeof(float);
   if (lds > max_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, K, P, U>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, K, P, U, BANDED>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
     max_set = lds;
   }
-  VrArgs b = a;
-  b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
-  vr_inner_fused_kernel<NOC, K, P, U><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs);
+  vr_inner_fused_kernel<NOC, K, P, U, BANDED><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs);
   return true;
 }
 
@@ -557,12 +573,16 @@ static bool launch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, fl
 template <int NOC>
 static bool dispatch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s)
 {
-  const int lds = 64 + (a.S + 2) * a.RPD * (int)sizeof(float2) + a.w * a.h * (int)sizeof(float);
+  const int lds = 128 + (a.S + 2) * a.RPD * (int)sizeof(float2) + a.w * a.h * (int)sizeof(float);
   // one workgroup does the per-pixel phases of its pair: only worth it for small levels (measured: 60x34 yes, 120x68 no)
   if (sweeps < 1 || sweeps > 4 || inner < 1 || lds > 156 * 1024 || a.S < 24 || a.w * a.h > 3000) return false;
+  VrArgs b = a;
+  b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
+  set_bands(b, sweeps, 8);
+  if (b.nbands > 0) return launch_inner_fused<NOC, 1, 8, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s);
   switch (a.K) {
-    case 1: return launch_inner_fused<NOC, 1, 8>(a, n, sweeps, inner, qa, hd, hg, omega, flow, fs, s);
-    case 2: return launch_inner_fused<NOC, 2, 4>(a, n, sweeps, inner, qa, hd, hg, omega, flow, fs, s);
+    case 1: return launch_inner_fused<NOC, 1, 8, false>(b, n, inner, qa, hd, hg, omega, flow, fs, s);
+    case 2: return launch_inner_fused<NOC, 2, 4, false>(b, n, inner, qa, hd, hg, omega, flow, fs, s);
     default: return false;
   }
 }

@@ -39,7 +39,7 @@ struct VrArgs {
   float2 *D;             // [pair][SC+1][RPD] float2
   long c_pair_stride;    // in float4
   long d_pair_stride;    // in float2
-  int S, SC, RP, RPD, K, nlanes, nsweeps;
+  int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows;
   __host__ __device__ float4 *Cp(int pair) const { return C + (size_t)pair * c_pair_stride; }
   __host__ __device__ float2 *Dp(int pair) const { return D + (size_t)pair * d_pair_stride; }
   __host__ __device__ size_t cidx(int i, int j) const { return ((size_t)(i + j) * RP + j) * 2; }
@@ -435,22 +435,23 @@ __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float 
 // are relaxed atomics).  The system C is streamed from global memory (nontemporal: L2-served, never stale in L1)
 // through the register ring.
 //
-// LDS map (dynamic): u64[0..8) = 16 int progress counters, u64[8 ..) = float2 cells of D ((S+2) rows of RPD cells:
+// LDS map (dynamic): u64[0..16) = 32 int progress counters, u64[16 ..) = float2 cells of D ((S+2) rows of RPD cells:
 // row S stays zero, row S+1 is scratch for the tail steps), then whatever the calling kernel appends.
 extern __shared__ unsigned long long fotg_lds64[];
+#define FOTG_LDS_HDR 16     // u64 units: 32 int progress counters (slot 31 = the always-ready dummy leader)
 #ifndef FOTG_FUSED_NT
 #define FOTG_FUSED_NT false
 #endif
 
-__device__ __forceinline__ float2 lds_d_ld(int idx) { return __builtin_bit_cast(float2, fotg_lds64[8 + idx]); }
-__device__ __forceinline__ void lds_d_st(int idx, float2 v) { fotg_lds64[8 + idx] = __builtin_bit_cast(unsigned long long, v); }
+__device__ __forceinline__ float2 lds_d_ld(int idx) { return __builtin_bit_cast(float2, fotg_lds64[FOTG_LDS_HDR + idx]); }
+__device__ __forceinline__ void lds_d_st(int idx, float2 v) { fotg_lds64[FOTG_LDS_HDR + idx] = __builtin_bit_cast(unsigned long long, v); }
 #define FOTG_CBAR() asm volatile("" ::: "memory")
 
 // call with all threads of the block, then __syncthreads()
 __device__ __forceinline__ void sor_pipe_reset_progress()
 {
   int *progress = reinterpret_cast<int *>(fotg_lds64);
-  if (threadIdx.x < 16) progress[threadIdx.x] = threadIdx.x == 15 ? 0x7fffffff : -1;   // slot 15: always-ready dummy leader of wave 0
+  if (threadIdx.x < 32) progress[threadIdx.x] = threadIdx.x == 31 ? 0x7fffffff : -1;   // slot 31: always-ready dummy leader
 }
 
 // one sweep by the calling wave `wv` (0 <= wv < nsweeps)
@@ -466,7 +467,7 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
   const int r0 = act ? lane * K : a.RP;
   const float om_lane = act ? omega : 0.f;
   const int S = a.S, RP = a.RP, RPD = a.RPD;
-  const int lead = wv > 0 ? wv - 1 : 15;
+  const int lead = wv > 0 ? wv - 1 : 31;
   const unsigned lead_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long *)fotg_lds64 + 4u * (unsigned)lead;
 
   struct Stage { float4 c[K][2]; };
@@ -543,7 +544,7 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
       const int dst = (!TAIL || s < S) ? lrow : (S + 1) * RPD + r0;          // tail steps write the scratch row
 #pragma unroll
       for (int m = 0; m < K; ++m) lds_d_st(dst + m, res[m]);
-      if (TAIL || (u % CHK) == CHK - 1) prog_store(wv, (!TAIL || s < S) ? s : S - 1);   // after the data: LDS keeps a wave's order
+      if ((u % CHK) == CHK - 1 || (TAIL && s == S - 1)) prog_store(wv, (!TAIL || s < S) ? s : S - 1);   // after the data: LDS keeps a wave's order
     }
 #pragma unroll
     for (int m = 0; m < K; ++m) { prev[m] = res[m]; hl[m] = st.c[m][1].y; own[m] = od.nxt[m]; }
@@ -556,9 +557,8 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
       if ((u % CHK) == 0) { wait_need(s + 3 + CHK - 1, seen); seen = prog_load(lead); }
       fetch_nxt(od, lrow + rpd3);
     } else {
-      wait_need(s + 3 < S - 1 ? s + 3 : S - 1, seen);
+      if ((u % CHK) == 0) { wait_need(s + 3 + CHK - 1 < S - 1 ? s + 3 + CHK - 1 : S - 1, seen); seen = prog_load(lead); }
       fetch_nxt(od, (s + 3 < S ? s + 3 : S) * RPD + r0);
-      seen = prog_load(lead);
     }
     lrow += RPD;
   };
@@ -573,9 +573,143 @@ __device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float o
   }
 }
 
+// Banded two-lanes-per-row variant of the sweep pipeline.  A wave owns a BAND of <= 32 consecutive image rows of one
+// sweep; lane l handles row (l & 31) of the band and ONE component (l >> 5: du or dv), so the ~28 flops of a pixel
+// update are split over two lanes (the two right-hand sides B1, B2 are exchanged with one v_permlane32_swap) and a
+// step costs ~2/3 of the instructions of the one-lane-per-row form -- the loop is bound by single-wave instruction
+// issue, so that is time.  Rows beyond 32 go to further waves: wave (sweep n, band b) trails (n-1, b) and (n-1, b+1)
+// [old values] and (n, b-1) [new top value of its first row, read from LDS instead of DPP], again only the
+// dependencies of the sequential sweep, so the result stays bit-identical.
+template <int P, int U, bool NT>
+__device__ __forceinline__ void sor_band_wave(const VrArgs &a, int pair, float omega, int wv, int lane)
+{
+  int *progress = reinterpret_cast<int *>(fotg_lds64);
+  float *Df = reinterpret_cast<float *>(fotg_lds64 + FOTG_LDS_HDR);          // D as floats: cell c -> Df[2c], Df[2c+1]
+  auto prog_load = [&](int i) { const int v = __hip_atomic_load(&progress[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); FOTG_CBAR(); return v; };
+  auto prog_store = [&](int i, int v) { FOTG_CBAR(); __hip_atomic_store(&progress[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  const int NB = a.nbands, n = wv / NB, b = wv % NB;
+  const int rb = b * a.band_rows, nrows = (rb + a.band_rows <= a.h ? a.band_rows : a.h - rb);
+  const int rr = lane & 31, comp = lane >> 5;
+  const bool isv = comp != 0, first_row = rr == 0;
+  const bool act = rr < nrows;
+  const int r = act ? rb + rr : a.RP;                          // idle lanes park on the zero padding cells with omega = 0
+  const float om_lane = act ? omega : 0.f;
+  const int S = a.S, RP = a.RP, RPD = a.RPD;
+  auto slot = [&](int nn, int bb) { return nn * 5 + bb; };
+  const int my_slot = slot(n, b);
+  const int lead_sw = n > 0 ? slot(n - 1, b) : 31;                               // old values of my rows
+  const int lead_bot = (n > 0 && b + 1 < NB) ? slot(n - 1, b + 1) : 31;          // old value below my last row
+  const int lead_top = b > 0 ? slot(n, b - 1) : 31;                              // new value above my first row
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long *)fotg_lds64;
+  auto wait_need = [&](int lead, int need, int &seen) {
+    if (seen < need) {
+      int v;
+      asm volatile("L_fotg_bspin_%=:\n\t"
+                   "ds_read_b32 %0, %1\n\t"
+                   "s_waitcnt lgkmcnt(0)\n\t"
+                   "v_cmp_lt_i32 vcc, %0, %2\n\t"
+                   "s_cbranch_vccz L_fotg_bdone_%=\n\t"
+                   "s_sleep 1\n\t"
+                   "s_branch L_fotg_bspin_%=\n\t"
+                   "L_fotg_bdone_%=:"
+                   : "=&v"(v) : "v"(lds0 + 4u * (unsigned)lead), "v"(need) : "vcc", "memory");
+      seen = v;
+    }
+  };
+  struct Stage { float a_self, a12, bb, hr, vb, vt; };          // this lane's component of the system cell
+  Stage ring[P];
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  const unsigned c_row = (unsigned)RP * 32u;
+  const char *cptr = reinterpret_cast<const char *>(a.Cp(pair)) + (size_t)r * 32u;
+  const char *cend = cptr + (size_t)S * c_row;
+  auto load_c = [&](Stage &st, const char *ptr) {
+    const vf4 *cp = reinterpret_cast<const vf4 *>(ptr);
+    const vf4 x = NT ? __builtin_nontemporal_load(cp) : cp[0], y = NT ? __builtin_nontemporal_load(cp + 1) : cp[1];
+    st.a_self = isv ? x.z : x.x; st.a12 = x.y; st.bb = isv ? y.x : x.w; st.hr = y.y; st.vb = y.z; st.vt = y.w;
+  };
+  constexpr int CHK = 4;
+  const int rpd2 = 2 * RPD;
+  int lf = 2 * r + comp;                                         // float index of (diagonal s, my row, my component)
+  int tf = 2 * (b > 0 ? rb - 1 : RP) + comp;                     // ... of (diagonal s, row above the band) [band 0: a zero cell]
+#pragma unroll
+  for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }
+  int seen_sw = -1, seen_bot = -1, seen_top = -1;
+  {
+    const int w0 = 2 * CHK + 4 < S - 1 ? 2 * CHK + 4 : S - 1;
+    wait_need(lead_sw, w0, seen_sw); wait_need(lead_bot, w0, seen_bot); wait_need(lead_top, w0, seen_top);
+  }
+  // old values of the next diagonal at my row (= my own old value one step later) and the row below; top value of the
+  // band's first row; two slots each, refilled two steps ahead
+  float own = Df[lf];
+  float nxr[2], nxb[2], tpl[2];
+  nxr[0] = Df[lf + rpd2]; nxb[0] = Df[lf + rpd2 + 2]; tpl[0] = 0.f;          // diagonal 1 (step 0 has no top: diagonal -1)
+  nxr[1] = Df[lf + 2 * rpd2]; nxb[1] = Df[lf + 2 * rpd2 + 2]; tpl[1] = Df[tf];   // diagonal 2; top for step 1 = (diagonal 0, row above)
+  float prev = 0.f, hl = 0.f;
+  auto step = [&](auto tail_tag, int u, int s) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    Stage &st = ring[u % P];
+    const int q = u & 1;
+    const float om = (!TAIL || s < S) ? om_lane : 0.f;
+    // the DPP read must execute with ALL lanes enabled (a lane reads its neighbour: a neighbour masked off by EXEC reads
+    // as 0), so it is computed unconditionally and pinned before the per-lane select
+    float dppv = dpp_wave_shr1(prev);
+    asm volatile("" : "+v"(dppv));
+    const float top = first_row ? tpl[q] : dppv;
+    float sv = st.hr * nxr[q];
+    sv = sv + st.vt * top;
+    sv = sv + st.vb * nxb[q];
+    sv = sv + st.bb;
+    const float B = hl * prev + sv;
+    // the other component's right-hand side (lane ^ 32)
+    // v_permlane32_swap swaps lanes 32-63 of its first register with lanes 0-31 of its second.  Two DISTINCT
+    // registers are required (with one register the low half of the result is lost), hence the asm with two
+    // read-write operands: afterwards lo = {B[0:31], B[0:31]}, hi = {B[32:63], B[32:63]}.
+    float lo = B, hi = B;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+    const float Bo = isv ? lo : hi;
+    const float res = own + om * (st.a_self * B + st.a12 * Bo - own);
+    {
+      const int dst = (!TAIL || s < S) ? lf : 2 * ((S + 1) * RPD + r) + comp;   // tail steps write the scratch row
+      Df[dst] = res;
+      if ((u % CHK) == CHK - 1 || (TAIL && s == S - 1)) prog_store(my_slot, (!TAIL || s < S) ? s : S - 1);
+    }
+    prev = res; hl = st.hr; own = nxr[q];
+    load_c(st, cptr);
+    if (!TAIL || cptr < cend) cptr += c_row;
+    if (!TAIL) {
+      if ((u % CHK) == 0) {
+        wait_need(lead_sw, s + 3 + CHK - 1, seen_sw); wait_need(lead_bot, s + 3 + CHK - 1, seen_bot); wait_need(lead_top, s + 1 + CHK - 1, seen_top);
+        seen_sw = prog_load(lead_sw); seen_bot = prog_load(lead_bot); seen_top = prog_load(lead_top);
+      }
+      nxr[q] = Df[lf + 3 * rpd2]; nxb[q] = Df[lf + 3 * rpd2 + 2];             // diagonal s+3
+      tpl[q] = Df[tf + rpd2];                                                // (diagonal s+1, row above): top of step s+2
+    } else {
+      // same scheme with the diagonals clamped to the last one (the leader's final publish is S-1)
+      if ((u % CHK) == 0) {
+        const int lim = S - 1, n3 = s + 3 + CHK - 1 < lim ? s + 3 + CHK - 1 : lim, n1 = s + 1 + CHK - 1 < lim ? s + 1 + CHK - 1 : lim;
+        wait_need(lead_sw, n3, seen_sw); wait_need(lead_bot, n3, seen_bot); wait_need(lead_top, n1, seen_top);
+        seen_sw = prog_load(lead_sw); seen_bot = prog_load(lead_bot); seen_top = prog_load(lead_top);
+      }
+      const int d3 = s + 3 < S ? s + 3 : S, d1 = s + 1 < S ? s + 1 : S;
+      nxr[q] = Df[2 * (d3 * RPD + r) + comp]; nxb[q] = Df[2 * (d3 * RPD + r + 1) + comp];
+      tpl[q] = Df[2 * (d1 * RPD + (b > 0 ? rb - 1 : RP)) + comp];
+    }
+    lf += rpd2; tf += rpd2;
+  };
+  int t0 = 0;
+  for (; t0 + U + P + CHK + 3 <= S; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(std::false_type{}, u, t0 + u);
+  }
+  for (; t0 < S; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(std::true_type{}, u, t0 + u);
+  }
+}
+
 // stand-alone launch of one sor_coupled call: D global -> LDS, sweeps, LDS -> global
-template <int K, int P, int U>
-__global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
+template <int K, int P, int U, bool BANDED>
+__global__ __launch_bounds__(BANDED ? 1024 : 256) void vr_sor_pipe_kernel(VrArgs a, float omega)
 {
   const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float2 *Dg = a.Dp(pair);
@@ -597,7 +731,8 @@ __global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
   }
   sor_pipe_reset_progress();
   __syncthreads();
-  if (wv < a.nsweeps) sor_pipe_wave<K, P, U, false>(a, pair, omega, wv, lane);
+  if constexpr (BANDED) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, false>(a, pair, omega, wv, lane); }
+  else { if (wv < a.nsweeps) sor_pipe_wave<K, P, U, false>(a, pair, omega, wv, lane); }
   __syncthreads();
   {
     float4 *g4 = reinterpret_cast<float4 *>(Dg);
@@ -613,14 +748,14 @@ __global__ __launch_bounds__(256) void vr_sor_pipe_kernel(VrArgs a, float omega)
 //   repeat inner times { smoothness, data term + sub_laplacian + block inverse -> system C ; sor_coupled } ; flow = w + d.
 // (du,dv) never leave LDS; the smoothness weights live in an LDS plane; C goes through global memory (L2) to the
 // solver waves of the same workgroup.  Replaces 2*inner + 2 launches (and the LDS copy-in/out of D) per level.
-template <int NOC, int K, int P, int U>
+template <int NOC, int K, int P, int U, bool BANDED>
 __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
                                                              float half_gamma_over3, float omega, float *__restrict__ flow, long flow_stride)
 {
   const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int w = a.w, h = a.h, st = a.st, S = a.S, RPD = a.RPD;
   const int ncell = (S + 2) * RPD;
-  float *sm = reinterpret_cast<float *>(fotg_lds64 + 8 + ncell);            // smoothness plane [h][w]
+  float *sm = reinterpret_cast<float *>(fotg_lds64 + FOTG_LDS_HDR + ncell);            // smoothness plane [h][w]
   const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
   for (int k = threadIdx.x; k < ncell; k += blockDim.x) lds_d_st(k, make_float2(0.f, 0.f));     // image_erase(du), (dv) (:185-186)
   __syncthreads();
@@ -677,7 +812,8 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
     }
     sor_pipe_reset_progress();
     __syncthreads();                                             // also drains the C stores (vmcnt(0)) before the solver reads them
-    if (wv < a.nsweeps) sor_pipe_wave<K, P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane);
+    if constexpr (BANDED) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
+    else { if (wv < a.nsweeps) sor_pipe_wave<K, P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
     __syncthreads();
   }
   float *f = flow + (size_t)pair * flow_stride;                  // refine_variational.cpp:208-221

@@ -173,12 +173,14 @@ def test_end_to_end_parity(case, op_point, sor_mode, alley):
     assert np.array_equal(ofc.calc(dev(f0), dev(f1)).cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("path", ["1", "2"])
-def test_solver_fallback_paths(path, alley, monkeypatch):
+@pytest.mark.parametrize("path,bands", [("1", "0"), ("2", "0"), ("0", "1"), ("2", "1")])
+def test_solver_fallback_paths(path, bands, alley, monkeypatch):
     """the automatic dispatch picks the fused / sweep-pipelined LDS solvers at these sizes; force the single-wave
-    global-memory solver (1) and the unfused pipelined solver (2) and require the same bits"""
+    global-memory solver (path 1), the unfused pipelined solver (path 2) and the banded two-lanes-per-row solver waves
+    (bands 1, fused and unfused) and require the same bits"""
     F, OFClass, _, O = _mods()
     monkeypatch.setenv("FOTG_VR_PATH", path)
+    monkeypatch.setenv("FOTG_VR_BANDS", bands)
     for case, op_point in (("alley", 2), ("synth_rgb", 2), ("synth_odd", 3)):
         f0, f1, noc = frames(case, alley)
         h, w = f0.shape[:2]
