@@ -213,6 +213,18 @@ def main():
             # the whole path against the same roof: pairs/s x 16 654 080 B / 8 TB/s
             res["whole_path_hbm_frac"] = value / world * (2 * W * H * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS
             res["time_dominant_stage"] = max(st, key=st.get)
+            # the same batch handed over as 8-bit frames (fotg_calc_batch_u8) -- NOT the headline value:
+            # the reference's API takes float32 frames (src/run_dense.cpp:144-162)
+            U0, U1 = I0.to(torch.uint8), I1.to(torch.uint8)
+            for _ in range(2):
+                ofc.calc_batch_u8(U0, U1, None, out)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                ofc.calc_batch_u8(U0, U1, None, out)
+            torch.cuda.synchronize()
+            res["u8_frames"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
+                                "note": "same workload with uint8 input frames (exact conversion on load); informational"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(I0, I1)
         print(json.dumps(res))

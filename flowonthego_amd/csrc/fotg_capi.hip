@@ -277,20 +277,22 @@ int fotg_num_patches(const fotg_ctx *c, int l, int *nopw, int *noph)
 /* ------------------------------------------------------------------------------------------------ */
 }  // extern "C"
 // I0 and/or I1 may be given; both frames of a batch share the launches
-template <int NOC>
-static int pyramid_impl(fotg_ctx *c, int n, const float *I0, const float *I1, hipStream_t s, int stages = 3)
+template <int NOC, typename T = float>
+static int pyramid_impl(fotg_ctx *c, int n, const T *I0, const T *I1, hipStream_t s, int stages = 3)
 {
   const int lv = c->base_lv, ps = c->ps;
   const LevelGeom &g0 = c->geom[lv];
   const int strips = (c->Wp + 255) >> 8, tiles = strips * (c->Hp >> lv);
   const long fstride = (long)c->w_org * c->h_org * NOC;
-  const float *A = I0 ? I0 : I1, *B = (I0 && I1) ? I1 : nullptr;
+  const T *A = I0 ? I0 : I1, *B = (I0 && I1) ? I1 : nullptr;
   float *dA = c->im[I0 ? 0 : 1][lv], *dB = c->im[1][lv];
   const int nimg = B ? 2 * n : n;
-  const int fast = (c->padw == 0) && ((c->w_org * NOC) % 4 == 0) && (((uintptr_t)A & 15) == 0) && (!B || ((uintptr_t)B & 15) == 0) && ((fstride % 4) == 0);
+  // fast path: no horizontal padding, rows and frames aligned for the wide loads (16 B for f32, 4 B for u8)
+  const uintptr_t amask = sizeof(T) == 4 ? 15 : 3;
+  const int fast = (c->padw == 0) && ((c->w_org * NOC) % 4 == 0) && (((uintptr_t)A & amask) == 0) && (!B || ((uintptr_t)B & amask) == 0) && ((fstride % 4) == 0);
   dim3 grid((tiles + 3) / 4, nimg), block(256);
-#define BASE(LV) do { if (fast) pyr_base_kernel<NOC, LV, true><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps); \
-    else pyr_base_kernel<NOC, LV, false><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps); } while (0)
+#define BASE(LV) do { if (fast) pyr_base_kernel<T, NOC, LV, true><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps); \
+    else pyr_base_kernel<T, NOC, LV, false><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps); } while (0)
   if (stages & 1) {
     switch (lv) {
       case 0: BASE(0); break;
@@ -717,10 +719,12 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
 /* whole flow: OFClass::calc (src/oflow.cpp:211-368) with kroeger numerics (kroeger/oflow.cpp:184-337)   */
 /* ------------------------------------------------------------------------------------------------ */
 // the scale loop for pairs [0, n) of context (view) c on one stream
-static int calc_range(fotg_ctx *c, int n, const float *I0, const float *I1, const float *initflow, float *outflow, hipStream_t stream)
+}  // extern "C"
+template <typename T>
+static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float *initflow, float *outflow, hipStream_t stream)
 {
   int st;
-  if ((st = c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, stream) : pyramid_impl<3>(c, n, I0, I1, stream))) return st;
+  if ((st = c->noc == 1 ? pyramid_impl<1, T>(c, n, I0, I1, stream) : pyramid_impl<3, T>(c, n, I0, I1, stream))) return st;
   for (int l = c->p.sc_f; l >= c->p.sc_l; --l) {
     if ((st = fotg_grid_init(c, l, n, c->im[0][l], c->dx0[l], c->dy0[l], c->lev_stride[l], stream))) return st;
     if ((st = fotg_grid_set_target(c, l, c->im[1][l], c->lev_stride[l]))) return st;
@@ -735,6 +739,7 @@ static int calc_range(fotg_ctx *c, int n, const float *I0, const float *I1, cons
   return FOTG_OK;
 }
 
+extern "C" {
 // a copy of the context whose per-pair arenas start at pair `p0` (nothing is owned by the copy)
 static void make_view(const fotg_ctx *c, int p0, fotg_ctx *v)
 {
@@ -826,6 +831,15 @@ int fotg_calc_batch(fotg_ctx *c, int n, const float *I0, const float *I1, const 
   }
   HIPCHK(hipGraphLaunch(c->gexec, s));
   return FOTG_OK;
+}
+
+/* 8-bit frames (SURVEY 8f "next" row 2): same path, the pyramid base kernel converts on load (exact) and reads a
+ * quarter of the bytes.  Eager single-stream launch sequence. */
+int fotg_calc_batch_u8(fotg_ctx *c, int n, const unsigned char *I0, const unsigned char *I1, const float *initflow, float *outflow, void *stream)
+{
+  if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
+  if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  return calc_range<unsigned char>(c, n, I0, I1, initflow, outflow, (hipStream_t)stream);
 }
 
 int fotg_calc(fotg_ctx *c, const float *I0, const float *I1, const float *initflow, float *outflow_host)

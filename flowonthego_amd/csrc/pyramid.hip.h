@@ -14,9 +14,9 @@
 
 namespace fotg {
 
-template <int NOC, int LV, bool FAST>
+template <typename T, int NOC, int LV, bool FAST>
 __global__ __launch_bounds__(256) void pyr_base_kernel(
-    const float *__restrict__ frames0, const float *__restrict__ frames1, int n_per_src, long frame_stride,  // 2 x n frames, h_org x w_org x NOC
+    const T *__restrict__ frames0, const T *__restrict__ frames1, int n_per_src, long frame_stride,  // 2 x n frames, h_org x w_org x NOC
     int w_org, int h_org, int left, int top,               // padding offsets (floor(pad/2))
     int Wp, int Hp,                                        // padded frame size
     float *__restrict__ dst0, float *__restrict__ dst1, long dst_stride, int tw, int ps)  // level LV padded buffers
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
   if (tile >= strips * oh) return;
   const int strip = tile % strips, oy = tile / strips;
   const int which = blockIdx.y >= n_per_src, img = blockIdx.y - (which ? n_per_src : 0);   // I0 batch first, then I1 batch
-  const float *src = (which ? frames1 : frames0) + (size_t)img * frame_stride;
+  const T *src = (which ? frames1 : frames0) + (size_t)img * frame_stride;
   float *dst = which ? dst1 : dst0;
   const int x0 = strip * 256 + lane * 4;     // first of this lane's 4 source pixels (padded coords)
   const bool active = x0 < Wp;               // Wp is a multiple of 4 whenever LV >= 2
@@ -41,11 +41,20 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int sy = clampi(oy * R + r - top, h_org);
-      const float *row = src + (size_t)sy * w_org * NOC;
-      if constexpr (FAST) {
+      const T *row = src + (size_t)sy * w_org * NOC;
+      if constexpr (FAST && sizeof(T) == 1) {
+        // 8-bit frames ("next" row f2 of SURVEY 8f): 4 pixels x NOC bytes = NOC dwords per lane and row; u8 -> f32 is exact
+        const unsigned *p32 = reinterpret_cast<const unsigned *>(row + (size_t)x0 * NOC);
+#pragma unroll
+        for (int k = 0; k < NOC; ++k) {
+          const unsigned t = __builtin_nontemporal_load(p32 + k);
+          v[r][4 * k] = (float)(t & 0xffu); v[r][4 * k + 1] = (float)((t >> 8) & 0xffu);
+          v[r][4 * k + 2] = (float)((t >> 16) & 0xffu); v[r][4 * k + 3] = (float)(t >> 24);
+        }
+      } else if constexpr (FAST) {
         // streamed once, never re-read: nontemporal 16-B loads keep the frames out of L2/MALL
         typedef float vf4 __attribute__((ext_vector_type(4)));
-        const vf4 *p4 = reinterpret_cast<const vf4 *>(row + (size_t)x0 * NOC);
+        const vf4 *p4 = reinterpret_cast<const vf4 *>(reinterpret_cast<const float *>(row) + (size_t)x0 * NOC);
 #pragma unroll
         for (int k = 0; k < NOC; ++k) {
           const vf4 t = __builtin_nontemporal_load(p4 + k);
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
         for (int px = 0; px < 4; ++px) {
           const int sx = clampi(x0 + px - left, w_org);
 #pragma unroll
-          for (int c = 0; c < NOC; ++c) v[r][px * NOC + c] = row[(size_t)sx * NOC + c];
+          for (int c = 0; c < NOC; ++c) v[r][px * NOC + c] = (float)row[(size_t)sx * NOC + c];
         }
       }
     }

@@ -112,6 +112,20 @@ class OFClass:
         check(lib().fotg_calc_batch(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(outflow), _stream()))
         return outflow
 
+    def calc_batch_u8(self, I0, I1, initflow=None, outflow=None):
+        """n pairs of 8-bit frames (n, h, w[, channels]) uint8 on the device; same result as calc_batch on float frames"""
+        for t in (I0, I1):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+                raise FotgError("frames must be contiguous uint8 CUDA(HIP) tensors")
+        n = I0.shape[0]
+        exp = (n, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
+        if tuple(I0.shape) != exp or I1.shape != I0.shape:
+            raise FotgError("frame shape %s does not match the configured %s" % (tuple(I0.shape), exp))
+        if outflow is None:
+            outflow = self.new_outflow(n)
+        check(lib().fotg_calc_batch_u8(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(_dev_f32(outflow, "outflow")), _stream()))
+        return outflow
+
     def upsample_crop(self, flow, out=None):
         """src/run_dense.cpp:293-303: x 2^finest, bilinear upsample, crop the padding -> (n, h_org, w_org, 2)"""
         flow = _dev_f32(flow, "flow")

@@ -72,6 +72,11 @@ void fotg_destroy(fotg_ctx *ctx);
  * stream: hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
 int fotg_calc_batch(fotg_ctx *ctx, int n, const float *I0, const float *I1, const float *initflow,
                     float *outflow, void *stream);
+/* The same for 8-bit frames (n x h_org x w_org x noc uint8, device memory): what cv::imread delivers before the
+ * reference converts to float (src/run_dense.cpp:137-145).  The conversion is exact and happens on load in the pyramid
+ * kernel, which then reads a quarter of the bytes.  Results are bit-identical to fotg_calc_batch on the converted frames. */
+int fotg_calc_batch_u8(fotg_ctx *ctx, int n, const unsigned char *I0, const unsigned char *I1, const float *initflow,
+                       float *outflow, void *stream);
 /* Single pair, outflow in HOST memory, synchronous -- the exact shape of the reference call. */
 int fotg_calc(fotg_ctx *ctx, const float *I0, const float *I1, const float *initflow, float *outflow_host);
 

@@ -250,6 +250,23 @@ def test_4k_quality_preset(monkeypatch):
     assert np.array_equal(got, ref)
 
 
+def test_uint8_frames(alley):
+    """8-bit front end: fotg_calc_batch_u8 == fotg_calc_batch on the converted frames == oracle; gray with
+    the fast 4-byte loads, a size that needs the padded (slow) path, and interleaved RGB"""
+    F, OFClass, _, O = _mods()
+    for case in ("alley", "synth_odd", "alley_rgb"):
+        f0, f1, noc = frames(case, alley)
+        h, w = f0.shape[:2]
+        op = F.operating_point(2, w, noc)
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        u0 = torch.from_numpy(np.ascontiguousarray(f0.astype(np.uint8))).cuda()[None]
+        u1 = torch.from_numpy(np.ascontiguousarray(f1.astype(np.uint8))).cuda()[None]
+        got = ofc.calc_batch_u8(u0, u1)[0].cpu().numpy()
+        p = oracle_params(O, op)
+        assert np.array_equal(got, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
+        assert np.array_equal(got, ofc.calc(dev(f0), dev(f1)).cpu().numpy()), case
+
+
 def test_initflow_warm_start(alley):
     """initflow (kroeger/oflow.h:91, oflow.cpp:217-220; src/oflow.cpp:268-271): coarsest-scale patches start from 2 x the
     given flow, sampled nearest-neighbour like a coarser scale"""

@@ -22,9 +22,9 @@ int main()
     float ms; hipEventElapsedTime(&ms, a, b); ms /= 10;
     printf("%-40s %8.1f us  %7.2f TB/s\n", name, ms * 1e3, 2.0 * img * N * 4 / (ms * 1e-3) / 1e12);
   };
-  run("pyr_base<1,4> fast both", [&] { pyr_base_kernel<1, 4, true><<<dim3((tiles + 3) / 4, 2 * N), 256>>>(d0, d1, N, img, W, H, 0, 4, W, Hp, o0, o1, ls, tw, ps); });
-  run("pyr_base<1,4> slow both", [&] { pyr_base_kernel<1, 4, false><<<dim3((tiles + 3) / 4, 2 * N), 256>>>(d0, d1, N, img, W, H, 0, 4, W, Hp, o0, o1, ls, tw, ps); });
-  run("pyr_base<1,3> fast both", [&] { pyr_base_kernel<1, 3, true><<<dim3((8 * 136 + 3) / 4, 2 * N), 256>>>(d0, d1, N, img, W, H, 0, 4, W, Hp, o0, o1, ls, tw, ps); });
-  run("pyr_base<1,2> fast both", [&] { pyr_base_kernel<1, 2, true><<<dim3((8 * 272 + 3) / 4, 2 * N), 256>>>(d0, d1, N, img, W, H, 0, 4, W, Hp, o0, o1, ls, tw, ps); });
+  run("pyr_base<1,4> fast both", [&] { pyr_base_kernel<float, 1, 4, true><<<dim3((tiles + 3) / 4, 2 * N), 256>>>(d0, d1, N, img, W, H, 0, 4, W, Hp, o0, o1, ls, tw, ps); });
+  run("pyr_base<1,4> slow both", [&] { pyr_base_kernel<float, 1, 4, false><<<dim3((tiles + 3) / 4, 2 * N), 256>>>(d0, d1, N, img, W, H, 0, 4, W, Hp, o0, o1, ls, tw, ps); });
+  run("pyr_base<1,3> fast both", [&] { pyr_base_kernel<float, 1, 3, true><<<dim3((8 * 136 + 3) / 4, 2 * N), 256>>>(d0, d1, N, img, W, H, 0, 4, W, Hp, o0, o1, ls, tw, ps); });
+  run("pyr_base<1,2> fast both", [&] { pyr_base_kernel<float, 1, 2, true><<<dim3((8 * 272 + 3) / 4, 2 * N), 256>>>(d0, d1, N, img, W, H, 0, 4, W, Hp, o0, o1, ls, tw, ps); });
   return 0;
 }
