@@ -555,7 +555,8 @@ static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, h
 }
 
 template <int NOC, int K, int P, bool BANDED>
-static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s)
+static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s,
+                               const float *I0, const float *I1, long img_stride, int tw, int pad)
 {
   constexpr int U = (P >= 8) ? 32 : 8 * P;
   static int max_set = 0;
@@ -567,13 +568,14 @@ static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, floa
     }
     max_set = lds;
   }
-  vr_inner_fused_kernel<NOC, K, P, U, BANDED><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs);
+  vr_inner_fused_kernel<NOC, K, P, U, BANDED><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
   return true;
 }
 
 // whole fixed-point loop in one launch when (du,dv) + the smoothness plane fit in LDS and sweeps <= 4
 template <int NOC>
-static bool dispatch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s)
+static bool dispatch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s,
+                                 const float *I0, const float *I1, long img_stride, int tw, int pad)
 {
   const int lds = 128 + (a.S + 2) * a.RPD * (int)sizeof(float2) + a.w * a.h * (int)sizeof(float);
   // one workgroup does the per-pixel phases of its pair: only worth it for small levels (measured: 60x34 yes, 120x68 no)
@@ -581,10 +583,10 @@ static bool dispatch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, 
   VrArgs b = a;
   b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
   set_bands(b, sweeps, 8);
-  if (b.nbands > 0) return launch_inner_fused<NOC, 1, 8, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s);
+  if (b.nbands > 0) return launch_inner_fused<NOC, 1, 8, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
   switch (a.K) {
-    case 1: return launch_inner_fused<NOC, 1, 8, false>(b, n, inner, qa, hd, hg, omega, flow, fs, s);
-    case 2: return launch_inner_fused<NOC, 2, 4, false>(b, n, inner, qa, hd, hg, omega, flow, fs, s);
+    case 1: return launch_inner_fused<NOC, 1, 8, false>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
+    case 2: return launch_inner_fused<NOC, 2, 4, false>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
     default: return false;
   }
 }
@@ -631,6 +633,13 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   const float half_gamma_over3 = c->p.tv_gamma * 0.5f / 3.0f;
   const float half_delta_over3 = c->p.tv_delta * 0.5f / 3.0f;
   const int inner = c->p.tv_innerit * (l + 1);
+  // small levels: the whole level (set-up stages, fixed-point loop, final w + d) in one launch, one workgroup per pair
+  if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && vr_path_override() == 0 &&
+      dispatch_inner_fused<NOC>(a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s,
+                                I0, I1, img_stride, g.tw, c->ps)) {
+    LAUNCHCHK();
+    return FOTG_OK;
+  }
   HIPCHK(hipMemsetAsync(a.D, 0, (size_t)n * a.d_pair_stride * sizeof(float2), s));      // image_erase(du), image_erase(dv) (:185-186)
   vr_prep_kernel<NOC><<<grid, block, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
   LAUNCHCHK();
@@ -638,11 +647,6 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   LAUNCHCHK();
   vr_deriv2_kernel<NOC><<<grid, block, 0, s>>>(a);
   LAUNCHCHK();
-  if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && vr_path_override() == 0 &&
-      dispatch_inner_fused<NOC>(a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s)) {
-    LAUNCHCHK();
-    return FOTG_OK;
-  }
   for (int it = 0; it < inner; ++it) {
     vr_data_kernel<NOC><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(a, quarter_alpha, half_delta_over3, half_gamma_over3);
     LAUNCHCHK();

@@ -70,15 +70,13 @@ __device__ __forceinline__ float conv_v5(const float *__restrict__ col, int j, i
 #undef S
 }
 
+// per-pixel bodies of the three set-up stages (shared by the wide kernels and the fused per-pair kernel)
 template <int NOC>
-__global__ __launch_bounds__(256) void vr_prep_kernel(VrArgs a, const float *__restrict__ I0, const float *__restrict__ I1,
-                                                      long img_stride, int tw, int pad,
-                                                      const float *__restrict__ flow, long flow_stride)
+__device__ __forceinline__ void prep_pixel(const VrArgs &a, int pair, int i, int j, const float *__restrict__ I0, const float *__restrict__ I1,
+                                           long img_stride, int tw, int pad, const float *__restrict__ flow, long flow_stride)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.w * a.h) return;
-  const int pair = blockIdx.y, i = idx % a.w, j = idx / a.w, o = j * a.st + i;
-  const float *f = flow + (size_t)pair * flow_stride + 2 * (size_t)idx;
+  const int o = j * a.st + i;
+  const float *f = flow + (size_t)pair * flow_stride + 2 * (size_t)(j * a.w + i);
   const float wx = f[0], wy = f[1];
   a.single(pair, P_WX)[o] = wx;
   a.single(pair, P_WY)[o] = wy;
@@ -102,11 +100,9 @@ __global__ __launch_bounds__(256) void vr_prep_kernel(VrArgs a, const float *__r
 }
 
 template <int NOC>
-__global__ __launch_bounds__(256) void vr_deriv1_kernel(VrArgs a)
+__device__ __forceinline__ void deriv1_pixel(const VrArgs &a, int pair, int i, int j)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.w * a.h) return;
-  const int pair = blockIdx.y, i = idx % a.w, j = idx / a.w, o = j * a.st + i;
+  const int o = j * a.st + i;
 #pragma unroll
   for (int c = 0; c < NOC; ++c) {
     const float *avg = a.color(pair, C_AVG, c), *iz = a.color(pair, C_IZ, c);
@@ -118,11 +114,9 @@ __global__ __launch_bounds__(256) void vr_deriv1_kernel(VrArgs a)
 }
 
 template <int NOC>
-__global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
+__device__ __forceinline__ void deriv2_pixel(const VrArgs &a, int pair, int i, int j)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.w * a.h) return;
-  const int pair = blockIdx.y, i = idx % a.w, j = idx / a.w, o = j * a.st + i;
+  const int o = j * a.st + i;
 #pragma unroll
   for (int c = 0; c < NOC; ++c) {
     const float *ix = a.color(pair, C_IX, c), *iy = a.color(pair, C_IY, c);
@@ -130,6 +124,32 @@ __global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
     a.color(pair, C_IXY, c)[o] = conv_v5(ix + i, j, a.h, a.st);
     a.color(pair, C_IYY, c)[o] = conv_v5(iy + i, j, a.h, a.st);
   }
+}
+
+template <int NOC>
+__global__ __launch_bounds__(256) void vr_prep_kernel(VrArgs a, const float *__restrict__ I0, const float *__restrict__ I1,
+                                                      long img_stride, int tw, int pad,
+                                                      const float *__restrict__ flow, long flow_stride)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.w * a.h) return;
+  prep_pixel<NOC>(a, blockIdx.y, idx % a.w, idx / a.w, I0, I1, img_stride, tw, pad, flow, flow_stride);
+}
+
+template <int NOC>
+__global__ __launch_bounds__(256) void vr_deriv1_kernel(VrArgs a)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.w * a.h) return;
+  deriv1_pixel<NOC>(a, blockIdx.y, idx % a.w, idx / a.w);
+}
+
+template <int NOC>
+__global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.w * a.h) return;
+  deriv2_pixel<NOC>(a, blockIdx.y, idx % a.w, idx / a.w);
 }
 
 // smoothness weight from the 3x3 cross of (uu,vv): compute_smoothness first half (opticalflow_aux.c:126-139);
@@ -750,7 +770,8 @@ __global__ __launch_bounds__(BANDED ? 1024 : 256) void vr_sor_pipe_kernel(VrArgs
 // solver waves of the same workgroup.  Replaces 2*inner + 2 launches (and the LDS copy-in/out of D) per level.
 template <int NOC, int K, int P, int U, bool BANDED>
 __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
-                                                             float half_gamma_over3, float omega, float *__restrict__ flow, long flow_stride)
+                                                             float half_gamma_over3, float omega, float *__restrict__ flow, long flow_stride,
+                                                             const float *__restrict__ I0, const float *__restrict__ I1, long img_stride, int tw, int pad)
 {
   const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int w = a.w, h = a.h, st = a.st, S = a.S, RPD = a.RPD;
@@ -758,6 +779,12 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
   float *sm = reinterpret_cast<float *>(fotg_lds64 + FOTG_LDS_HDR + ncell);            // smoothness plane [h][w]
   const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
   for (int k = threadIdx.x; k < ncell; k += blockDim.x) lds_d_st(k, make_float2(0.f, 0.f));     // image_erase(du), (dv) (:185-186)
+  // set-up stages of the level (refine_variational.cpp:182-183): warp + mask + mean/difference, then the derivative planes
+  for (int px = threadIdx.x; px < w * h; px += blockDim.x) prep_pixel<NOC>(a, pair, px % w, px / w, I0, I1, img_stride, tw, pad, flow, flow_stride);
+  __syncthreads();
+  for (int px = threadIdx.x; px < w * h; px += blockDim.x) deriv1_pixel<NOC>(a, pair, px % w, px / w);
+  __syncthreads();
+  for (int px = threadIdx.x; px < w * h; px += blockDim.x) deriv2_pixel<NOC>(a, pair, px % w, px / w);
   __syncthreads();
   constexpr int B = 4;                                           // pixels per thread whose global loads are in flight together
   const int npx = w * h, nth = blockDim.x;
