@@ -116,13 +116,13 @@ def roofline(ofc, I0, I1, lib, stream_ptr, batch):
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             k = json.load(f)["kernels"]
-        key = [x for x in k if "pyr_base_kernel<1, 4, true>" in x]
+        key = [x for x in k if "pyr_base_kernel<float, 1, 4, true>" in x]
         if key and batch == 64:
             traffic = k[key[0]]["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass
     gbs = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<1,4,true> (frames -> pyramid level 4, both frames of the batch in one launch)",
+    return {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,1,4,true> (frames -> pyramid level 4, both frames of the batch in one launch)",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms}
 
