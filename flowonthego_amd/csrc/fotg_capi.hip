@@ -503,23 +503,29 @@ static void launch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStrea
   vr_sor_kernel<K, P, U><<<n, 64, 0, s>>>(a, sweeps, omega);
 }
 
-// Banded two-lanes-per-row solver waves (sor_band_wave).  Measured on MI355X (64 x 1080p): they lose to the
-// one-lane-per-row waves when the level fits one wave with K = 1 (the two interleaved (du,dv) chains of a lane give
-// the single in-order wave more independent work than one longer chain per lane) and win slightly when K >= 2
-// (68 rows: 3 bands of 23 rows instead of 2 rows per lane), so that is the default.  FOTG_VR_BANDS=0/1 forces (tests).
+// Solver-wave flavours of the LDS solvers (FOTG_VR_BANDS forces one; tests run them all against the oracle):
+//   0  sor_pipe_wave   one wave per sweep, K rows per lane, progress-counter handshake between sweeps
+//   1  sor_band_wave   bands of <= 32 rows, two lanes per row (u / v split), progress counters
+//   2  sor_rows_wave   bands of <= 64 rows, one lane per row, progress counters
+//   3  sor_sync_wave   bands of <= 64 rows, one lane per row, lock step by a workgroup barrier every 4 steps  [default]
+// Measured on MI355X (64 x 1080p, varref[6]/[5]/[4] ms): mode 0/2 0.121/0.145/0.323, mode 3 0.093/0.150/0.328 -- the
+// barrier-stepped waves start sweep n+1 only 8-12 diagonals behind sweep n (24 with the handshake), which wins on the
+// short diagonals of the coarse levels.
 static void set_bands(VrArgs &b, int sweeps, int max_waves)
 {
-  b.nbands = 0; b.band_rows = 0;
+  b.nbands = 0; b.band_rows = 0; b.band_mode = 0;
   const char *e = getenv("FOTG_VR_BANDS");
-  const int force = e ? atoi(e) : -1;
-  if (force == 0 || (force < 0 && b.h <= 64)) return;
-  const int nb = (b.h + 31) / 32;
-  if (nb > 5 || sweeps * nb > max_waves || sweeps > 4) return;
+  const int mode = e ? atoi(e) : 3;
+  if (mode < 1 || mode > 3) return;
+  const int rows = mode == 1 ? 32 : 64;
+  const int nb = (b.h + rows - 1) / rows;
+  if (nb > 5 || sweeps * nb > (mode >= 2 && max_waves > 8 ? 8 : max_waves) || sweeps > 4) return;
   b.nbands = nb;
   b.band_rows = (b.h + nb - 1) / nb;
+  b.band_mode = mode;
 }
 
-template <int K, int P, bool BANDED>
+template <int K, int P, int BANDED>
 static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s, const VrArgs &b, int threads)
 {
   constexpr int U = (P >= 8) ? 32 : 8 * P;
@@ -539,22 +545,25 @@ static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hip
 // sweep-pipelined LDS solver when it applies: <= 4 sweeps (one wave each), (du,dv) of the level fit in LDS
 static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
+  if (const char *e = getenv("FOTG_DEBUG_SWEEPS")) sweeps = atoi(e);                    // timing experiments only (wrong results)
   const int lds = 128 + (a.S + 2) * a.RPD * (int)sizeof(float2);
   if (sweeps < 1 || sweeps > 4 || lds > 150 * 1024 || a.S < 24) return false;
   VrArgs b = a;
   b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
   set_bands(b, sweeps, 16);
-  if (b.nbands > 0) return launch_sor_pipe<1, 8, true>(a, n, sweeps, omega, s, b, sweeps * b.nbands * 64);
+  if (b.band_mode == 1) return launch_sor_pipe<1, 8, 1>(a, n, sweeps, omega, s, b, sweeps * b.nbands * 64);
+  if (b.band_mode == 2) return launch_sor_pipe<1, 8, 2>(a, n, sweeps, omega, s, b, (sweeps * b.nbands < 4 ? 4 : sweeps * b.nbands) * 64);
+  if (b.band_mode == 3) return launch_sor_pipe<1, 8, 3>(a, n, sweeps, omega, s, b, (sweeps * b.nbands < 4 ? 4 : sweeps * b.nbands) * 64);
   switch (a.K) {
-    case 1: return launch_sor_pipe<1, 8, false>(a, n, sweeps, omega, s, b, 256);
-    case 2: return launch_sor_pipe<2, 8, false>(a, n, sweeps, omega, s, b, 256);
-    case 3: return launch_sor_pipe<3, 4, false>(a, n, sweeps, omega, s, b, 256);
-    case 4: return launch_sor_pipe<4, 4, false>(a, n, sweeps, omega, s, b, 256);
+    case 1: return launch_sor_pipe<1, 8, 0>(a, n, sweeps, omega, s, b, 256);
+    case 2: return launch_sor_pipe<2, 8, 0>(a, n, sweeps, omega, s, b, 256);
+    case 3: return launch_sor_pipe<3, 4, 0>(a, n, sweeps, omega, s, b, 256);
+    case 4: return launch_sor_pipe<4, 4, 0>(a, n, sweeps, omega, s, b, 256);
     default: return false;
   }
 }
 
-template <int NOC, int K, int P, bool BANDED>
+template <int NOC, int K, int P, int BANDED>
 static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s,
                                const float *I0, const float *I1, long img_stride, int tw, int pad)
 {
@@ -583,10 +592,12 @@ static bool dispatch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, 
   VrArgs b = a;
   b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
   set_bands(b, sweeps, 8);
-  if (b.nbands > 0) return launch_inner_fused<NOC, 1, 8, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
+  if (b.band_mode == 2) { b.nbands = 0; b.band_mode = 0; }      // the fused kernel has no mode 2: plain waves
+  if (b.band_mode == 3) return launch_inner_fused<NOC, 1, 8, 3>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
+  if (b.band_mode == 1) return launch_inner_fused<NOC, 1, 8, 1>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
   switch (a.K) {
-    case 1: return launch_inner_fused<NOC, 1, 8, false>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
-    case 2: return launch_inner_fused<NOC, 2, 4, false>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
+    case 1: return launch_inner_fused<NOC, 1, 8, 0>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
+    case 2: return launch_inner_fused<NOC, 2, 4, 0>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
     default: return false;
   }
 }

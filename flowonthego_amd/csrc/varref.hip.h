@@ -39,7 +39,7 @@ struct VrArgs {
   float2 *D;             // [pair][SC+1][RPD] float2
   long c_pair_stride;    // in float4
   long d_pair_stride;    // in float2
-  int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows;
+  int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows, band_mode;
   __host__ __device__ float4 *Cp(int pair) const { return C + (size_t)pair * c_pair_stride; }
   __host__ __device__ float2 *Dp(int pair) const { return D + (size_t)pair * d_pair_stride; }
   __host__ __device__ size_t cidx(int i, int j) const { return ((size_t)(i + j) * RP + j) * 2; }
@@ -461,6 +461,9 @@ extern __shared__ unsigned long long fotg_lds64[];
 #define FOTG_LDS_HDR 16     // u64 units: 32 int progress counters (slot 31 = the always-ready dummy leader)
 #ifndef FOTG_FUSED_NT
 #define FOTG_FUSED_NT false
+#ifndef FOTG_SYNC_M
+#define FOTG_SYNC_M 4          // solver steps per workgroup barrier of the barrier-stepped solver waves
+#endif
 #endif
 
 __device__ __forceinline__ float2 lds_d_ld(int idx) { return __builtin_bit_cast(float2, fotg_lds64[FOTG_LDS_HDR + idx]); }
@@ -727,9 +730,235 @@ __device__ __forceinline__ void sor_band_wave(const VrArgs &a, int pair, float o
   }
 }
 
+// Banded one-lane-per-row variant: like sor_pipe_wave with K = 1, but a wave owns only a band of <= 64 rows of its
+// sweep, so a level taller than 64 rows keeps one row per lane (2 bands of 34 rows at 1080p level 4) instead of two
+// rows per lane.  Dependencies across bands as in sor_band_wave: the first row's new top value comes from LDS
+// (written by band b-1 of the same sweep), the last row's old bottom value is band b+1's row of the previous sweep.
+template <int P, int U, bool NT>
+__device__ __forceinline__ void sor_rows_wave(const VrArgs &a, int pair, float omega, int wv, int lane)
+{
+  int *progress = reinterpret_cast<int *>(fotg_lds64);
+  auto prog_load = [&](int i) { const int v = __hip_atomic_load(&progress[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); FOTG_CBAR(); return v; };
+  auto prog_store = [&](int i, int v) { FOTG_CBAR(); __hip_atomic_store(&progress[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  const int NB = a.nbands, n = wv / NB, b = wv % NB;
+  const int rb = b * a.band_rows, nrows = (rb + a.band_rows <= a.h ? a.band_rows : a.h - rb);
+  const bool first_row = lane == 0;
+  const bool act = lane < nrows;
+  const int r = act ? rb + lane : a.RP;                         // idle lanes park on the zero padding cells with omega = 0
+  const float om_lane = act ? omega : 0.f;
+  const int S = a.S, RP = a.RP, RPD = a.RPD;
+  auto slot = [&](int nn, int bb) { return nn * 5 + bb; };
+  const int my_slot = slot(n, b);
+  const int lead_sw = n > 0 ? slot(n - 1, b) : 31;
+  const int lead_bot = (n > 0 && b + 1 < NB) ? slot(n - 1, b + 1) : 31;
+  const int lead_top = b > 0 ? slot(n, b - 1) : 31;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long *)fotg_lds64;
+  auto wait_need = [&](int lead, int need, int &seen) {
+    if (seen < need) {
+      int v;
+      asm volatile("L_fotg_rspin_%=:\n\t"
+                   "ds_read_b32 %0, %1\n\t"
+                   "s_waitcnt lgkmcnt(0)\n\t"
+                   "v_cmp_lt_i32 vcc, %0, %2\n\t"
+                   "s_cbranch_vccz L_fotg_rdone_%=\n\t"
+                   "s_sleep 1\n\t"
+                   "s_branch L_fotg_rspin_%=\n\t"
+                   "L_fotg_rdone_%=:"
+                   : "=&v"(v) : "v"(lds0 + 4u * (unsigned)lead), "v"(need) : "vcc", "memory");
+      seen = v;
+    }
+  };
+  struct Stage { float4 c0, c1; };
+  Stage ring[P];
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  const unsigned c_row = (unsigned)RP * 32u;
+  const char *cptr = reinterpret_cast<const char *>(a.Cp(pair)) + (size_t)r * 32u;
+  const char *cend = cptr + (size_t)S * c_row;
+  auto load_c = [&](Stage &st, const char *ptr) {
+    const vf4 *cp = reinterpret_cast<const vf4 *>(ptr);
+    const vf4 x = NT ? __builtin_nontemporal_load(cp) : cp[0], y = NT ? __builtin_nontemporal_load(cp + 1) : cp[1];
+    st.c0 = make_float4(x.x, x.y, x.z, x.w); st.c1 = make_float4(y.x, y.y, y.z, y.w);
+  };
+  constexpr int CHK = 4;
+  int lrow = r;                                                  // LDS cell of (diagonal s, my row)
+  int trow = b > 0 ? rb - 1 : RP;                                // ... of (diagonal s, row above the band) [band 0: a zero cell]
+#pragma unroll
+  for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }
+  int seen_sw = -1, seen_bot = -1, seen_top = -1;
+  {
+    const int w0 = 2 * CHK + 4 < S - 1 ? 2 * CHK + 4 : S - 1;
+    wait_need(lead_sw, w0, seen_sw); wait_need(lead_bot, w0, seen_bot); wait_need(lead_top, w0, seen_top);
+  }
+  float2 own = lds_d_ld(lrow);
+  float2 nxr[2], nxb[2], tpl[2];
+  nxr[0] = lds_d_ld(lrow + RPD); nxb[0] = lds_d_ld(lrow + RPD + 1); tpl[0] = make_float2(0.f, 0.f);
+  nxr[1] = lds_d_ld(lrow + 2 * RPD); nxb[1] = lds_d_ld(lrow + 2 * RPD + 1); tpl[1] = lds_d_ld(trow);
+  float2 prev = make_float2(0.f, 0.f);
+  float hl = 0.f;
+  const int rpd3 = 3 * RPD;
+  auto step = [&](auto tail_tag, int u, int s) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    Stage &st = ring[u % P];
+    const int q = u & 1;
+    const float om = (!TAIL || s < S) ? om_lane : 0.f;
+    // DPP reads must run with all lanes enabled: compute, pin, then select
+    float dx = dpp_wave_shr1(prev.x), dy = dpp_wave_shr1(prev.y);
+    asm volatile("" : "+v"(dx), "+v"(dy));
+    const float2 top = first_row ? tpl[q] : make_float2(dx, dy);
+    const float2 res = sor_update(own, st.c0, st.c1, hl, prev, top, nxr[q], nxb[q], om);
+    {
+      const int dst = (!TAIL || s < S) ? lrow : (S + 1) * RPD + r;
+      lds_d_st(dst, res);
+      if ((u % CHK) == CHK - 1 || (TAIL && s == S - 1)) prog_store(my_slot, (!TAIL || s < S) ? s : S - 1);
+    }
+    prev = res; hl = st.c1.y; own = nxr[q];
+    load_c(st, cptr);
+    if (!TAIL || cptr < cend) cptr += c_row;
+    if (!TAIL) {
+      if ((u % CHK) == 0) {
+        wait_need(lead_sw, s + 3 + CHK - 1, seen_sw); wait_need(lead_bot, s + 3 + CHK - 1, seen_bot); wait_need(lead_top, s + 1 + CHK - 1, seen_top);
+        seen_sw = prog_load(lead_sw); seen_bot = prog_load(lead_bot); seen_top = prog_load(lead_top);
+      }
+      nxr[q] = lds_d_ld(lrow + rpd3); nxb[q] = lds_d_ld(lrow + rpd3 + 1);    // diagonal s+3
+      tpl[q] = lds_d_ld(trow + RPD);                                         // (diagonal s+1, row above): top of step s+2
+    } else {
+      if ((u % CHK) == 0) {
+        const int lim = S - 1, n3 = s + 3 + CHK - 1 < lim ? s + 3 + CHK - 1 : lim, n1 = s + 1 + CHK - 1 < lim ? s + 1 + CHK - 1 : lim;
+        wait_need(lead_sw, n3, seen_sw); wait_need(lead_bot, n3, seen_bot); wait_need(lead_top, n1, seen_top);
+        seen_sw = prog_load(lead_sw); seen_bot = prog_load(lead_bot); seen_top = prog_load(lead_top);
+      }
+      const int d3 = s + 3 < S ? s + 3 : S, d1 = s + 1 < S ? s + 1 : S;
+      nxr[q] = lds_d_ld(d3 * RPD + r); nxb[q] = lds_d_ld(d3 * RPD + r + 1);
+      tpl[q] = lds_d_ld(d1 * RPD + (b > 0 ? rb - 1 : RP));
+    }
+    lrow += RPD; trow += RPD;
+  };
+  int t0 = 0;
+  for (; t0 + U + P + CHK + 3 <= S; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(std::false_type{}, u, t0 + u);
+  }
+  for (; t0 < S; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(std::true_type{}, u, t0 + u);
+  }
+}
+
+// Barrier-stepped solver waves: every wave of the workgroup executes one s_barrier per M solver steps, so the sweep /
+// band stagger is a fixed number of steps instead of a progress-counter handshake:
+//   wave (sweep n, band b) relaxes diagonal s at global step t = s + n*DS + b*DB.
+// What a wave stores during step t' is only guaranteed visible to loads issued behind the first barrier after t', i.e.
+// to loads of step t >= M*floor(t/M) > t'.  The loads of step t fetch, for step t+1,
+//   the top of a band's first row (s, rb-1), stored by band b-1 at t - DB                      -> DB >= M
+//   right / bottom (s+2, .),         stored by sweep n-1 [band b+1] at t + 2 - DS [+ DB]       -> DS >= M + 2 [+ DB]
+// (worst case t = M*I + M - 1), rounded up to multiples of M so that all waves hit the barrier on the same local step.
+// Nobody overwrites a value a slower wave still needs: the reader's load and the overwrite are always separated by at
+// least DB + 2 >= M steps, hence by a barrier.  The barrier sits a third into its step (after the neighbour products)
+// so the latency of the previous step's LDS store and of the loads issued behind the barrier is covered by arithmetic.
+// Waves that do not solve (copy helpers, the other waves of the fused kernel) only count barriers.
+template <int P, int U, bool NT, int M>
+__device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float omega, int wv, int lane)
+{
+  constexpr int UT = P;                                          // unroll of the tail loop
+  static_assert(U % M == 0 && UT % M == 0 && U % P == 0, "barrier phase must be a compile-time property of the unrolled step");
+  const int NB = a.nbands > 0 ? a.nbands : 1;
+  constexpr int DB = M, DS1 = ((M + 2 + M - 1) / M) * M, DSB = ((2 * M + 2 + M - 1) / M) * M;
+  const int DS = NB > 1 ? DSB : DS1;
+  const int S = a.S, RP = a.RP, RPD = a.RPD;
+  int E = 0;                                                     // steps every solver wave executes (the last ones are no-ops)
+  while (E + U + P <= S) E += U;
+  while (E < S) E += UT;
+  const int omax = a.nsweeps > 0 ? (a.nsweeps - 1) * DS + (NB - 1) * DB : 0;
+  if (wv >= a.nsweeps * NB) {
+    for (int t = 0; t < (E + omax) / M; ++t) asm volatile("s_barrier" ::: "memory");
+    return;
+  }
+  const int n = wv / NB, b = wv % NB, off = n * DS + b * DB;
+  const int rb = b * a.band_rows, nrows = NB > 1 ? (rb + a.band_rows <= a.h ? a.band_rows : a.h - rb) : a.h;
+  const bool first_row = lane == 0;
+  const bool act = lane < nrows;
+  const int r = act ? rb + lane : RP;                            // idle lanes park on the zero padding cells with omega = 0
+  const float om_lane = act ? omega : 0.f;
+  struct Stage { float4 c0, c1; };
+  Stage ring[P];
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  const unsigned c_row = (unsigned)RP * 32u;
+  const char *cptr = reinterpret_cast<const char *>(a.Cp(pair)) + (size_t)r * 32u;
+  const char *cend = cptr + (size_t)S * c_row;
+  auto load_c = [&](Stage &st, const char *ptr) {
+    const vf4 *cp = reinterpret_cast<const vf4 *>(ptr);
+    const vf4 x = NT ? __builtin_nontemporal_load(cp) : cp[0], y = NT ? __builtin_nontemporal_load(cp + 1) : cp[1];
+    st.c0 = make_float4(x.x, x.y, x.z, x.w); st.c1 = make_float4(y.x, y.y, y.z, y.w);
+  };
+#pragma unroll
+  for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }
+  for (int t = 0; t < off / M; ++t) asm volatile("s_barrier" ::: "memory");
+  int lrow = r;                                                  // LDS cell (diagonal s, my row)
+  int trow = b > 0 ? rb - 1 : RP;                                // LDS cell (diagonal s, row above the band) [band 0: a zero cell]
+  float2 own = lds_d_ld(lrow), nxr = lds_d_ld(lrow + RPD), nxb = lds_d_ld(lrow + RPD + 1);
+  float2 tpl = make_float2(0.f, 0.f), prev = make_float2(0.f, 0.f);
+  float hl = 0.f;
+  const int rpd2 = 2 * RPD;
+  auto step = [&](auto tail_tag, int u, int s) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    Stage &st = ring[u % P];
+    const float om = (!TAIL || s < S) ? om_lane : 0.f;
+    // DPP reads must run with all lanes enabled: compute, pin, then select
+    float dx = dpp_wave_shr1(prev.x), dy = dpp_wave_shr1(prev.y);
+    asm volatile("" : "+v"(dx), "+v"(dy));
+    const float2 top = first_row ? tpl : make_float2(dx, dy);
+    // sor_update()'s expression order
+    const float a11 = st.c0.x, a12 = st.c0.y, a22 = st.c0.z, b1 = st.c0.w, b2 = st.c1.x, hr = st.c1.y, vb = st.c1.z, vt = st.c1.w;
+    float s1 = hr * nxr.x, s2 = hr * nxr.y;
+    s1 = s1 + vt * top.x;  s2 = s2 + vt * top.y;
+    s1 = s1 + vb * nxb.x;  s2 = s2 + vb * nxb.y;
+#ifndef FOTG_X_NOBAR
+    if (u % M == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(s1), "+v"(s2) :: "memory");   // tied to (s1,s2): placed here
+#endif
+    float2 nr, nb, tp;
+#ifdef FOTG_X_NOLDR
+    nr = nxr; nb = nxb; tp = tpl;
+    if (false) {
+#else
+    if (!TAIL) {
+#endif
+      nr = lds_d_ld(lrow + rpd2); nb = lds_d_ld(lrow + rpd2 + 1);  // diagonal s+2: right / bottom of step s+1
+      tp = lds_d_ld(trow);                                         // (diagonal s, row above the band): top of step s+1
+    } else {
+      const int d2 = s + 2 < S + 1 ? s + 2 : S + 1, d0 = s < S ? s : S;
+      nr = lds_d_ld(d2 * RPD + r); nb = lds_d_ld(d2 * RPD + r + 1);
+      tp = lds_d_ld(d0 * RPD + (b > 0 ? rb - 1 : RP));
+    }
+    s1 = s1 + b1;          s2 = s2 + b2;
+    const float B1 = hl * prev.x + s1, B2 = hl * prev.y + s2;
+    float2 res;
+    res.x = own.x + om * (a11 * B1 + a12 * B2 - own.x);
+    res.y = own.y + om * (a12 * B1 + a22 * B2 - own.y);
+#ifndef FOTG_X_NOSTORE
+    lds_d_st((!TAIL || s < S) ? lrow : (S + 1) * RPD + r, res);
+#endif
+    prev = res; hl = hr; own = nxr; nxr = nr; nxb = nb; tpl = tp;
+#ifndef FOTG_X_NOC
+    load_c(st, cptr);
+#endif
+    if (!TAIL || cptr < cend) cptr += c_row;
+    lrow += RPD; trow += RPD;
+  };
+  int t0 = 0;
+  for (; t0 + U + P <= S; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(std::false_type{}, u, t0 + u);
+  }
+  for (; t0 < S; t0 += UT) {
+#pragma unroll
+    for (int u = 0; u < UT; ++u) step(std::true_type{}, u, t0 + u);
+  }
+  for (int t = off / M; t < omax / M; ++t) asm volatile("s_barrier" ::: "memory");
+}
+
 // stand-alone launch of one sor_coupled call: D global -> LDS, sweeps, LDS -> global
-template <int K, int P, int U, bool BANDED>
-__global__ __launch_bounds__(BANDED ? 1024 : 256) void vr_sor_pipe_kernel(VrArgs a, float omega)
+template <int K, int P, int U, int BANDED>
+__global__ __launch_bounds__(BANDED == 1 ? 1024 : BANDED >= 2 ? 512 : 256) void vr_sor_pipe_kernel(VrArgs a, float omega)
 {
   const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float2 *Dg = a.Dp(pair);
@@ -751,7 +980,9 @@ __global__ __launch_bounds__(BANDED ? 1024 : 256) void vr_sor_pipe_kernel(VrArgs
   }
   sor_pipe_reset_progress();
   __syncthreads();
-  if constexpr (BANDED) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, false>(a, pair, omega, wv, lane); }
+  if constexpr (BANDED == 1) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, false>(a, pair, omega, wv, lane); }
+  else if constexpr (BANDED == 2) { if (wv < a.nsweeps * a.nbands) sor_rows_wave<P, U, false>(a, pair, omega, wv, lane); }
+  else if constexpr (BANDED == 3) sor_sync_wave<P, U, false, FOTG_SYNC_M>(a, pair, omega, wv, lane);
   else { if (wv < a.nsweeps) sor_pipe_wave<K, P, U, false>(a, pair, omega, wv, lane); }
   __syncthreads();
   {
@@ -768,7 +999,7 @@ __global__ __launch_bounds__(BANDED ? 1024 : 256) void vr_sor_pipe_kernel(VrArgs
 //   repeat inner times { smoothness, data term + sub_laplacian + block inverse -> system C ; sor_coupled } ; flow = w + d.
 // (du,dv) never leave LDS; the smoothness weights live in an LDS plane; C goes through global memory (L2) to the
 // solver waves of the same workgroup.  Replaces 2*inner + 2 launches (and the LDS copy-in/out of D) per level.
-template <int NOC, int K, int P, int U, bool BANDED>
+template <int NOC, int K, int P, int U, int BANDED>
 __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
                                                              float half_gamma_over3, float omega, float *__restrict__ flow, long flow_stride,
                                                              const float *__restrict__ I0, const float *__restrict__ I1, long img_stride, int tw, int pad)
@@ -839,7 +1070,8 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
     }
     sor_pipe_reset_progress();
     __syncthreads();                                             // also drains the C stores (vmcnt(0)) before the solver reads them
-    if constexpr (BANDED) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
+    if constexpr (BANDED == 3) sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M>(a, pair, omega, wv, lane);
+    else if constexpr (BANDED) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
     else { if (wv < a.nsweeps) sor_pipe_wave<K, P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
     __syncthreads();
   }

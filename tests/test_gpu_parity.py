@@ -173,11 +173,11 @@ def test_end_to_end_parity(case, op_point, sor_mode, alley):
     assert np.array_equal(ofc.calc(dev(f0), dev(f1)).cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("path,bands", [("1", "0"), ("2", "0"), ("0", "1"), ("2", "1")])
+@pytest.mark.parametrize("path,bands", [("1", "0"), ("0", "0"), ("2", "0"), ("0", "1"), ("2", "1"), ("2", "2"), ("2", "3")])
 def test_solver_fallback_paths(path, bands, alley, monkeypatch):
     """the automatic dispatch picks the fused / sweep-pipelined LDS solvers at these sizes; force the single-wave
-    global-memory solver (path 1), the unfused pipelined solver (path 2) and the banded two-lanes-per-row solver waves
-    (bands 1, fused and unfused) and require the same bits"""
+    global-memory solver (path 1), the unfused LDS solver (path 2) and every solver-wave flavour (bands 0: progress
+    counters, 1: two lanes per row, 2: row bands with counters, 3: barrier-stepped = the default) and require the same bits"""
     F, OFClass, _, O = _mods()
     monkeypatch.setenv("FOTG_VR_PATH", path)
     monkeypatch.setenv("FOTG_VR_BANDS", bands)
