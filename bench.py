@@ -225,6 +225,18 @@ def main():
             torch.cuda.synchronize()
             res["u8_frames"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
                                 "note": "same workload with uint8 input frames (exact conversion on load); informational"}
+            # video mode (fotg_calc_sequence): batch+1 consecutive frames -> batch flows, every pyramid built once
+            seq = torch.cat([I0, I1[-1:]]).contiguous()
+            for _ in range(2):
+                ofc.calc_sequence(seq, None, out)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                ofc.calc_sequence(seq, None, out)
+            torch.cuda.synchronize()
+            res["sequence_mode"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
+                                    "note": "%d consecutive f32 frames -> %d flows, one pyramid per frame; informational" % (a.batch + 1, a.batch)}
+            del seq
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(I0, I1)
         print(json.dumps(res))

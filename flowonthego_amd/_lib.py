@@ -28,6 +28,8 @@ SYMBOLS = [
     ("fotg_destroy", None, [vp]),
     ("fotg_calc_batch", C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp]),
     ("fotg_calc_batch_u8", C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp]),
+    ("fotg_calc_sequence", C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+    ("fotg_calc_sequence_u8", C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     ("fotg_calc", C.c_int, [vp, vp, vp, vp, vp]),
     ("fotg_upsample_crop", C.c_int, [vp, C.c_int, vp, vp, vp]),
     ("fotg_level_size", C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

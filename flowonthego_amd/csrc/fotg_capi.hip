@@ -183,11 +183,12 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
     c->lev_stride[l] = (long)g.tw * g.th * c->noc;
     const size_t bytes = B * c->lev_stride[l] * sizeof(float);
 #define ALLOC(ptr, nbytes) do { if (hipMalloc((void **)&(ptr), (nbytes)) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; } } while (0)
-    ALLOC(c->im[0][l], bytes);
+    const size_t bytes1 = (B + 1) * c->lev_stride[l] * sizeof(float);       // sequence mode: max_batch pairs = max_batch + 1 frames
+    ALLOC(c->im[0][l], bytes1);
     ALLOC(c->im[1][l], bytes);
     if (l >= p->sc_l) {
-      ALLOC(c->dx0[l], bytes);
-      ALLOC(c->dy0[l], bytes);
+      ALLOC(c->dx0[l], bytes1);
+      ALLOC(c->dy0[l], bytes1);
       ALLOC(c->flow[l], B * g.w * g.h * 2 * sizeof(float));
       ALLOC(c->p_iter[l], B * g.nop * 2 * sizeof(float));
       ALLOC(c->pweight[l], B * g.nop * (size_t)(p->ps * p->ps * c->noc) * sizeof(float));
@@ -563,37 +564,49 @@ static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, h
   }
 }
 
-template <int NOC, int K, int P, int BANDED>
+static int fused_lds_bytes(const VrArgs &b, bool with_c)
+{
+  return 128 + (b.S + 2) * b.RPD * (int)sizeof(float2) + ((b.w * b.h + 3) / 4) * 16 + (with_c ? (b.SC * b.RP + 1) * 32 : 0);
+}
+
+template <int NOC, int K, int P, int BANDED, bool CL = false>
 static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s,
                                const float *I0, const float *I1, long img_stride, int tw, int pad)
 {
   constexpr int U = (P >= 8) ? 32 : 8 * P;
   static int max_set = 0;
-  const int lds = 128 + (b.S + 2) * b.RPD * (int)sizeof(float2) + b.w * b.h * (int)sizeof(float);
+  const int lds = fused_lds_bytes(b, CL);
   if (lds > max_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, K, P, U, BANDED>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
     max_set = lds;
   }
-  vr_inner_fused_kernel<NOC, K, P, U, BANDED><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
+  vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
   return true;
 }
 
 // whole fixed-point loop in one launch when (du,dv) + the smoothness plane fit in LDS and sweeps <= 4
 template <int NOC>
 static bool dispatch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s,
-                                 const float *I0, const float *I1, long img_stride, int tw, int pad)
+                                 const float *I0, const float *I1, long img_stride, int tw, int pad, int taps)
 {
-  const int lds = 128 + (a.S + 2) * a.RPD * (int)sizeof(float2) + a.w * a.h * (int)sizeof(float);
+  const int lds = fused_lds_bytes(a, false);
   // one workgroup does the per-pixel phases of its pair: only worth it for small levels (measured: 60x34 yes, 120x68 no)
   if (sweeps < 1 || sweeps > 4 || inner < 1 || lds > 156 * 1024 || a.S < 24 || a.w * a.h > 3000) return false;
   VrArgs b = a;
+  b.taps = taps;
   b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
   set_bands(b, sweeps, 8);
   if (b.band_mode == 2) { b.nbands = 0; b.band_mode = 0; }      // the fused kernel has no mode 2: plain waves
-  if (b.band_mode == 3) return launch_inner_fused<NOC, 1, 8, 3>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
+  if (b.band_mode == 3) {
+    // system cells in LDS as well when they fit (FOTG_VR_CLDS=0: keep them in global memory; tests)
+    const char *e = getenv("FOTG_VR_CLDS");
+    if ((!e || atoi(e)) && fused_lds_bytes(a, true) <= 160 * 1024 &&
+        launch_inner_fused<NOC, 1, 8, 3, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
+    return launch_inner_fused<NOC, 1, 8, 3>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
+  }
   if (b.band_mode == 1) return launch_inner_fused<NOC, 1, 8, 1>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
   switch (a.K) {
     case 1: return launch_inner_fused<NOC, 1, 8, 0>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
@@ -647,7 +660,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   // small levels: the whole level (set-up stages, fixed-point loop, final w + d) in one launch, one workgroup per pair
   if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && vr_path_override() == 0 &&
       dispatch_inner_fused<NOC>(a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s,
-                                I0, I1, img_stride, g.tw, c->ps)) {
+                                I0, I1, img_stride, g.tw, c->ps, c->taps ? 1 : 0)) {
     LAUNCHCHK();
     return FOTG_OK;
   }
@@ -735,21 +748,26 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
 /* ------------------------------------------------------------------------------------------------ */
 // the scale loop for pairs [0, n) of context (view) c on one stream
 }  // extern "C"
+// I1 == nullptr: sequence mode -- I0 holds n+1 consecutive frames, pair k is (frame k, frame k+1); every frame's pyramid
+// is built once (with gradients) and serves as the target of pair k-1 and the template source of pair k.
 template <typename T>
 static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float *initflow, float *outflow, hipStream_t stream)
 {
   int st;
-  if ((st = c->noc == 1 ? pyramid_impl<1, T>(c, n, I0, I1, stream) : pyramid_impl<3, T>(c, n, I0, I1, stream))) return st;
+  const bool seq = I1 == nullptr;
+  const int nimg = seq ? n + 1 : n;
+  if ((st = c->noc == 1 ? pyramid_impl<1, T>(c, nimg, I0, I1, stream) : pyramid_impl<3, T>(c, nimg, I0, I1, stream))) return st;
   for (int l = c->p.sc_f; l >= c->p.sc_l; --l) {
+    const float *tgt = seq ? c->im[0][l] + c->lev_stride[l] : c->im[1][l];
     if ((st = fotg_grid_init(c, l, n, c->im[0][l], c->dx0[l], c->dy0[l], c->lev_stride[l], stream))) return st;
-    if ((st = fotg_grid_set_target(c, l, c->im[1][l], c->lev_stride[l]))) return st;
+    if ((st = fotg_grid_set_target(c, l, tgt, c->lev_stride[l]))) return st;
     if (l < c->p.sc_f) { if ((st = fotg_grid_init_from_coarser(c, l, n, c->flow[l + 1], stream))) return st; }
     else if (initflow) { if ((st = fotg_grid_init_from_coarser(c, l, n, initflow, stream))) return st; }
     if ((st = fotg_grid_optimize(c, l, n, stream))) return st;
     float *out = (l == c->p.sc_l) ? outflow : c->flow[l];
     if ((st = fotg_grid_aggregate(c, l, n, out, stream))) return st;
     if (c->p.usetvref)
-      if ((st = fotg_varref(c, l, n, c->im[0][l], c->im[1][l], c->lev_stride[l], out, stream))) return st;
+      if ((st = fotg_varref(c, l, n, c->im[0][l], tgt, c->lev_stride[l], out, stream))) return st;
   }
   return FOTG_OK;
 }
@@ -855,6 +873,20 @@ int fotg_calc_batch_u8(fotg_ctx *c, int n, const unsigned char *I0, const unsign
   if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
   return calc_range<unsigned char>(c, n, I0, I1, initflow, outflow, (hipStream_t)stream);
+}
+
+/* sequence mode (SURVEY 8f "next" row 2): n_frames consecutive frames -> n_frames - 1 flows (frame k -> k+1) */
+int fotg_calc_sequence(fotg_ctx *c, int n_frames, const float *frames, const float *initflow, float *outflow, void *stream)
+{
+  if (!c || !frames || !outflow) return FOTG_ERR_ARG;
+  if (n_frames < 2 || n_frames - 1 > c->max_batch) return FOTG_ERR_BATCH;
+  return calc_range<float>(c, n_frames - 1, frames, nullptr, initflow, outflow, (hipStream_t)stream);
+}
+int fotg_calc_sequence_u8(fotg_ctx *c, int n_frames, const unsigned char *frames, const float *initflow, float *outflow, void *stream)
+{
+  if (!c || !frames || !outflow) return FOTG_ERR_ARG;
+  if (n_frames < 2 || n_frames - 1 > c->max_batch) return FOTG_ERR_BATCH;
+  return calc_range<unsigned char>(c, n_frames - 1, frames, nullptr, initflow, outflow, (hipStream_t)stream);
 }
 
 int fotg_calc(fotg_ctx *c, const float *I0, const float *I1, const float *initflow, float *outflow_host)

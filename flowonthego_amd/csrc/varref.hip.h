@@ -39,7 +39,7 @@ struct VrArgs {
   float2 *D;             // [pair][SC+1][RPD] float2
   long c_pair_stride;    // in float4
   long d_pair_stride;    // in float2
-  int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows, band_mode;
+  int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows, band_mode, taps;
   __host__ __device__ float4 *Cp(int pair) const { return C + (size_t)pair * c_pair_stride; }
   __host__ __device__ float2 *Dp(int pair) const { return D + (size_t)pair * d_pair_stride; }
   __host__ __device__ size_t cidx(int i, int j) const { return ((size_t)(i + j) * RP + j) * 2; }
@@ -198,8 +198,8 @@ __device__ __forceinline__ PixIn<NOC> data_load(const VrArgs &a, int pair, int i
 // compute_data (:310-438) + sub_laplacian (:172-199) + the 2x2 block inverse of sor_coupled's first sweep
 // (solver.c:115-120) for pixel (i,j), given the four smoothness pair sums and (du,dv); writes the skewed system cell.
 template <int NOC>
-__device__ __forceinline__ void data_term_compute(const VrArgs &a, int pair, int i, int j, const PixIn<NOC> &p, float hr, float hl,
-                                                  float vb, float vt, float u, float v, float half_delta_over3, float half_gamma_over3)
+__device__ __forceinline__ void data_term_cell(const VrArgs &a, int i, int j, const PixIn<NOC> &p, float hr, float hl, float vb, float vt,
+                                               float u, float v, float half_delta_over3, float half_gamma_over3, float4 &c0, float4 &c1)
 {
   const int w = a.w, h = a.h;
   // compute_data (:310-438)
@@ -283,9 +283,19 @@ __device__ __forceinline__ void data_term_compute(const VrArgs &a, int pair, int
   if (j < h - 1) dps = dps + vb;
   const float M11 = A22 + dps, M22 = A11 + dps;
   const float det = M11 * M22 - A12 * A12;
+  c0 = make_float4(M11 / det, A12 / -det, M22 / det, B1);
+  c1 = make_float4(B2, hr, vb, vt);
+}
+
+template <int NOC>
+__device__ __forceinline__ void data_term_compute(const VrArgs &a, int pair, int i, int j, const PixIn<NOC> &p, float hr, float hl,
+                                                  float vb, float vt, float u, float v, float half_delta_over3, float half_gamma_over3)
+{
+  float4 c0, c1;
+  data_term_cell<NOC>(a, i, j, p, hr, hl, vb, vt, u, v, half_delta_over3, half_gamma_over3, c0, c1);
   float4 *C = a.Cp(pair) + a.cidx(i, j);
-  C[0] = make_float4(M11 / det, A12 / -det, M22 / det, B1);
-  C[1] = make_float4(B2, hr, vb, vt);
+  C[0] = c0;
+  C[1] = c1;
 }
 
 template <int NOC>
@@ -856,8 +866,10 @@ __device__ __forceinline__ void sor_rows_wave(const VrArgs &a, int pair, float o
 // least DB + 2 >= M steps, hence by a barrier.  The barrier sits a third into its step (after the neighbour products)
 // so the latency of the previous step's LDS store and of the loads issued behind the barrier is covered by arithmetic.
 // Waves that do not solve (copy helpers, the other waves of the fused kernel) only count barriers.
-template <int P, int U, bool NT, int M>
-__device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float omega, int wv, int lane)
+// CL: the system cells come from an LDS copy `lc` of the pair's skewed C (the fused kernel's data phase writes it there)
+// instead of the register-ring prefetch from global memory.
+template <int P, int U, bool NT, int M, bool CL = false>
+__device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float omega, int wv, int lane, const float4 *lc = nullptr)
 {
   constexpr int UT = P;                                          // unroll of the tail loop
   static_assert(U % M == 0 && UT % M == 0 && U % P == 0, "barrier phase must be a compile-time property of the unrolled step");
@@ -890,8 +902,15 @@ __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float o
     const vf4 x = NT ? __builtin_nontemporal_load(cp) : cp[0], y = NT ? __builtin_nontemporal_load(cp + 1) : cp[1];
     st.c0 = make_float4(x.x, x.y, x.z, x.w); st.c1 = make_float4(y.x, y.y, y.z, y.w);
   };
+  Stage cnx;
+  const int lc_pl = a.SC * RP + 1;                               // two planes (c0 | c1) of 16-byte cells: conflict-free ds_read_b128
+  if constexpr (CL) {
+    lc += r;
+    cnx.c0 = lc[0]; cnx.c1 = lc[lc_pl];
+  } else {
 #pragma unroll
-  for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }
+    for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }
+  }
   for (int t = 0; t < off / M; ++t) asm volatile("s_barrier" ::: "memory");
   int lrow = r;                                                  // LDS cell (diagonal s, my row)
   int trow = b > 0 ? rb - 1 : RP;                                // LDS cell (diagonal s, row above the band) [band 0: a zero cell]
@@ -901,9 +920,11 @@ __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float o
   const int rpd2 = 2 * RPD;
   auto step = [&](auto tail_tag, int u, int s) {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    Stage &st = ring[u % P];
+    Stage &st = ring[CL ? 0 : u % P];
+    if constexpr (CL) st = cnx;
     const float om = (!TAIL || s < S) ? om_lane : 0.f;
-    // DPP reads must run with all lanes enabled: compute, pin, then select
+    // DPP reads must run with all lanes enabled: compute, pin, then select.  (wave_shr:1 with old = tpl and no
+    // bound_ctrl would drop the two selects, but ties the DPP to the LDS load of tpl: measured 3 % slower.)
     float dx = dpp_wave_shr1(prev.x), dy = dpp_wave_shr1(prev.y);
     asm volatile("" : "+v"(dx), "+v"(dy));
     const float2 top = first_row ? tpl : make_float2(dx, dy);
@@ -912,16 +933,9 @@ __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float o
     float s1 = hr * nxr.x, s2 = hr * nxr.y;
     s1 = s1 + vt * top.x;  s2 = s2 + vt * top.y;
     s1 = s1 + vb * nxb.x;  s2 = s2 + vb * nxb.y;
-#ifndef FOTG_X_NOBAR
     if (u % M == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(s1), "+v"(s2) :: "memory");   // tied to (s1,s2): placed here
-#endif
     float2 nr, nb, tp;
-#ifdef FOTG_X_NOLDR
-    nr = nxr; nb = nxb; tp = tpl;
-    if (false) {
-#else
     if (!TAIL) {
-#endif
       nr = lds_d_ld(lrow + rpd2); nb = lds_d_ld(lrow + rpd2 + 1);  // diagonal s+2: right / bottom of step s+1
       tp = lds_d_ld(trow);                                         // (diagonal s, row above the band): top of step s+1
     } else {
@@ -929,19 +943,21 @@ __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float o
       nr = lds_d_ld(d2 * RPD + r); nb = lds_d_ld(d2 * RPD + r + 1);
       tp = lds_d_ld(d0 * RPD + (b > 0 ? rb - 1 : RP));
     }
+    if constexpr (CL) {                                          // cells of diagonal s+1 (diagonal S is all zero)
+      if (!TAIL || s + 1 <= S) lc += RP;
+      cnx.c0 = lc[0]; cnx.c1 = lc[lc_pl];
+    }
     s1 = s1 + b1;          s2 = s2 + b2;
     const float B1 = hl * prev.x + s1, B2 = hl * prev.y + s2;
     float2 res;
     res.x = own.x + om * (a11 * B1 + a12 * B2 - own.x);
     res.y = own.y + om * (a12 * B1 + a22 * B2 - own.y);
-#ifndef FOTG_X_NOSTORE
     lds_d_st((!TAIL || s < S) ? lrow : (S + 1) * RPD + r, res);
-#endif
     prev = res; hl = hr; own = nxr; nxr = nr; nxb = nb; tpl = tp;
-#ifndef FOTG_X_NOC
-    load_c(st, cptr);
-#endif
-    if (!TAIL || cptr < cend) cptr += c_row;
+    if constexpr (!CL) {
+      load_c(st, cptr);
+      if (!TAIL || cptr < cend) cptr += c_row;
+    }
     lrow += RPD; trow += RPD;
   };
   int t0 = 0;
@@ -999,7 +1015,9 @@ __global__ __launch_bounds__(BANDED == 1 ? 1024 : BANDED >= 2 ? 512 : 256) void 
 //   repeat inner times { smoothness, data term + sub_laplacian + block inverse -> system C ; sor_coupled } ; flow = w + d.
 // (du,dv) never leave LDS; the smoothness weights live in an LDS plane; C goes through global memory (L2) to the
 // solver waves of the same workgroup.  Replaces 2*inner + 2 launches (and the LDS copy-in/out of D) per level.
-template <int NOC, int K, int P, int U, int BANDED>
+// CL (barrier-stepped waves only): the system cells C stay in LDS too -- the data phase writes them there and the solver
+// waves read them with ds_read_b128, so nothing but the level's input planes crosses the CU boundary inside the loop.
+template <int NOC, int K, int P, int U, int BANDED, bool CL>
 __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
                                                              float half_gamma_over3, float omega, float *__restrict__ flow, long flow_stride,
                                                              const float *__restrict__ I0, const float *__restrict__ I1, long img_stride, int tw, int pad)
@@ -1008,8 +1026,11 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
   const int w = a.w, h = a.h, st = a.st, S = a.S, RPD = a.RPD;
   const int ncell = (S + 2) * RPD;
   float *sm = reinterpret_cast<float *>(fotg_lds64 + FOTG_LDS_HDR + ncell);            // smoothness plane [h][w]
+  float4 *lc = reinterpret_cast<float4 *>(fotg_lds64 + FOTG_LDS_HDR + ncell + 2 * ((w * h + 3) / 4));   // CL: skewed C, SC x RP cells (+1)
+  const int nlc = CL ? (a.SC * a.RP + 1) * 2 : 0;
   const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
   for (int k = threadIdx.x; k < ncell; k += blockDim.x) lds_d_st(k, make_float2(0.f, 0.f));     // image_erase(du), (dv) (:185-186)
+  for (int k = threadIdx.x; k < nlc; k += blockDim.x) lc[k] = make_float4(0.f, 0.f, 0.f, 0.f);  // cells outside the image stay zero
   // set-up stages of the level (refine_variational.cpp:182-183): warp + mask + mean/difference, then the derivative planes
   for (int px = threadIdx.x; px < w * h; px += blockDim.x) prep_pixel<NOC>(a, pair, px % w, px / w, I0, I1, img_stride, tw, pad, flow, flow_stride);
   __syncthreads();
@@ -1065,12 +1086,19 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
         const float vb = (j < h - 1) ? s_o + sm[px + w] : 0.0f;
         const float vt = (j > 0) ? sm[px - w] + s_o : 0.0f;
         const float2 duv = lds_d_ld((i + j) * RPD + j);
-        data_term_compute<NOC>(a, pair, i, j, pin[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
+        if constexpr (CL) {
+          float4 c0, c1;
+          data_term_cell<NOC>(a, i, j, pin[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3, c0, c1);
+          lc[(i + j) * a.RP + j] = c0;
+          lc[(i + j) * a.RP + j + a.SC * a.RP + 1] = c1;
+        } else {
+          data_term_compute<NOC>(a, pair, i, j, pin[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
+        }
       }
     }
     sor_pipe_reset_progress();
     __syncthreads();                                             // also drains the C stores (vmcnt(0)) before the solver reads them
-    if constexpr (BANDED == 3) sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M>(a, pair, omega, wv, lane);
+    if constexpr (BANDED == 3) sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M, CL>(a, pair, omega, wv, lane, lc);
     else if constexpr (BANDED) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
     else { if (wv < a.nsweeps) sor_pipe_wave<K, P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
     __syncthreads();
@@ -1082,8 +1110,13 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
     f[2 * px] = wx[o] + d.x;
     f[2 * px + 1] = wy[o] + d.y;
   }
-  float2 *Dg = a.Dp(pair);                                       // keep the global copy of (du,dv) current (test taps)
+  if (!a.taps) return;
+  float2 *Dg = a.Dp(pair);                                       // test taps: global copies of (du,dv) and of the last system
   for (int k = threadIdx.x; k < (S + 1) * RPD; k += blockDim.x) Dg[k] = lds_d_ld(k);
+  if constexpr (CL) {
+    float4 *Cg = a.Cp(pair);
+    for (int k = threadIdx.x; k < a.SC * a.RP; k += blockDim.x) { Cg[2 * k] = lc[k]; Cg[2 * k + 1] = lc[k + a.SC * a.RP + 1]; }
+  }
 }
 #undef FOTG_CBAR
 

@@ -126,6 +126,21 @@ class OFClass:
         check(lib().fotg_calc_batch_u8(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(_dev_f32(outflow, "outflow")), _stream()))
         return outflow
 
+    def calc_sequence(self, frames, initflow=None, outflow=None):
+        """video mode: frames (n+1, h, w[, channels]) float32 or uint8 on the device -> the n flows frame k -> k+1; every
+        frame's pyramid is built once.  Same bits as calc_batch(frames[:-1], frames[1:])"""
+        if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.is_contiguous() and frames.dtype in (torch.float32, torch.uint8)):
+            raise FotgError("frames must be a contiguous float32 or uint8 CUDA(HIP) tensor")
+        n = frames.shape[0] - 1
+        exp = (n + 1, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
+        if n < 1 or tuple(frames.shape) != exp:
+            raise FotgError("frame shape %s does not match the configured %s" % (tuple(frames.shape), exp))
+        if outflow is None:
+            outflow = self.new_outflow(n)
+        fn = lib().fotg_calc_sequence if frames.dtype == torch.float32 else lib().fotg_calc_sequence_u8
+        check(fn(self._h, n + 1, _ptr(frames), _ptr(initflow), _ptr(_dev_f32(outflow, "outflow")), _stream()))
+        return outflow
+
     def upsample_crop(self, flow, out=None):
         """src/run_dense.cpp:293-303: x 2^finest, bilinear upsample, crop the padding -> (n, h_org, w_org, 2)"""
         flow = _dev_f32(flow, "flow")

@@ -77,6 +77,13 @@ int fotg_calc_batch(fotg_ctx *ctx, int n, const float *I0, const float *I1, cons
  * kernel, which then reads a quarter of the bytes.  Results are bit-identical to fotg_calc_batch on the converted frames. */
 int fotg_calc_batch_u8(fotg_ctx *ctx, int n, const unsigned char *I0, const unsigned char *I1, const float *initflow,
                        float *outflow, void *stream);
+/* Sequence mode (video): `frames` = n_frames consecutive frames (same layout as I0 above), outflow = the n_frames - 1
+ * flows frame k -> frame k+1 (2 <= n_frames <= max_batch + 1).  Each frame's pyramid is built once and serves as the
+ * target of pair k-1 and as the template source of pair k -- the reference rebuilds both pyramids for every pair
+ * (kroeger/run_dense.cpp:331-336).  Bit-identical to fotg_calc_batch(frames[0..n-2], frames[1..n-1]). */
+int fotg_calc_sequence(fotg_ctx *ctx, int n_frames, const float *frames, const float *initflow, float *outflow, void *stream);
+int fotg_calc_sequence_u8(fotg_ctx *ctx, int n_frames, const unsigned char *frames, const float *initflow, float *outflow,
+                          void *stream);
 /* Single pair, outflow in HOST memory, synchronous -- the exact shape of the reference call. */
 int fotg_calc(fotg_ctx *ctx, const float *I0, const float *I1, const float *initflow, float *outflow_host);
 
@@ -125,6 +132,8 @@ int fotg_grid_set_trace(fotg_ctx *ctx, int level, float *trace_host);
 int fotg_varref(fotg_ctx *ctx, int level, int n, const float *I0, const float *I1, long pair_stride,
                 float *flow, void *stream);
 /* test tap: copy one refinement workspace plane (stride-padded, FDF image_t layout) of pair `pair` to host.
+ * The solver planes (du, dv, a11 .. sv) of levels refined entirely on chip are only written back when
+ * fotg_enable_taps(ctx, 1) was called before fotg_varref.
  * name: "wx","wy","mask","du","dv","sh","sv","a11","a12","a22" (block inverse),"b1","b2","avg","Iz","Ix","Iy","Ixx","Ixy","Iyy","Ixz","Iyz" */
 int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, float *host_out);
 

@@ -133,6 +133,7 @@ def test_varref_golden_reference_vectors(noc):
         ps = 8
         padlvl = lambda a: np.pad(a.transpose(1, 2, 0), ((ps, ps), (ps, ps), (0, 0)), mode="edge")
         flow = dev(np.stack([wx, wy], -1))[None].contiguous()
+        F.lib().fotg_enable_taps(ofc._h, 1)     # solver planes of on-chip levels are only written back for taps
         VarRefClass(ofc, dev(padlvl(im1))[None], dev(padlvl(im2))[None], ofc.iparams[0], op, flow)
         out = flow[0].cpu().numpy()
         st = ((w + 3) // 4) * 4
@@ -189,6 +190,21 @@ def test_solver_fallback_paths(path, bands, alley, monkeypatch):
         out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
         p = oracle_params(O, op)
         assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (path, case)
+
+
+def test_fused_level_system_in_global_memory(alley, monkeypatch):
+    """the on-chip levels keep the linear system in LDS when it fits; FOTG_VR_CLDS=0 forces the variant that streams it
+    through global memory (what larger levels use): same bits"""
+    F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_CLDS", "0")
+    for case, op_point in (("alley", 2), ("synth_rgb", 2)):
+        f0, f1, noc = frames(case, alley)
+        h, w = f0.shape[:2]
+        op = F.operating_point(op_point, w, noc)
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        p = oracle_params(O, op)
+        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
 
 
 @pytest.mark.parametrize("np_per_wave", ["2", "4"])
@@ -265,6 +281,29 @@ def test_uint8_frames(alley):
         p = oracle_params(O, op)
         assert np.array_equal(got, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
         assert np.array_equal(got, ofc.calc(dev(f0), dev(f1)).cpu().numpy()), case
+
+
+def test_sequence_mode(alley):
+    """video front end: n+1 consecutive frames -> n flows with every pyramid built once; each flow
+    equals the oracle on its pair (float and 8-bit frames, gray and RGB, full max_batch)"""
+    F, OFClass, _, O = _mods()
+    for noc, (h, w) in ((1, (272, 480)), (3, (200, 328))):
+        seq = [synth_pair(h, w, seed=40 + k, noc=noc)[0] for k in range(2)]
+        seq += [synth_pair(h, w, seed=40, noc=noc)[1], synth_pair(h, w, seed=41, noc=noc)[1]]
+        seq = np.stack(seq)                                               # 4 frames -> 3 pairs
+        op = F.operating_point(2, w, noc)
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=3)
+        p = oracle_params(O, op)
+        ref = [O.flow(O.pad_frame(seq[k], p.sc_f), O.pad_frame(seq[k + 1], p.sc_f), p, 0) for k in range(3)]
+        got = ofc.calc_sequence(dev(seq)).cpu().numpy()
+        for k in range(3):
+            assert np.array_equal(got[k], ref[k]), (noc, k)
+        got8 = ofc.calc_sequence(torch.from_numpy(np.ascontiguousarray(seq.astype(np.uint8))).cuda()).cpu().numpy()
+        assert np.array_equal(got8, got), noc
+        # an ordinary batch call afterwards is unaffected by the shifted target pointers
+        assert np.array_equal(ofc.calc_batch(dev(seq[:3]), dev(seq[1:])).cpu().numpy(), got)
+        with pytest.raises(F.FotgError):
+            ofc.calc_sequence(dev(np.concatenate([seq, seq[:1]])))        # 4 pairs > max_batch
 
 
 def test_initflow_warm_start(alley):
