@@ -111,6 +111,7 @@ int fotg_op_point(int op, int width_org, int channels, fotg_params *p)
   memset(p, 0, sizeof(*p));
   p->dp_thresh = 0.05f; p->dr_thresh = 0.95f; p->res_thresh = 0.0f; p->patnorm = 1; p->noc = channels;
   p->tv_alpha = 10.0f; p->tv_gamma = 10.0f; p->tv_delta = 5.0f; p->tv_innerit = 1; p->tv_solverit = 3; p->tv_sor = 1.6f;
+  p->costfct = 0; p->normoutlier = 5.0f;
   p->sor_mode = FOTG_SOR_LEXICOGRAPHIC;
   int sub;
   switch (op) {
@@ -167,6 +168,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   if (p->ps != 8 && p->ps != 12) return FOTG_ERR_UNSUPPORTED;     // op-points use 8 and 12 (run_dense.cpp:242-261)
   if (p->sc_l < 0 || p->sc_f < p->sc_l || p->sc_f >= FOTG_MAXLEV) return FOTG_ERR_ARG;
   if (p->max_iter < 0 || p->tv_solverit < 0 || p->tv_innerit < 0) return FOTG_ERR_ARG;
+  if (p->costfct < 0 || p->costfct > 2 || (p->costfct == 2 && !(p->normoutlier > 0))) return FOTG_ERR_ARG;
   HIPCHK(hipSetDevice(device));
   fotg_ctx *c = new (std::nothrow) fotg_ctx();
   if (!c) return FOTG_ERR_ARG;
@@ -435,6 +437,7 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   a.trace = gs.trace_host ? c->trace_dev[l] : nullptr;
   a.g = g;
   a.max_iter = c->p.max_iter; a.min_iter = c->p.min_iter; a.patnorm = c->p.patnorm;
+  a.costfct = c->p.costfct; a.huber_bsq = c->p.normoutlier * c->p.normoutlier; a.huber_2bsq = a.huber_bsq * 2.0f;   // kroeger/oflow.cpp:106-107
   a.dp_thresh_sq = c->p.dp_thresh * c->p.dp_thresh;                 // kroeger/oflow.cpp:88
   a.dr_thresh = c->p.dr_thresh; a.res_thresh = c->p.res_thresh;
   a.outlier = (float)c->ps / 2;                                     // :82

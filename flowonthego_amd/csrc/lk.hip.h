@@ -33,8 +33,8 @@ struct LkArgs {
   float *trace;                       // optional [nop][(max_iter+1)][4], pair 0 only
   LevelGeom g;
   int ps_unused;
-  int max_iter, min_iter, patnorm;
-  float dp_thresh_sq, dr_thresh, res_thresh, outlier;
+  int max_iter, min_iter, patnorm, costfct;
+  float dp_thresh_sq, dr_thresh, res_thresh, outlier, huber_bsq, huber_2bsq;
 };
 
 // NP patches per wave.  The per-pixel work (template, bilinear query patch, residual, wave reductions) runs patch
@@ -256,7 +256,12 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
             for (int e = 0; e < NE; ++e) q[e] -= m;
           }
 #pragma unroll
-          for (int e = 0; e < NE; ++e) { r[k][e] = q[e] - T[k][e]; wabs[k][e] = fabsf(r[k][e]); }   // :230-236
+          for (int e = 0; e < NE; ++e) {
+            float d = q[e] - T[k][e];                            // :230-236 L2: the difference image itself
+            if (a.costfct == 1) d = copysignf(sqrtf(fabsf(d)), d);                                      // :238-246 L1
+            else if (a.costfct == 2) d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / a.huber_bsq) - 1.0f) * a.huber_2bsq), d);   // :247-261
+            r[k][e] = d; wabs[k][e] = fabsf(d);
+          }
           maresu[k] = wave_sum(lane_sum(wabs[k])) / (float)NV;   // :278
         }
       }

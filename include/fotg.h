@@ -48,6 +48,8 @@ typedef struct fotg_params {
   int tv_solverit;     /* 3                         (src: var_ref_iter) */
   float tv_sor;        /* 1.6                       (src: var_ref_sor_weight) */
   int sor_mode;        /* FOTG_SOR_* */
+  int costfct;         /* patch cost: 0 L2 (all operating points), 1 L1, 2 pseudo-Huber (kroeger/oflow.h:45, patch.cpp:230-261) */
+  float normoutlier;   /* 5.0: Huber threshold (kroeger/oflow.h:63; src: norm_outlier) */
 } fotg_params;
 
 typedef struct fotg_ctx fotg_ctx;

@@ -43,6 +43,7 @@ void dis_op_point(int op, int width_org, int noc, dis_params *p)
   p->patnorm = 1; p->noc = noc;
   p->tv_alpha = 10.0f; p->tv_gamma = 10.0f; p->tv_delta = 5.0f;
   p->tv_innerit = 1; p->tv_solverit = 3; p->tv_sor = 1.6f;
+  p->costfct = 0; p->normoutlier = 5.0f;                          /* run_dense.cpp:228, oflow.h:63 */
   int sub;
   switch (op) {
     case 1: p->ps = 8;  p->patove = 0.3f;  sub = 2; p->max_iter = 16;  p->usetvref = 0; break;
@@ -282,7 +283,7 @@ static void patch_bil(const dis_grid *g, const dis_params *p, const float *img, 
 }
 
 /* patchgrid.cpp:134-141 Optimize -> patch.cpp:159-212 OptimizeIter, :120-156 OptimizeStart,
- * :264-284 OptimizeComputeErrImg, :223-236 LossComputeErrorImage (L2 cost, costfct 0) */
+ * :264-284 OptimizeComputeErrImg, :223-261 LossComputeErrorImage (costfct 0 L2, 1 L1, 2 pseudo-Huber) */
 void dis_grid_optimize(dis_grid *g, const dis_params *p, const float *I1, float *trace)
 {
   const int ps = g->ps, noc = g->noc, nv = ps * ps * noc;
@@ -337,7 +338,15 @@ void dis_grid_optimize(dis_grid *g, const dis_params *p, const float *I1, float 
       }
     compute_err:
       patch_bil(g, p, I1, ptx, pty, pdiff);                          /* :266 */
-      for (int e = 0; e < nv; ++e) { pdiff[e] = pdiff[e] - T[e]; pw[e] = fabsf(pdiff[e]); }  /* :230-236 */
+      for (int e = 0; e < nv; ++e) {
+        float d = pdiff[e] - T[e];                                   /* :230-236 L2: the difference image itself */
+        if (p->costfct == 1) d = copysignf(sqrtf(fabsf(d)), d);      /* :238-246 L1: sign(d) * sqrt(|d|) */
+        else if (p->costfct == 2) {                                  /* :247-261 pseudo-Huber, b = normoutlier (oflow.cpp:106-107) */
+          const float bsq = p->normoutlier * p->normoutlier, bsq2 = bsq * 2.0f;
+          d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / bsq) - 1.0f) * bsq2), d);
+        }
+        pdiff[e] = d; pw[e] = fabsf(d);
+      }
       dpn = dp0 * dp0 + dp1 * dp1;                                   /* :272 */
       if (cnt == 1) dpn_init = dpn;
       mares_old = mares;

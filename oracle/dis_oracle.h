@@ -41,6 +41,8 @@ typedef struct dis_params {
   float tv_alpha, tv_gamma, tv_delta;
   int tv_innerit, tv_solverit;
   float tv_sor;
+  int costfct;       /* oflow.h:45: 0 L2, 1 L1, 2 pseudo-Huber (patch.cpp:230-261); the operating points use 0 */
+  float normoutlier; /* oflow.h:63: 5.0, Huber threshold b */
 } dis_params;
 
 /* kroeger/run_dense.cpp:180-183 and :225-268.  op in 1..4 (anything else -> 2). */

@@ -35,6 +35,7 @@ def oracle_params(O, op):
     p.patove, p.patnorm, p.noc, p.usetvref = op.patch_stride, int(op.use_mean_normalization), op.channels, int(op.use_var_ref)
     p.tv_alpha, p.tv_gamma, p.tv_delta = op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta
     p.tv_innerit, p.tv_solverit, p.tv_sor = 1, op.var_ref_iter, op.var_ref_sor_weight
+    p.costfct, p.normoutlier = op.cost_func, op.norm_outlier
     return p
 
 
@@ -281,6 +282,27 @@ def test_uint8_frames(alley):
         p = oracle_params(O, op)
         assert np.array_equal(got, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
         assert np.array_equal(got, ofc.calc(dev(f0), dev(f1)).cpu().numpy()), case
+
+
+@pytest.mark.parametrize("cost_func", [1, 2])
+def test_patch_cost_functions(cost_func, alley):
+    """L1 and pseudo-Huber patch costs (kroeger/patch.cpp:238-261; the operating points use L2):
+    patch grid state and the final flow against the oracle, gray and RGB"""
+    F, OFClass, _, O = _mods()
+    for case in ("alley", "synth_rgb"):
+        f0, f1, noc = frames(case, alley)
+        h, w = f0.shape[:2]
+        op = F.operating_point(2, w, noc)
+        op.cost_func = cost_func
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        p = oracle_params(O, op)
+        ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+        assert np.array_equal(out, ref), (cost_func, case)
+        op.cost_func = 0
+        l2 = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size)).calc(dev(f0), dev(f1)).cpu().numpy()
+        assert not np.array_equal(out, l2)                     # the switch does something
+        assert np.median(epe(out, l2)) < 0.5                   # ... but it is still the same flow field
 
 
 def test_sequence_mode(alley):

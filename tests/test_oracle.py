@@ -106,6 +106,35 @@ def test_synthetic_flow_recovers_shift():
     assert np.median(epe(fl, gt)) < 0.5
 
 
+def test_patch_cost_functions_numpy_restatement():
+    """costfct 1 / 2 (kroeger/patch.cpp:238-261): the oracle's L1 and pseudo-Huber error images, checked through the
+    patch weights it reports against a numpy restatement of the two formulas applied to the L2 run's first error image
+    (at iteration 0 all three see the same difference image), and through the recovered flow"""
+    f0, f1, gt = synth_pair(272, 480, seed=7, truth=True)
+    p = O.op_point(2, 480, 1)
+    p.max_iter = p.min_iter = 0                    # OptimizeStart only: pweight = |transformed difference image|
+    a, b = O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f)
+    P0, P1 = O.Pyramid(a, p.sc_f, p.ps), O.Pyramid(b, p.sc_f, p.ps)
+    l = p.sc_l
+    pw = {}
+    for cf in (0, 1, 2):
+        p.costfct = cf
+        g = O.Grid(*P0.level_wh(l), l, p)
+        g.init(P0.im[l], P0.dx[l], P0.dy[l])
+        g.optimize(P1.im[l])
+        pw[cf] = g.pweight
+    d = pw[0]                                      # |d| (sign does not matter for the weights)
+    assert np.array_equal(pw[1], np.sqrt(d))
+    bsq = np.float32(25.0)
+    hub = np.sqrt((np.sqrt(np.float32(1.0) + (d * d) / bsq) - np.float32(1.0)) * (bsq * np.float32(2.0)))
+    assert np.array_equal(pw[2], hub.astype(np.float32))
+    for cf in (1, 2):
+        q = O.op_point(2, 480, 1)
+        q.costfct = cf
+        fl = O.upsample_crop(O.flow(a, b, q, 0), q.sc_l, *O.padded_size(480, 272, q.sc_f)[2:], 480, 272)
+        assert np.median(epe(fl, gt)) < 0.5
+
+
 def test_redblack_is_not_reference(alley):
     a, b = alley["frame_0001"].astype(np.float32), alley["frame_0002"].astype(np.float32)
     e = epe(O.full_flow(a, b, op=2), O.full_flow(a, b, op=2, sor_mode=1))
