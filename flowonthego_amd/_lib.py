@@ -17,7 +17,7 @@ class FotgParams(C.Structure):
                 ("res_thresh", C.c_float), ("patove", C.c_float), ("patnorm", C.c_int), ("noc", C.c_int),
                 ("usetvref", C.c_int), ("tv_alpha", C.c_float), ("tv_gamma", C.c_float),
                 ("tv_delta", C.c_float), ("tv_innerit", C.c_int), ("tv_solverit", C.c_int),
-                ("tv_sor", C.c_float), ("sor_mode", C.c_int), ("costfct", C.c_int), ("normoutlier", C.c_float)]
+                ("tv_sor", C.c_float), ("sor_mode", C.c_int), ("costfct", C.c_int), ("normoutlier", C.c_float), ("usefbcon", C.c_int)]
 
 
 # every symbol include/fotg.h declares: (name, restype, argtypes)

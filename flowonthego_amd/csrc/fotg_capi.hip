@@ -43,6 +43,8 @@ struct fotg_ctx {
   float *flow[FOTG_MAXLEV];          // [B][h][w][2]
   float *p_iter[FOTG_MAXLEV];        // [B][nop][2]
   float *pweight[FOTG_MAXLEV];       // [B][nop][nv]
+  // forward-backward merge (usefbcon): frame-1 gradients and the backward grid / flow (kroeger/oflow.cpp:133-170)
+  float *dx1[FOTG_MAXLEV], *dy1[FOTG_MAXLEV], *p_iter_bw[FOTG_MAXLEV], *pweight_bw[FOTG_MAXLEV], *flow_bw[FOTG_MAXLEV];
   float *tap_t[FOTG_MAXLEV], *tap_tx[FOTG_MAXLEV], *tap_ty[FOTG_MAXLEV], *tap_hes[FOTG_MAXLEV];
   int *tap_cnt[FOTG_MAXLEV];
   float *trace_dev[FOTG_MAXLEV];
@@ -111,7 +113,7 @@ int fotg_op_point(int op, int width_org, int channels, fotg_params *p)
   memset(p, 0, sizeof(*p));
   p->dp_thresh = 0.05f; p->dr_thresh = 0.95f; p->res_thresh = 0.0f; p->patnorm = 1; p->noc = channels;
   p->tv_alpha = 10.0f; p->tv_gamma = 10.0f; p->tv_delta = 5.0f; p->tv_innerit = 1; p->tv_solverit = 3; p->tv_sor = 1.6f;
-  p->costfct = 0; p->normoutlier = 5.0f;
+  p->costfct = 0; p->normoutlier = 5.0f; p->usefbcon = 0;
   p->sor_mode = FOTG_SOR_LEXICOGRAPHIC;
   int sub;
   switch (op) {
@@ -146,6 +148,7 @@ void fotg_destroy(fotg_ctx *c)
   for (int l = 0; l < FOTG_MAXLEV; ++l) {
     (void)hipFree(c->im[0][l]); (void)hipFree(c->im[1][l]); (void)hipFree(c->dx0[l]); (void)hipFree(c->dy0[l]);
     (void)hipFree(c->flow[l]); (void)hipFree(c->p_iter[l]); (void)hipFree(c->pweight[l]);
+    (void)hipFree(c->dx1[l]); (void)hipFree(c->dy1[l]); (void)hipFree(c->p_iter_bw[l]); (void)hipFree(c->pweight_bw[l]); (void)hipFree(c->flow_bw[l]);
     (void)hipFree(c->tap_t[l]); (void)hipFree(c->tap_tx[l]); (void)hipFree(c->tap_ty[l]); (void)hipFree(c->tap_hes[l]); (void)hipFree(c->tap_cnt[l]);
     (void)hipFree(c->trace_dev[l]);
     (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]);
@@ -194,6 +197,13 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       ALLOC(c->flow[l], B * g.w * g.h * 2 * sizeof(float));
       ALLOC(c->p_iter[l], B * g.nop * 2 * sizeof(float));
       ALLOC(c->pweight[l], B * g.nop * (size_t)(p->ps * p->ps * c->noc) * sizeof(float));
+      if (p->usefbcon) {
+        ALLOC(c->dx1[l], bytes);
+        ALLOC(c->dy1[l], bytes);
+        ALLOC(c->flow_bw[l], B * g.w * g.h * 2 * sizeof(float));
+        ALLOC(c->p_iter_bw[l], B * g.nop * 2 * sizeof(float));
+        ALLOC(c->pweight_bw[l], B * g.nop * (size_t)(p->ps * p->ps * c->noc) * sizeof(float));
+      }
     }
   }
   if (p->usetvref) {
@@ -460,20 +470,35 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   return FOTG_OK;
 }
 
+// AggregateFlowDense of the grid (p_iter, pweight); cg_*: the complementary grid set by SetComplGrid or nullptr
+static int aggregate_impl(fotg_ctx *c, int l, int n, const float *p_iter, const float *pweight, const float *cg_p_iter,
+                          const float *cg_pweight, float *flowout, hipStream_t s)
+{
+  const LevelGeom &g = c->geom[l];
+  const long fs = (long)g.w * g.h * 2;
+  if (cg_p_iter) {
+    dim3 grid(((g.w + 15) / 16) * ((g.h + 15) / 16), n), block(256);
+    if (c->ps == 8 && c->noc == 1) densify_fb_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g);
+    else if (c->ps == 8) densify_fb_kernel<8, 3><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g);
+    else if (c->noc == 1) densify_fb_kernel<12, 1><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g);
+    else densify_fb_kernel<12, 3><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g);
+    LAUNCHCHK();
+    return FOTG_OK;
+  }
+  dim3 grid((g.w * g.h + 255) / 256, n), block(256);
+  if (c->ps == 8 && c->noc == 1) densify_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g);
+  else if (c->ps == 8) densify_kernel<8, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g);
+  else if (c->noc == 1) densify_kernel<12, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g);
+  else densify_kernel<12, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g);
+  LAUNCHCHK();
+  return FOTG_OK;
+}
+
 int fotg_grid_aggregate(fotg_ctx *c, int l, int n, float *flowout, void *stream)
 {
   int st = check_level(c, l, n); if (st) return st;
   if (!flowout) return FOTG_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  const LevelGeom &g = c->geom[l];
-  dim3 grid((g.w * g.h + 255) / 256, n), block(256);
-  const long fs = (long)g.w * g.h * 2;
-  if (c->ps == 8 && c->noc == 1) densify_kernel<8, 1><<<grid, block, 0, s>>>(c->p_iter[l], c->pweight[l], flowout, fs, g);
-  else if (c->ps == 8) densify_kernel<8, 3><<<grid, block, 0, s>>>(c->p_iter[l], c->pweight[l], flowout, fs, g);
-  else if (c->noc == 1) densify_kernel<12, 1><<<grid, block, 0, s>>>(c->p_iter[l], c->pweight[l], flowout, fs, g);
-  else densify_kernel<12, 3><<<grid, block, 0, s>>>(c->p_iter[l], c->pweight[l], flowout, fs, g);
-  LAUNCHCHK();
-  return FOTG_OK;
+  return aggregate_impl(c, l, n, c->p_iter[l], c->pweight[l], nullptr, nullptr, flowout, (hipStream_t)stream);
 }
 
 int fotg_grid_read(fotg_ctx *c, int l, int pair, float *p_iter, float *pweight, float *tmpl, float *tdx, float *tdy,
@@ -557,7 +582,7 @@ static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, h
   set_bands(b, sweeps, 16);
   if (b.band_mode == 1) return launch_sor_pipe<1, 8, 1>(a, n, sweeps, omega, s, b, sweeps * b.nbands * 64);
   if (b.band_mode == 2) return launch_sor_pipe<1, 8, 2>(a, n, sweeps, omega, s, b, (sweeps * b.nbands < 4 ? 4 : sweeps * b.nbands) * 64);
-  if (b.band_mode == 3) return launch_sor_pipe<1, 8, 3>(a, n, sweeps, omega, s, b, (sweeps * b.nbands < 4 ? 4 : sweeps * b.nbands) * 64);
+  if (b.band_mode == 3) return launch_sor_pipe<1, 8, 3>(a, n, sweeps, omega, s, b, 1024);     // all 16 waves copy D in and out
   switch (a.K) {
     case 1: return launch_sor_pipe<1, 8, 0>(a, n, sweeps, omega, s, b, 256);
     case 2: return launch_sor_pipe<2, 8, 0>(a, n, sweeps, omega, s, b, 256);
@@ -757,11 +782,54 @@ template <typename T>
 static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float *initflow, float *outflow, hipStream_t stream)
 {
   int st;
-  const bool seq = I1 == nullptr;
+  const bool seq = I1 == nullptr, fb = c->p.usefbcon != 0;
   const int nimg = seq ? n + 1 : n;
-  if ((st = c->noc == 1 ? pyramid_impl<1, T>(c, nimg, I0, I1, stream) : pyramid_impl<3, T>(c, nimg, I0, I1, stream))) return st;
+  // the backward grid lives in a view of the context whose grid arrays are the *_bw ones (nothing is owned by the view)
+  fotg_ctx *vb = nullptr;
+  struct ViewGuard { fotg_ctx *&v; ~ViewGuard() { free(v); } } guard{vb};
+  if (fb) {
+    vb = (fotg_ctx *)malloc(sizeof(fotg_ctx));
+    if (!vb) return FOTG_ERR_ARG;
+    memcpy((void *)vb, (const void *)c, sizeof(fotg_ctx));
+    vb->taps = false;
+    for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) { vb->p_iter[l] = c->p_iter_bw[l]; vb->pweight[l] = c->pweight_bw[l]; memset((void *)&vb->gs[l], 0, sizeof(GridState)); }
+  }
+  if (fb && !seq) {
+    // both frames need gradients: two template-type pyramids (the second one into the frame-1 buffers)
+    if ((st = c->noc == 1 ? pyramid_impl<1, T>(c, n, I0, (const T *)nullptr, stream) : pyramid_impl<3, T>(c, n, I0, (const T *)nullptr, stream))) return st;
+    fotg_ctx *v1 = (fotg_ctx *)malloc(sizeof(fotg_ctx));
+    if (!v1) return FOTG_ERR_ARG;
+    memcpy((void *)v1, (const void *)c, sizeof(fotg_ctx));
+    for (int l = c->base_lv; l <= c->p.sc_f; ++l) { v1->im[0][l] = c->im[1][l]; v1->dx0[l] = c->dx1[l]; v1->dy0[l] = c->dy1[l]; }
+    st = c->noc == 1 ? pyramid_impl<1, T>(v1, n, I1, (const T *)nullptr, stream) : pyramid_impl<3, T>(v1, n, I1, (const T *)nullptr, stream);
+    free(v1);
+    if (st) return st;
+  } else if ((st = c->noc == 1 ? pyramid_impl<1, T>(c, nimg, I0, I1, stream) : pyramid_impl<3, T>(c, nimg, I0, I1, stream))) return st;
   for (int l = c->p.sc_f; l >= c->p.sc_l; --l) {
-    const float *tgt = seq ? c->im[0][l] + c->lev_stride[l] : c->im[1][l];
+    const long ls = c->lev_stride[l];
+    const float *tgt = seq ? c->im[0][l] + ls : c->im[1][l];
+    if (fb) {
+      // kroeger/oflow.cpp:190-235 and :262-295 with usefbcon: both grids, each one's densification merges the other's patches
+      const float *tx = seq ? c->dx0[l] + ls : c->dx1[l], *ty = seq ? c->dy0[l] + ls : c->dy1[l];
+      if ((st = fotg_grid_init(c, l, n, c->im[0][l], c->dx0[l], c->dy0[l], ls, stream))) return st;
+      if ((st = fotg_grid_set_target(c, l, tgt, ls))) return st;
+      if ((st = fotg_grid_init(vb, l, n, tgt, tx, ty, ls, stream))) return st;
+      if ((st = fotg_grid_set_target(vb, l, c->im[0][l], ls))) return st;
+      if (l < c->p.sc_f) {
+        if ((st = fotg_grid_init_from_coarser(c, l, n, c->flow[l + 1], stream))) return st;
+        if ((st = fotg_grid_init_from_coarser(vb, l, n, c->flow_bw[l + 1], stream))) return st;
+      } else if (initflow) { if ((st = fotg_grid_init_from_coarser(c, l, n, initflow, stream))) return st; }
+      if ((st = fotg_grid_optimize(c, l, n, stream))) return st;
+      if ((st = fotg_grid_optimize(vb, l, n, stream))) return st;
+      float *out = (l == c->p.sc_l) ? outflow : c->flow[l];
+      if ((st = aggregate_impl(c, l, n, c->p_iter[l], c->pweight[l], c->p_iter_bw[l], c->pweight_bw[l], out, stream))) return st;
+      if (l > c->p.sc_l && (st = aggregate_impl(c, l, n, c->p_iter_bw[l], c->pweight_bw[l], c->p_iter[l], c->pweight[l], c->flow_bw[l], stream))) return st;
+      if (c->p.usetvref) {
+        if ((st = fotg_varref(c, l, n, c->im[0][l], tgt, ls, out, stream))) return st;
+        if (l > c->p.sc_l && (st = fotg_varref(c, l, n, tgt, c->im[0][l], ls, c->flow_bw[l], stream))) return st;
+      }
+      continue;
+    }
     if ((st = fotg_grid_init(c, l, n, c->im[0][l], c->dx0[l], c->dy0[l], c->lev_stride[l], stream))) return st;
     if ((st = fotg_grid_set_target(c, l, tgt, c->lev_stride[l]))) return st;
     if (l < c->p.sc_f) { if ((st = fotg_grid_init_from_coarser(c, l, n, c->flow[l + 1], stream))) return st; }
@@ -806,7 +874,7 @@ static void make_view(const fotg_ctx *c, int p0, fotg_ctx *v)
 // enqueue the whole batch on stream s (forking to the internal sub-batch streams and joining back)
 static int calc_enqueue(fotg_ctx *c, int n, const float *I0, const float *I1, const float *initflow, float *outflow, hipStream_t s)
 {
-  const int nsub = (c->nsub > 1 && n >= 4 * c->nsub) ? c->nsub : 1;    // >= 4 pairs per sub-batch
+  const int nsub = (c->nsub > 1 && n >= 4 * c->nsub && !c->p.usefbcon) ? c->nsub : 1;    // >= 4 pairs per sub-batch
   if (nsub == 1) return calc_range(c, n, I0, I1, initflow, outflow, s);
   const LevelGeom &gf = c->geom[c->p.sc_l], &gc = c->geom[c->p.sc_f];
   const size_t frame = (size_t)c->w_org * c->h_org * c->noc, oflow = (size_t)gf.w * gf.h * 2;

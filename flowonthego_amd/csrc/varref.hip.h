@@ -974,7 +974,7 @@ __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float o
 
 // stand-alone launch of one sor_coupled call: D global -> LDS, sweeps, LDS -> global
 template <int K, int P, int U, int BANDED>
-__global__ __launch_bounds__(BANDED == 1 ? 1024 : BANDED >= 2 ? 512 : 256) void vr_sor_pipe_kernel(VrArgs a, float omega)
+__global__ __launch_bounds__(BANDED == 1 || BANDED == 3 ? 1024 : BANDED == 2 ? 512 : 256) void vr_sor_pipe_kernel(VrArgs a, float omega)
 {
   const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float2 *Dg = a.Dp(pair);
@@ -983,12 +983,13 @@ __global__ __launch_bounds__(BANDED == 1 ? 1024 : BANDED >= 2 ? 512 : 256) void 
   {
     const float4 *g4 = reinterpret_cast<const float4 *>(Dg);
     const int n2 = ncell >> 1;
-    for (int k = threadIdx.x; k < n2; k += 4 * blockDim.x) {
-      float4 v[4];
+    constexpr int Q = BANDED == 3 ? 8 : 4;                        // loads in flight per lane
+    for (int k = threadIdx.x; k < n2; k += Q * blockDim.x) {
+      float4 v[Q];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int kk = k + q * blockDim.x; v[q] = kk < n2 ? g4[kk] : make_float4(0.f, 0.f, 0.f, 0.f); }
+      for (int q = 0; q < Q; ++q) { const int kk = k + q * blockDim.x; v[q] = kk < n2 ? g4[kk] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < Q; ++q) {
         const int kk = k + q * blockDim.x;
         if (kk < n2) { lds_d_st(2 * kk, make_float2(v[q].x, v[q].y)); lds_d_st(2 * kk + 1, make_float2(v[q].z, v[q].w)); }
       }

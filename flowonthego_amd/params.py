@@ -45,6 +45,7 @@ class opt_params:
     channels: int = 1
     sor_mode: int = 0                # 0 lexicographic (kroeger, parity), 1 red-black (src/ ordering)
     cost_func: int = 0               # kroeger/oflow.h:45: 0 L2, 1 L1, 2 pseudo-Huber (threshold norm_outlier)
+    use_fbcon: bool = False          # kroeger/oflow.h:44 usefbcon: forward-backward merge in the densification
     # derived (src/oflow.cpp:45-48)
     outlier_thresh: float = 0.0
     steps: int = 0
@@ -70,7 +71,7 @@ class opt_params:
         p.tv_alpha, p.tv_gamma, p.tv_delta = self.var_ref_alpha, self.var_ref_gamma, self.var_ref_delta
         p.tv_innerit, p.tv_solverit, p.tv_sor = 1, self.var_ref_iter, self.var_ref_sor_weight
         p.sor_mode = self.sor_mode
-        p.costfct, p.normoutlier = self.cost_func, self.norm_outlier
+        p.costfct, p.normoutlier, p.usefbcon = self.cost_func, self.norm_outlier, int(self.use_fbcon)
         return p
 
 

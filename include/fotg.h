@@ -50,6 +50,8 @@ typedef struct fotg_params {
   int sor_mode;        /* FOTG_SOR_* */
   int costfct;         /* patch cost: 0 L2 (all operating points), 1 L1, 2 pseudo-Huber (kroeger/oflow.h:45, patch.cpp:230-261) */
   float normoutlier;   /* 5.0: Huber threshold (kroeger/oflow.h:63; src: norm_outlier) */
+  int usefbcon;        /* 0 (all operating points); 1: also compute the backward flow at every scale and merge both in the
+                          densification (kroeger/oflow.h:44, oflow.cpp:160-170, patchgrid.cpp:278-375) */
 } fotg_params;
 
 typedef struct fotg_ctx fotg_ctx;

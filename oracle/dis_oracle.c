@@ -44,6 +44,7 @@ void dis_op_point(int op, int width_org, int noc, dis_params *p)
   p->tv_alpha = 10.0f; p->tv_gamma = 10.0f; p->tv_delta = 5.0f;
   p->tv_innerit = 1; p->tv_solverit = 3; p->tv_sor = 1.6f;
   p->costfct = 0; p->normoutlier = 5.0f;                          /* run_dense.cpp:228, oflow.h:63 */
+  p->usefbcon = 0;                                                /* run_dense.cpp:228 */
   int sub;
   switch (op) {
     case 1: p->ps = 8;  p->patove = 0.3f;  sub = 2; p->max_iter = 16;  p->usetvref = 0; break;
@@ -368,6 +369,11 @@ void dis_grid_optimize(dis_grid *g, const dis_params *p, const float *I1, float 
 /* patchgrid.cpp:213-275 + :377-397 (usefbcon = 0) */
 void dis_grid_aggregate(const dis_grid *g, const dis_params *p, float *flowout)
 {
+  dis_grid_aggregate_fb(g, NULL, p, flowout);
+}
+
+void dis_grid_aggregate_fb(const dis_grid *g, const dis_grid *cg, const dis_params *p, float *flowout)
+{
   const int ps = g->ps, noc = g->noc, nv = ps * ps * noc, w = g->w, h = g->h;
   const float minerr = 2.0f;                                         /* oflow.h:62 */
   float *we = (float *)calloc((size_t)w * h, sizeof(float));
@@ -395,6 +401,38 @@ void dis_grid_aggregate(const dis_grid *g, const dis_params *p, float *flowout)
         we[i] += absw;
         flowout[2 * i] += f0 * absw;
         flowout[2 * i + 1] += f1 * absw;
+      }
+    }
+  }
+  /* patchgrid.cpp:278-375: the complementary grid's patches, at their position after optimisation (pt_iter), with
+     bilinear weights and reversed flow; same serial order (patch id, window row, window column, taps cc fc cf ff) */
+  for (int ip = 0; cg && ip < cg->nop; ++ip) {
+    const float f0 = cg->p_iter[2 * ip], f1 = cg->p_iter[2 * ip + 1];
+    const float *pw = cg->pweight + (size_t)ip * nv;
+    const float rx = cg->pt_ref[2 * ip] + f0, ry = cg->pt_ref[2 * ip + 1] + f1;      /* GetPointPos() = pt_iter (patch.cpp:214-221) */
+    const int pos0 = (int)ceil(rx + .00001), pos1 = (int)ceil(ry + .00001);        /* :302-305 (double arithmetic) */
+    const int pos2 = (int)floorf(rx), pos3 = (int)floorf(ry);
+    const float r0 = rx - pos2, r1 = ry - pos3;
+    const float wb0 = r0 * r1, wb1 = (1 - r0) * r1, wb2 = r0 * (1 - r1), wb3 = (1 - r0) * (1 - r1);
+    int lb = -ps / 2, ub = ps / 2 - 1;
+    for (int y = lb; y <= ub; ++y) for (int x = lb; x <= ub; ++x, ++pw) {
+      int yt = y + pos1, xt = x + pos0;
+      if (xt >= 1 && yt >= 1 && xt < (w - 1) && yt < (h - 1)) {
+        float absw;
+        if (noc == 1) absw = 1.0f / (float)(*pw > minerr ? *pw : minerr);
+        else {
+          absw = (float)(*pw > minerr ? *pw : minerr); ++pw;
+          absw += (float)(*pw > minerr ? *pw : minerr); ++pw;
+          absw += (float)(*pw > minerr ? *pw : minerr);
+          absw = 1.0f / absw;
+        }
+        const float n0 = f0 * absw, n1 = f1 * absw;
+        const int cc = xt + yt * w, fc = (xt - 1) + yt * w, cf = xt + (yt - 1) * w, ff = (xt - 1) + (yt - 1) * w;
+        we[cc] += wb0 * absw; we[fc] += wb1 * absw; we[cf] += wb2 * absw; we[ff] += wb3 * absw;
+        flowout[2 * cc] -= wb0 * n0; flowout[2 * cc + 1] -= wb0 * n1;
+        flowout[2 * fc] -= wb1 * n0; flowout[2 * fc + 1] -= wb1 * n1;
+        flowout[2 * cf] -= wb2 * n0; flowout[2 * cf + 1] -= wb2 * n1;
+        flowout[2 * ff] -= wb3 * n0; flowout[2 * ff + 1] -= wb3 * n1;
       }
     }
   }
@@ -750,26 +788,33 @@ void dis_varref(const float *I0, const float *I1, int w, int h, int lvl, const d
 void dis_flow_pyr(const dis_pyramid *P0, const dis_pyramid *P1, const dis_params *p,
                   const float *initflow, float *outflow, int sor_mode, float *level_dump)
 {
-  const int ns = p->sc_f - p->sc_l + 1;
-  float **flow = (float **)calloc(ns, sizeof(float *));
+  const int ns = p->sc_f - p->sc_l + 1, fb = p->usefbcon != 0;
+  float **flow = (float **)calloc(ns, sizeof(float *)), **flow_bw = (float **)calloc(ns, sizeof(float *));
   size_t dump_off = 0;
   for (int sl = p->sc_f; sl >= p->sc_l; --sl) {
     const int ii = sl - p->sc_l, w = dis_level_w(P0, sl), h = dis_level_h(P0, sl);
-    dis_grid *g = dis_grid_new(w, h, sl, p);
+    dis_grid *g = dis_grid_new(w, h, sl, p), *gb = fb ? dis_grid_new(w, h, sl, p) : NULL;   /* oflow.cpp:160-170 */
     flow[ii] = (float *)malloc(sizeof(float) * 2 * (size_t)w * h);
     dis_grid_init(g, p, P0->im[sl], P0->dx[sl], P0->dy[sl]);
-    if (sl < p->sc_f) dis_grid_init_from_coarser(g, flow[ii + 1]);
+    if (fb) { flow_bw[ii] = (float *)malloc(sizeof(float) * 2 * (size_t)w * h); dis_grid_init(gb, p, P1->im[sl], P1->dx[sl], P1->dy[sl]); }   /* :193-197 */
+    if (sl < p->sc_f) { dis_grid_init_from_coarser(g, flow[ii + 1]); if (fb) dis_grid_init_from_coarser(gb, flow_bw[ii + 1]); }   /* :209-216 */
     else if (initflow) dis_grid_init_from_coarser(g, initflow);
     dis_grid_optimize(g, p, P1->im[sl], NULL);
+    if (fb) dis_grid_optimize(gb, p, P0->im[sl], NULL);                                   /* :233-235 */
     float *out = (sl == p->sc_l) ? outflow : flow[ii];
-    dis_grid_aggregate(g, p, out);
+    dis_grid_aggregate_fb(g, gb, p, out);
+    if (fb && sl > p->sc_l) dis_grid_aggregate_fb(gb, g, p, flow_bw[ii]);                 /* :269-270 */
     if (level_dump) { memcpy(level_dump + dump_off, out, sizeof(float) * 2 * (size_t)w * h); dump_off += 2 * (size_t)w * h; }
-    if (p->usetvref) dis_varref(P0->im[sl], P1->im[sl], w, h, sl, p, out, sor_mode);
+    if (p->usetvref) {
+      dis_varref(P0->im[sl], P1->im[sl], w, h, sl, p, out, sor_mode);
+      if (fb && sl > p->sc_l) dis_varref(P1->im[sl], P0->im[sl], w, h, sl, p, flow_bw[ii], sor_mode);   /* :291-294 */
+    }
     if (level_dump) { memcpy(level_dump + dump_off, out, sizeof(float) * 2 * (size_t)w * h); dump_off += 2 * (size_t)w * h; }
     dis_grid_free(g);
+    if (gb) dis_grid_free(gb);
   }
-  for (int i = 0; i < ns; ++i) free(flow[i]);
-  free(flow);
+  for (int i = 0; i < ns; ++i) { free(flow[i]); free(flow_bw[i]); }
+  free(flow); free(flow_bw);
 }
 
 void dis_flow(const float *I0, const float *I1, int wp, int hp, const dis_params *p, float *outflow, int sor_mode)

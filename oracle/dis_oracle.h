@@ -43,6 +43,7 @@ typedef struct dis_params {
   float tv_sor;
   int costfct;       /* oflow.h:45: 0 L2, 1 L1, 2 pseudo-Huber (patch.cpp:230-261); the operating points use 0 */
   float normoutlier; /* oflow.h:63: 5.0, Huber threshold b */
+  int usefbcon;      /* oflow.h:44: merge forward and backward flow (patchgrid.cpp:278-375); the operating points use 0 */
 } dis_params;
 
 /* kroeger/run_dense.cpp:180-183 and :225-268.  op in 1..4 (anything else -> 2). */
@@ -91,6 +92,9 @@ void dis_grid_init_from_coarser(dis_grid *g, const float *flow_prev);
 /* trace (optional): per patch (max_iter+1) x 4 floats [p0,p1,mares,cnt] rows; may be NULL */
 void dis_grid_optimize(dis_grid *g, const dis_params *p, const float *I1, float *trace);
 void dis_grid_aggregate(const dis_grid *g, const dis_params *p, float *flowout);
+/* the same with a complementary grid cg (SetComplGrid, patchgrid.cpp:92-95): after g's own patches, every patch of cg is
+ * splatted at its MOVED position with bilinear weights and reversed flow (patchgrid.cpp:278-375).  cg may be NULL. */
+void dis_grid_aggregate_fb(const dis_grid *g, const dis_grid *cg, const dis_params *p, float *flowout);
 
 /* ---- variational refinement (kroeger/refine_variational.cpp + FDF1.0.1) ----
  * planar images have stride = ceil4(w) like image_new (image.c:15-31). */

@@ -23,7 +23,7 @@ class DisParams(C.Structure):
                 ("noc", C.c_int), ("usetvref", C.c_int), ("tv_alpha", C.c_float),
                 ("tv_gamma", C.c_float), ("tv_delta", C.c_float), ("tv_innerit", C.c_int),
                 ("tv_solverit", C.c_int), ("tv_sor", C.c_float),
-                ("costfct", C.c_int), ("normoutlier", C.c_float)]
+                ("costfct", C.c_int), ("normoutlier", C.c_float), ("usefbcon", C.c_int)]
 
 
 class DisPyramid(C.Structure):

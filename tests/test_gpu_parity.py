@@ -35,7 +35,7 @@ def oracle_params(O, op):
     p.patove, p.patnorm, p.noc, p.usetvref = op.patch_stride, int(op.use_mean_normalization), op.channels, int(op.use_var_ref)
     p.tv_alpha, p.tv_gamma, p.tv_delta = op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta
     p.tv_innerit, p.tv_solverit, p.tv_sor = 1, op.var_ref_iter, op.var_ref_sor_weight
-    p.costfct, p.normoutlier = op.cost_func, op.norm_outlier
+    p.costfct, p.normoutlier, p.usefbcon = op.cost_func, op.norm_outlier, int(op.use_fbcon)
     return p
 
 
@@ -303,6 +303,27 @@ def test_patch_cost_functions(cost_func, alley):
         l2 = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size)).calc(dev(f0), dev(f1)).cpu().numpy()
         assert not np.array_equal(out, l2)                     # the switch does something
         assert np.median(epe(out, l2)) < 0.5                   # ... but it is still the same flow field
+
+
+@pytest.mark.parametrize("case,op_point", [("alley", 2), ("synth_rgb", 2), ("synth_odd", 3), ("alley", 1)])
+def test_forward_backward_merge(case, op_point, alley):
+    """usefbcon (kroeger/oflow.cpp:160-170,193-197,233-235,269-270,291-294; patchgrid.cpp:278-375): backward
+    grid + refinement at every scale but the last, both densifications merge the other grid's patches at their moved
+    positions -- bit-identical to the oracle, also through the sequence entry point"""
+    F, OFClass, _, O = _mods()
+    f0, f1, noc = frames(case, alley)
+    h, w = f0.shape[:2]
+    op = F.operating_point(op_point, w, noc)
+    op.use_fbcon = True
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+    assert np.array_equal(ofc.calc_sequence(dev(np.stack([f0, f1])))[0].cpu().numpy(), ref)
+    op.use_fbcon = False
+    plain = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size)).calc(dev(f0), dev(f1)).cpu().numpy()
+    assert not np.array_equal(out, plain) and np.median(epe(out, plain)) < 0.5
 
 
 def test_sequence_mode(alley):

@@ -3,6 +3,7 @@
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,3 +61,22 @@ def test_product_package_does_not_import_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "dis_oracle" not in txt.replace("oracle/dis_oracle.c", ""), f
+
+
+def test_flo_writer_matches_reference_file_layout(tmp_path, alley_golden_flow):
+    """write_flo == SaveFlowFile (kroeger/run_dense.cpp:16-57): tag, int32 w, int32 h, h*w*2 float32; the golden flow of the
+    reference's own kroeger/flows/alley_0001.flo (tests/golden/alley_0001_flo.npz) survives a round trip bit for bit"""
+    from flowonthego_amd.flo import read_flo, write_flo
+    from oracle import oracle as O
+    path = str(tmp_path / "a.flo")
+    write_flo(path, alley_golden_flow)
+    raw = open(path, "rb").read()
+    h, w = alley_golden_flow.shape[:2]
+    assert raw[:4] == b"PIEH" and np.frombuffer(raw[4:12], "<i4").tolist() == [w, h] and len(raw) == 12 + h * w * 8
+    assert np.array_equal(read_flo(path), alley_golden_flow)
+    assert np.array_equal(O.read_flo(path), alley_golden_flow)        # the oracle's reader agrees
+    with pytest.raises(ValueError):
+        write_flo(path, alley_golden_flow[..., 0])
+    open(path, "wb").write(b"PIEX" + raw[4:])
+    with pytest.raises(ValueError):
+        read_flo(path)

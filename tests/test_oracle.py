@@ -135,6 +135,63 @@ def test_patch_cost_functions_numpy_restatement():
         assert np.median(epe(fl, gt)) < 0.5
 
 
+def test_forward_backward_merge_python_restatement():
+    """usefbcon: the oracle's dis_grid_aggregate_fb against a line-by-line Python restatement of the scatter loops of
+    kroeger/patchgrid.cpp:213-275 (own patches) and :278-375 (complementary grid at its moved positions, bilinear taps,
+    reversed flow) on a small level, with both grids filled by real LK runs"""
+    f0, f1 = synth_pair(96, 160, seed=11)
+    p = O.op_point(2, 160, 1)
+    p.sc_f = p.sc_l = 1
+    a, b = O.pad_frame(f0, 1), O.pad_frame(f1, 1)
+    P0, P1 = O.Pyramid(a, 1, p.ps), O.Pyramid(b, 1, p.ps)
+    w, h = P0.level_wh(1)
+    g, gb = O.Grid(w, h, 1, p), O.Grid(w, h, 1, p)
+    g.init(P0.im[1], P0.dx[1], P0.dy[1]); g.optimize(P1.im[1])
+    gb.init(P1.im[1], P1.dx[1], P1.dy[1]); gb.optimize(P0.im[1])
+    got = np.zeros((h, w, 2), np.float32)
+    O.lib().dis_grid_aggregate_fb(g.ptr, gb.ptr, O.C.byref(p), O.P(got))
+    f = np.float32
+    flow, we = np.zeros((h, w, 2), f), np.zeros((h, w), f)
+    ps, lb, ub = p.ps, -p.ps // 2, p.ps // 2 - 1
+    for ip in range(g.nop):                                           # :223-272
+        fl, pw, ref = g.p_iter[ip], g.pweight[ip].reshape(ps, ps), g.pt_ref[ip]
+        for y in range(lb, ub + 1):
+            for x in range(lb, ub + 1):
+                yt, xt = int(y + ref[1]), int(x + ref[0])
+                if 0 <= xt < w and 0 <= yt < h:
+                    absw = f(1.0) / max(f(2.0), pw[y - lb, x - lb])
+                    we[yt, xt] += absw
+                    flow[yt, xt] += fl * absw
+    for ip in range(gb.nop):                                          # :286-374
+        fl, pw = gb.p_iter[ip], gb.pweight[ip].reshape(ps, ps)
+        rp = gb.pt_ref[ip] + fl
+        pos = (int(np.ceil(float(rp[0]) + .00001)), int(np.ceil(float(rp[1]) + .00001)), int(np.floor(rp[0])), int(np.floor(rp[1])))
+        r0, r1 = rp[0] - f(pos[2]), rp[1] - f(pos[3])
+        wb = (r0 * r1, (f(1) - r0) * r1, r0 * (f(1) - r1), (f(1) - r0) * (f(1) - r1))
+        for y in range(lb, ub + 1):
+            for x in range(lb, ub + 1):
+                yt, xt = y + pos[1], x + pos[0]
+                if xt >= 1 and yt >= 1 and xt < w - 1 and yt < h - 1:
+                    absw = f(1.0) / max(f(2.0), pw[y - lb, x - lb])
+                    fn = fl * absw
+                    for k, (yy, xx) in enumerate(((yt, xt), (yt, xt - 1), (yt - 1, xt), (yt - 1, xt - 1))):
+                        we[yy, xx] += wb[k] * absw
+                        flow[yy, xx] -= wb[k] * fn
+    nz = we > 0
+    flow[nz] /= we[nz][:, None]
+    assert np.array_equal(got, flow)
+    plain = g.aggregate()
+    assert not np.array_equal(got, plain) and np.median(epe(got, plain)) < 0.3
+
+
+def test_forward_backward_merge_recovers_flow():
+    f0, f1, gt = synth_pair(272, 480, seed=5, truth=True)
+    p = O.op_point(2, 480, 1)
+    p.usefbcon = 1
+    fl = O.upsample_crop(O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0), p.sc_l, *O.padded_size(480, 272, p.sc_f)[2:], 480, 272)
+    assert np.median(epe(fl, gt)) < 0.5
+
+
 def test_redblack_is_not_reference(alley):
     a, b = alley["frame_0001"].astype(np.float32), alley["frame_0002"].astype(np.float32)
     e = epe(O.full_flow(a, b, op=2), O.full_flow(a, b, op=2, sor_mode=1))
