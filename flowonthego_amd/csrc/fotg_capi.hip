@@ -597,7 +597,7 @@ static int fused_lds_bytes(const VrArgs &b, bool with_c)
   return 128 + (b.S + 2) * b.RPD * (int)sizeof(float2) + ((b.w * b.h + 3) / 4) * 16 + (with_c ? (b.SC * b.RP + 1) * 32 : 0);
 }
 
-template <int NOC, int K, int P, int BANDED, bool CL = false>
+template <int NOC, int K, int P, int BANDED, bool CL = false, bool RES = false>
 static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s,
                                const float *I0, const float *I1, long img_stride, int tw, int pad)
 {
@@ -605,13 +605,13 @@ static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, floa
   static int max_set = 0;
   const int lds = fused_lds_bytes(b, CL);
   if (lds > max_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
     max_set = lds;
   }
-  vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
+  vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL, RES><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
   return true;
 }
 
@@ -631,8 +631,13 @@ static bool dispatch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, 
   if (b.band_mode == 3) {
     // system cells in LDS as well when they fit (FOTG_VR_CLDS=0: keep them in global memory; tests)
     const char *e = getenv("FOTG_VR_CLDS");
-    if ((!e || atoi(e)) && fused_lds_bytes(a, true) <= 160 * 1024 &&
-        launch_inner_fused<NOC, 1, 8, 3, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
+    if ((!e || atoi(e)) && fused_lds_bytes(a, true) <= 160 * 1024) {
+      // gray levels of <= 4 pixels per thread also keep their per-pixel inputs in registers over the loop
+      if constexpr (NOC == 1) {
+        if (a.w * a.h <= 4 * 512 && launch_inner_fused<1, 1, 8, 3, true, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
+      }
+      if (launch_inner_fused<NOC, 1, 8, 3, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
+    }
     return launch_inner_fused<NOC, 1, 8, 3>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
   }
   if (b.band_mode == 1) return launch_inner_fused<NOC, 1, 8, 1>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);

@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(BANDED == 1 || BANDED == 3 ? 1024 : BANDED == 2 ? 5
 // solver waves of the same workgroup.  Replaces 2*inner + 2 launches (and the LDS copy-in/out of D) per level.
 // CL (barrier-stepped waves only): the system cells C stay in LDS too -- the data phase writes them there and the solver
 // waves read them with ds_read_b128, so nothing but the level's input planes crosses the CU boundary inside the loop.
-template <int NOC, int K, int P, int U, int BANDED, bool CL>
+template <int NOC, int K, int P, int U, int BANDED, bool CL, bool RES = false>
 __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
                                                              float half_gamma_over3, float omega, float *__restrict__ flow, long flow_stride,
                                                              const float *__restrict__ I0, const float *__restrict__ I1, long img_stride, int tw, int pad)
@@ -1041,7 +1041,31 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
   __syncthreads();
   constexpr int B = 4;                                           // pixels per thread whose global loads are in flight together
   const int npx = w * h, nth = blockDim.x;
+  // Gray levels of at most B pixels per thread: everything the loop reads from global memory (mask, derivative planes,
+  // wx / wy with their neighbours) is constant over the inner iterations -> load it once and keep it in registers;
+  // inside the loop only LDS is touched.  (RGB has 35 values per pixel: reloaded every iteration.)
+  // (template flag RES, set by the host when NOC == 1 and npx <= B * 512)
+  constexpr bool resident = RES;
+  PixIn<NOC> rp[RES ? B : 1];
+  if constexpr (resident) {
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+      const int px = threadIdx.x + q * nth < npx ? threadIdx.x + q * nth : npx - 1;
+      rp[q] = data_load<NOC>(a, pair, px % w, px / w);
+    }
+  }
   for (int it = 0; it < inner; ++it) {
+    if constexpr (resident) {
+      // opaque to the optimiser: otherwise every loop-invariant product of compute_data is hoisted and kept live too
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        PixIn<NOC> &r = rp[q];
+#pragma unroll
+        for (int c = 0; c < NOC; ++c)
+          asm volatile("" : "+v"(r.Ix[c]), "+v"(r.Iy[c]), "+v"(r.Iz[c]), "+v"(r.Ixx[c]), "+v"(r.Ixy[c]), "+v"(r.Iyy[c]), "+v"(r.Ixz[c]), "+v"(r.Iyz[c]));
+        asm volatile("" : "+v"(r.m), "+v"(r.wxc), "+v"(r.wxl), "+v"(r.wxr), "+v"(r.wxt), "+v"(r.wxb), "+v"(r.wyc), "+v"(r.wyl), "+v"(r.wyr), "+v"(r.wyt), "+v"(r.wyb));
+      }
+    }
     for (int k0 = threadIdx.x; k0 < npx; k0 += B * nth) {        // compute_smoothness first half (:126-139)
       float gx[B][5], gy[B][5];                                  // wx, wy at centre, left, right, top, bottom (clamped)
       int qi[B], qj[B];
@@ -1050,6 +1074,12 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
         const int px = k0 + q * nth < npx ? k0 + q * nth : npx - 1;
         const int i = px % w, j = px / w;
         qi[q] = i; qj[q] = j;
+        if constexpr (resident) {
+          const PixIn<NOC> &r = rp[q];
+          gx[q][0] = r.wxc; gx[q][1] = r.wxl; gx[q][2] = r.wxr; gx[q][3] = r.wxt; gx[q][4] = r.wxb;
+          gy[q][0] = r.wyc; gy[q][1] = r.wyl; gy[q][2] = r.wyr; gy[q][3] = r.wyt; gy[q][4] = r.wyb;
+          continue;
+        }
         const int jc[5] = {j, j, j, clampi(j - 1, h), clampi(j + 1, h)}, ic[5] = {i, clampi(i - 1, w), clampi(i + 1, w), i, i};
 #pragma unroll
         for (int t = 0; t < 5; ++t) { gx[q][t] = wx[jc[t] * st + ic[t]]; gy[q][t] = wy[jc[t] * st + ic[t]]; }
@@ -1074,7 +1104,7 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
 #pragma unroll
       for (int q = 0; q < B; ++q) {
         const int px = k0 + q * nth < npx ? k0 + q * nth : npx - 1;
-        pin[q] = data_load<NOC>(a, pair, px % w, px / w);
+        if constexpr (resident) pin[q] = rp[q]; else pin[q] = data_load<NOC>(a, pair, px % w, px / w);
       }
 #pragma unroll
       for (int q = 0; q < B; ++q) {
