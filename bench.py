@@ -154,15 +154,19 @@ def cpu_baseline(I0, I1, budget_s=12.0):
         one(n1)
         n1 += 1
     single = n1 / (time.perf_counter() - t0)
-    # all cores: enough pairs for ~budget_s * 0.8 of wall time at the single-thread rate (assumes near-linear scaling)
-    nall = max(cores, int(single * cores * 0.8 * budget_s / 1.5))
-    nall = min(nall, 64 * cores)
-    for k in range(min(nall, nb)):
+    # all cores: a calibration round of one pair per thread, then enough pairs for ~0.6 * budget_s at the measured rate
+    for k in range(min(cores, nb)):
         pair(k)                                                            # device -> host copies outside the timed part
-    t1 = time.perf_counter()
+    tc = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(one, range(cores)))
+        rate = cores / (time.perf_counter() - tc)
+        nall = max(cores, min(int(rate * 0.6 * budget_s), 64 * cores))
+        for k in range(min(nall, nb)):
+            pair(k)
+        t1 = time.perf_counter()
         list(ex.map(one, range(nall)))
-    el = time.perf_counter() - t1
+        el = time.perf_counter() - t1
     return {"value": nall / el, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
             "single_thread": single,
             "sample": "%d of the batch's 1080p pairs (cycled), op-pt 2 + refinement, pyramid included, oracle/libdis_oracle.so "
@@ -178,6 +182,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU per step (BASELINE configs[2]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time the video entry point fotg_calc_sequence (off by default: "
+                    "its half-size pyramid launches would blur the per-kernel averages of a rocprofv3 --stats run of this command)")
     ap.add_argument("--sor-mode", type=int, default=0, help="0 lexicographic (reference order, parity mode), 1 red-black")
     a = ap.parse_args()
 
@@ -249,6 +255,7 @@ def main():
             torch.cuda.synchronize()
             res["u8_frames"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
                                 "note": "same workload with uint8 input frames (exact conversion on load); informational"}
+        if a.extras:
             # video mode (fotg_calc_sequence): batch+1 consecutive frames -> batch flows, every pyramid built once
             seq = torch.cat([I0, I1[-1:]]).contiguous()
             for _ in range(2):

@@ -60,6 +60,9 @@ class OFClass {
   // n pairs, device output, asynchronous on `stream` (hipStream_t)
   void calc_batch(int n, const float *_I0, const float *_I1, const float *initflow, float *outflow_dev, void *stream = nullptr)
   { fotgCheck(fotg_calc_batch(ctx, n, _I0, _I1, initflow, outflow_dev, stream), "OFClass::calc_batch"); }
+  // video: n_frames consecutive frames -> n_frames - 1 flows, every frame's pyramid built once
+  void calc_sequence(int n_frames, const float *frames, const float *initflow, float *outflow_dev, void *stream = nullptr)
+  { fotgCheck(fotg_calc_sequence(ctx, n_frames, frames, initflow, outflow_dev, stream), "OFClass::calc_sequence"); }
 
   fotg_ctx *handle() { return ctx; }
   PatGridClass *GetGrid(int scale) { return grid[scale - op.finest_scale]; }

@@ -326,6 +326,28 @@ def test_forward_backward_merge(case, op_point, alley):
     assert not np.array_equal(out, plain) and np.median(epe(out, plain)) < 0.5
 
 
+def test_random_sizes_sweep():
+    """seeded sweep over frame sizes (odd widths / heights, tall, wide, tiny coarsest levels), channel counts and operating
+    points 1-3: every size takes different padding, grid offsets, band / lane counts and solver paths -- all bit-exact"""
+    F, OFClass, _, O = _mods()
+    rng = np.random.default_rng(2024)
+    cases = [(int(rng.integers(150, 700)), int(rng.integers(120, 420)), int(rng.integers(1, 4)), 1 + 2 * int(rng.integers(0, 2))) for _ in range(10)]
+    cases += [(1280, 720, 2, 1), (333, 800, 2, 1), (900, 130, 2, 3)]
+    for w, h, op_point, noc in cases:
+        f0, f1 = synth_pair(h, w, seed=w + h, noc=noc)
+        op = F.operating_point(op_point, w, noc)
+        try:
+            ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        except F.FotgError:
+            assert min(w, h) >> op.coarsest_scale < 5, (w, h, op_point)      # refused only when the coarsest level is degenerate
+            continue
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        p = oracle_params(O, op)
+        ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+        assert np.array_equal(out, ref), (w, h, op_point, noc, float(np.abs(out - ref).max()))
+        ofc.close()
+
+
 def test_sequence_mode(alley):
     """video front end: n+1 consecutive frames -> n flows with every pyramid built once; each flow
     equals the oracle on its pair (float and 8-bit frames, gray and RGB, full max_batch)"""
