@@ -571,6 +571,33 @@ static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hip
   return true;
 }
 
+// streaming solver (vr_sor_stream_kernel): diagonals travel through LDS rings.  Instantiated for 64..69 rows (1080p level 4).
+// FOTG_VR_STREAM=1 selects it (tests).
+static bool launch_sor_stream(const VrArgs &b, int n, float omega, hipStream_t s)
+{
+  constexpr int RD = 70, RCW = 70, M = FOTG_SYNC_M, U = 32;
+  using GEO = StreamGeom<RD, RCW>;
+  const char *e = getenv("FOTG_VR_STREAM");                      // opt-in: measured equal to the resident kernel at 1080p (see the kernel's header)
+  if (!e || !atoi(e)) return false;
+  const int NB = b.nbands > 0 ? b.nbands : 1;
+  if (b.RP < 64 || b.RP + 1 > RCW || b.RPD > RD || (b.RPD & 1) || b.nsweeps * NB + 3 > 10 || b.S < 2 * U) return false;
+  const int DS = NB > 1 ? ((2 * M + 2 + M - 1) / M) * M : ((M + 2 + M - 1) / M) * M;
+  const int omax = b.nsweeps > 0 ? (b.nsweeps - 1) * DS + (NB - 1) * M : 0;
+  const int RDN = M * (GEO::LI + omax / M + 1 + 1), RCN = RDN - M;
+  const int lds = RCN * GEO::CSLOT + RDN * GEO::DB + GEO::DB;
+  if (lds > 160 * 1024) return false;
+  static int max_set = 0;
+  if (lds > max_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_sor_stream_kernel<RD, RCW, M, U>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    max_set = lds;
+  }
+  vr_sor_stream_kernel<RD, RCW, M, U><<<n, 640, lds, s>>>(b, omega);
+  return true;
+}
+
 // sweep-pipelined LDS solver when it applies: <= 4 sweeps (one wave each), (du,dv) of the level fit in LDS
 static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
@@ -582,7 +609,10 @@ static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, h
   set_bands(b, sweeps, 16);
   if (b.band_mode == 1) return launch_sor_pipe<1, 8, 1>(a, n, sweeps, omega, s, b, sweeps * b.nbands * 64);
   if (b.band_mode == 2) return launch_sor_pipe<1, 8, 2>(a, n, sweeps, omega, s, b, (sweeps * b.nbands < 4 ? 4 : sweeps * b.nbands) * 64);
-  if (b.band_mode == 3) return launch_sor_pipe<1, 8, 3>(a, n, sweeps, omega, s, b, 1024);     // all 16 waves copy D in and out
+  if (b.band_mode == 3) {
+    if (launch_sor_stream(b, n, omega, s)) return true;
+    return launch_sor_pipe<1, 8, 3>(a, n, sweeps, omega, s, b, 1024);     // all 16 waves copy D in and out
+  }
   switch (a.K) {
     case 1: return launch_sor_pipe<1, 8, 0>(a, n, sweeps, omega, s, b, 256);
     case 2: return launch_sor_pipe<2, 8, 0>(a, n, sweeps, omega, s, b, 256);

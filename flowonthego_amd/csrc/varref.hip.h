@@ -1012,6 +1012,190 @@ __global__ __launch_bounds__(BANDED == 1 || BANDED == 3 ? 1024 : BANDED == 2 ? 5
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Streaming launch of one sor_coupled call for levels whose (du,dv) AND system do not fit LDS together (1080p level 4):
+// the anti-diagonals travel through two LDS rings, one slot per diagonal: the D ring (RD cells of 8 B per slot) and the C
+// ring (two planes of RCW 16-byte cells per slot).  Besides the barrier-stepped solver waves (sor_sync_wave's schedule,
+// M steps per barrier) the workgroup has
+//   * two LOADER waves (A: D row + plane 0 of C, B: plane 1 of C): in barrier interval I they issue the direct-to-LDS
+//     loads (global_load_lds_dwordx4, no VGPRs) of the M diagonals of chunk I + LI and, before the next barrier, wait
+//     (counted vmcnt) until only the G-1 newest chunks are in flight, so chunk c is visible to everybody from interval
+//     c - LI + G on.  The first solver wave reads diagonal s+2 <= M*I + M + 1 in interval I  ->  LI = G + 1.  G-1 = 4
+//     chunks in flight cover the ~1.2 us the data kernel's output takes to arrive from another XCD's L2 / the MALL.
+//   * a WRITER wave: in interval J it copies the D rows of chunk J - WO back to global memory, WO = omax/M + 1 (the last
+//     sweep relaxed them in interval J - 1 at the latest, and its stores landed before barrier J).
+// A D slot therefore lives LI + WO + 1 intervals and a C slot LI + omax/M + 1: 60 + 56 slots = 160 KB for 120x68 with
+// 3 sweeps x 2 bands.  Compared with vr_sor_pipe_kernel this removes the D copy-in / copy-out phases (they overlap the
+// solve) and the two global loads per solver wave and step (the system now comes out of LDS), and the LDS footprint no
+// longer grows with the level's width.
+// MEASURED (MI355X, 64 x 1080p level 4): 41.8 us per call against 41.6 us for the resident kernel -- the loaders keep up
+// (9 us per call with the solver waves switched off), but a solver step costs the same whether its 32 bytes of system come
+// through the LDS port or the texture-address path; six lock-stepped in-order solver waves on four SIMDs are the limit
+// either way.  So this kernel is opt-in (FOTG_VR_STREAM=1) and kept for levels too wide for a resident D.
+// ------------------------------------------------------------------------------------------------------------------
+template <int RD, int RCW>
+struct StreamGeom {
+  static constexpr int DB = RD * 8, CB = RCW * 16, CSLOT = 2 * CB;         // bytes
+  static constexpr int G = 5, LI = G + 1;                                  // chunks in flight + 1, load lead (intervals)
+};
+
+__device__ __forceinline__ char *lds_bytes() { return reinterpret_cast<char *>(fotg_lds64); }
+
+// one 16-byte-per-lane direct load: lane L's 16 bytes at `src` land at lds_dst + 16 L (lds_dst wave-uniform)
+__device__ __forceinline__ void glds16(const void *src, unsigned lds_dst_byte)
+{
+  typedef __attribute__((address_space(1))) const void gvoid;
+  typedef __attribute__((address_space(3))) void lvoid;
+  __builtin_amdgcn_global_load_lds((gvoid *)src, (lvoid *)(lds_bytes() + lds_dst_byte), 16, 0, 0);
+}
+
+template <int RD, int RCW, int M, int U>
+__global__ __launch_bounds__(640) void vr_sor_stream_kernel(VrArgs a, float omega)
+{
+  using GEO = StreamGeom<RD, RCW>;
+  constexpr int DB = GEO::DB, CB = GEO::CB, CSLOT = GEO::CSLOT, G = GEO::G, LI = GEO::LI;
+  constexpr int UT = 8;
+  static_assert(U % M == 0 && UT % M == 0, "barrier phase is a compile-time property of the unrolled step");
+  static_assert(RCW > 64 && RCW <= 128, "two direct loads per C plane and diagonal");
+  const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int NB = a.nbands > 0 ? a.nbands : 1;
+  constexpr int DBS = M, DS1 = ((M + 2 + M - 1) / M) * M, DSB = ((2 * M + 2 + M - 1) / M) * M;
+  const int DS = NB > 1 ? DSB : DS1;
+  const int S = a.S, RP = a.RP, RPD = a.RPD;
+  int E = 0;
+  while (E + U <= S) E += U;
+  while (E < S) E += UT;
+  const int omax = a.nsweeps > 0 ? (a.nsweeps - 1) * DS + (NB - 1) * DBS : 0;
+  const int WO = omax / M + 1;
+  const int RDN = M * (LI + WO + 1), RCN = RDN - M;               // ring slots
+  const int NI = (E + omax) / M + 1;                              // barrier intervals every wave goes through
+  const int nsolver = a.nsweeps * NB;
+  const unsigned CRING = (unsigned)RCN * CSLOT, DRING = (unsigned)RDN * DB;     // bytes
+  const unsigned DBASE = CRING, DUMP = CRING + DRING;             // C ring | D ring | one spare D row for the no-op tail steps
+  char *Dg = reinterpret_cast<char *>(a.Dp(pair));
+  const char *Cg = reinterpret_cast<const char *>(a.Cp(pair));
+  auto ld_f2 = [&](unsigned off) { return *reinterpret_cast<const float2 *>(lds_bytes() + off); };
+  auto st_f2 = [&](unsigned off, float2 v) { *reinterpret_cast<float2 *>(lds_bytes() + off) = v; };
+  auto ld_f4 = [&](unsigned off) { return *reinterpret_cast<const float4 *>(lds_bytes() + off); };
+
+  // direct loads of the next M diagonals (diagonals past S re-read the all-zero diagonal S); running diagonal / slot offsets.
+  // Loader A: D row + C plane 0 (3 loads per diagonal), loader B: C plane 1 (2 loads).
+  int ld = 0;
+  unsigned ldslot = 0, lcslot = 0;
+  auto issue_chunk = [&](auto which) {
+    constexpr bool A = decltype(which)::value;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const int ds = ld < S ? ld : S;
+      const char *crow = Cg + ((size_t)ds * RP) * 32 + (A ? 0 : 16);
+      const unsigned cdst = lcslot + (A ? 0 : CB);
+      if (A) { if (lane < RPD / 2) glds16(Dg + ((size_t)ds * RPD) * 8 + lane * 16, DBASE + ldslot); }
+      if (lane <= RP) glds16(crow + lane * 32, cdst);             // rows 0 .. RP (row RP = what the idle lanes read; finite)
+      if (lane + 64 <= RP) glds16(crow + (lane + 64) * 32, cdst + 1024);
+      ++ld;
+      ldslot += DB; if (ldslot == DRING) ldslot = 0;
+      lcslot += CSLOT; if (lcslot == CRING) lcslot = 0;
+    }
+  };
+  constexpr int NGA = M * 3, NGB = M * 2;                         // direct loads per chunk
+  static_assert(NGA * (G - 1) <= 63, "vmcnt is a 6-bit counter");
+
+  if (wv == nsolver) { for (int c = 0; c < LI; ++c) issue_chunk(std::true_type{}); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  if (wv == nsolver + 1) { for (int c = 0; c < LI; ++c) issue_chunk(std::false_type{}); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  if (threadIdx.x < RD) st_f2(DUMP + threadIdx.x * 8, make_float2(0.f, 0.f));
+  __syncthreads();
+
+  if (wv == nsolver) {                                            // ---------------- loader A ----------------
+    for (int I = 0; I < NI; ++I) {
+      asm volatile("s_barrier" ::: "memory");
+      issue_chunk(std::true_type{});
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NGA * (G - 1)) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may land after the workgroup's LDS is released
+    return;
+  }
+  if (wv == nsolver + 1) {                                        // ---------------- loader B ----------------
+    for (int I = 0; I < NI; ++I) {
+      asm volatile("s_barrier" ::: "memory");
+      issue_chunk(std::false_type{});
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NGB * (G - 1)) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  if (wv == nsolver + 2) {                                        // ---------------- writer ----------------
+    int wd = 0;
+    unsigned wslot = 0;
+    for (int I = 0; I < NI; ++I) {
+      asm volatile("s_barrier" ::: "memory");
+      if (I >= WO) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          if (wd < S && lane < RPD / 2) *reinterpret_cast<float4 *>(Dg + ((size_t)wd * RPD) * 8 + lane * 16) = ld_f4(DBASE + wslot + lane * 16);
+          ++wd; wslot += DB; if (wslot == DRING) wslot = 0;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+  if (wv > nsolver + 2) {                                         // spare waves only count barriers
+    for (int I = 0; I < NI; ++I) asm volatile("s_barrier" ::: "memory");
+    return;
+  }
+
+  // ---------------- solver wave (sweep n, band b): sor_sync_wave's schedule on the rings ----------------
+  const int n = wv / NB, b = wv % NB, off = n * DS + b * DBS;
+  const int rb = b * a.band_rows, nrows = NB > 1 ? (rb + a.band_rows <= a.h ? a.band_rows : a.h - rb) : a.h;
+  const bool first_row = lane == 0;
+  const bool act = lane < nrows;
+  const int r = act ? rb + lane : RP;                             // idle lanes park on the padding row with omega = 0
+  const float om_lane = act ? omega : 0.f;
+  const unsigned vD = DBASE + (unsigned)r * 8;
+  const unsigned vC = (unsigned)r * 16;                           // (the second load's rows 64.. follow the first's at +1024)
+  const unsigned vT = DBASE + (unsigned)(b > 0 ? rb - 1 : RP + 1) * 8;               // row above the band [band 0: a zero padding cell]
+  for (int t = 0; t < off / M; ++t) asm volatile("s_barrier" ::: "memory");
+  unsigned d0 = 0, d1 = DB, d2 = 2 * DB, c1o = CSLOT;              // D slots of diagonals s, s+1, s+2; C slot of diagonal s+1
+  float2 own = ld_f2(d0 + vD), nxr = ld_f2(d1 + vD), nxb = ld_f2(d1 + vD + 8);
+  float4 c0 = ld_f4(vC), c1 = ld_f4(vC + CB);
+  float2 tpl = make_float2(0.f, 0.f), prev = make_float2(0.f, 0.f);
+  float hl = 0.f;
+  auto step = [&](auto tail_tag, int u, int s) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const float om = (!TAIL || s < S) ? om_lane : 0.f;
+    float dx = dpp_wave_shr1(prev.x), dy = dpp_wave_shr1(prev.y);
+    asm volatile("" : "+v"(dx), "+v"(dy));
+    const float2 top = first_row ? tpl : make_float2(dx, dy);
+    const float a11 = c0.x, a12 = c0.y, a22 = c0.z, b1 = c0.w, b2 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
+    float s1 = hr * nxr.x, s2 = hr * nxr.y;
+    s1 = s1 + vt * top.x;  s2 = s2 + vt * top.y;
+    s1 = s1 + vb * nxb.x;  s2 = s2 + vb * nxb.y;
+    if (u % M == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(s1), "+v"(s2) :: "memory");
+    const float2 nr = ld_f2(d2 + vD), nb = ld_f2(d2 + vD + 8);   // diagonal s+2: right / bottom of step s+1
+    const float2 tp = ld_f2(d0 + vT);                            // (diagonal s, row above the band): top of step s+1
+    const float4 n0 = ld_f4(c1o + vC), n1 = ld_f4(c1o + vC + CB); // system cells of diagonal s+1
+    s1 = s1 + b1;          s2 = s2 + b2;
+    const float B1 = hl * prev.x + s1, B2 = hl * prev.y + s2;
+    float2 res;
+    res.x = own.x + om * (a11 * B1 + a12 * B2 - own.x);
+    res.y = own.y + om * (a12 * B1 + a22 * B2 - own.y);
+    st_f2((!TAIL || s < S) ? d0 + vD : DUMP + (unsigned)r * 8, res);
+    prev = res; hl = hr; own = nxr; nxr = nr; nxb = nb; tpl = tp; c0 = n0; c1 = n1;
+    d0 = d1; d1 = d2; d2 += DB; if (d2 == DRING) d2 = 0;
+    c1o += CSLOT; if (c1o == CRING) c1o = 0;
+  };
+  int t0 = 0;
+  for (; t0 + U <= S; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(std::false_type{}, u, t0 + u);
+  }
+  for (; t0 < S; t0 += UT) {
+#pragma unroll
+    for (int u = 0; u < UT; ++u) step(std::true_type{}, u, t0 + u);
+  }
+  for (int t = off / M; t < omax / M + 1; ++t) asm volatile("s_barrier" ::: "memory");
+}
+
 // The whole fixed-point loop of one level in ONE launch, one workgroup per pair (refine_variational.cpp:182-221):
 //   repeat inner times { smoothness, data term + sub_laplacian + block inverse -> system C ; sor_coupled } ; flow = w + d.
 // (du,dv) never leave LDS; the smoothness weights live in an LDS plane; C goes through global memory (L2) to the

@@ -193,6 +193,22 @@ def test_solver_fallback_paths(path, bands, alley, monkeypatch):
         assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (path, case)
 
 
+def test_streaming_solver_kernel(monkeypatch):
+    """FOTG_VR_STREAM=1: the 64..69-row level is solved by vr_sor_stream_kernel ((du,dv) and the system travel through LDS
+    rings filled by direct-to-LDS loads, results written back by a writer wave while the solve runs): same bits, on a
+    1080p pair (68-row finest level, 2 row bands) and on a 66-row level with a different width"""
+    F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_STREAM", "1")
+    for w, h in ((1920, 1080), (1280, 1050)):
+        f0, f1 = synth_pair(h, w, seed=9)
+        op = F.operating_point(2, 1920, 1)                   # scales 6-5-4 for both sizes
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+        out = ofc.calc_batch(dev(np.stack([f0, f1])), dev(np.stack([f1, f0]))).cpu().numpy()
+        p = oracle_params(O, op)
+        a, b = O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f)
+        assert np.array_equal(out[0], O.flow(a, b, p, 0)) and np.array_equal(out[1], O.flow(b, a, p, 0)), (w, h)
+
+
 def test_fused_level_system_in_global_memory(alley, monkeypatch):
     """the on-chip levels keep the linear system in LDS when it fits; FOTG_VR_CLDS=0 forces the variant that streams it
     through global memory (what larger levels use): same bits"""
