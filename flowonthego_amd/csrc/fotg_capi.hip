@@ -764,7 +764,7 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
   if (!name || !host_out || !c->vr || pair < 0 || pair >= c->max_batch) return FOTG_ERR_ARG;
   static const char *singles[] = {"wx", "wy", "mask"};
   static const char *colors[] = {"avg", "Iz", "Ix", "Iy", "Ixx", "Ixy", "Iyy", "Ixz", "Iyz"};
-  static const char *sys[] = {"a11", "a12", "a22", "b1", "b2", "sh", "sv", "svt"};
+  static const char *sys[] = {"a11", "a12", "b1", "b2", "a22", "sh", "sv", "svt"};      // cell layout of data_term_cell()
   const LevelGeom &g = c->geom[l];
   const VrArgs &a = c->vra[l];
   const size_t pl = (size_t)g.st * g.h;

@@ -24,7 +24,8 @@ enum VrPlane { P_WX = 0, P_WY, P_MASK, P_NSINGLE };
 enum VrCPlane { C_AVG = 0, C_IZ, C_IX, C_IY, C_IXX, C_IXY, C_IYY, C_IXZ, C_IYZ, C_NCOLOR };
 
 // Skewed (anti-diagonal major) arrays used by the solver: cell (i,j) of the image lives at [i+j][j].
-//   C[s][r] = {a11,a12,a22 (2x2 block inverse), b1, b2, psi_right, psi_bottom, psi_top}   8 floats
+//   C[s][r] = {a11, a12 (2x2 block inverse), b1, b2 | a22, psi_right, psi_bottom, psi_top}   8 floats
+//             (pairs the solver multiplies as packed f32 sit in even-aligned register pairs)
 //   D[s][r] = {du, dv}                                                                     2 floats
 // Row s holds exactly the pixels the lexicographic sweep may process together (step s of the wavefront),
 // contiguous in the row index r, so one wave reads/writes a step with fully coalesced 16-B / 8-B accesses.
@@ -283,8 +284,8 @@ __device__ __forceinline__ void data_term_cell(const VrArgs &a, int i, int j, co
   if (j < h - 1) dps = dps + vb;
   const float M11 = A22 + dps, M22 = A11 + dps;
   const float det = M11 * M22 - A12 * A12;
-  c0 = make_float4(M11 / det, A12 / -det, M22 / det, B1);
-  c1 = make_float4(B2, hr, vb, vt);
+  c0 = make_float4(M11 / det, A12 / -det, B1, B2);             // cell layout: (a11', a12', b1, b2 | a22', psi_r, psi_b, psi_t)
+  c1 = make_float4(M22 / det, hr, vb, vt);
 }
 
 template <int NOC>
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_al
 // the neighbour values finite, so the skipped terms add +-0 and the sums are the same floats.
 __device__ __forceinline__ float2 sor_update(float2 cur, float4 c0, float4 c1, float hl, float2 left, float2 top, float2 right, float2 bottom, float omega)
 {
-  const float a11 = c0.x, a12 = c0.y, a22 = c0.z, b1 = c0.w, b2 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
+  const float a11 = c0.x, a12 = c0.y, b1 = c0.z, b2 = c0.w, a22 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
   float s1 = hr * right.x, s2 = hr * right.y;
   s1 = s1 + vt * top.x;    s2 = s2 + vt * top.y;
   s1 = s1 + vb * bottom.x; s2 = s2 + vb * bottom.y;
@@ -658,7 +659,7 @@ __device__ __forceinline__ void sor_band_wave(const VrArgs &a, int pair, float o
   auto load_c = [&](Stage &st, const char *ptr) {
     const vf4 *cp = reinterpret_cast<const vf4 *>(ptr);
     const vf4 x = NT ? __builtin_nontemporal_load(cp) : cp[0], y = NT ? __builtin_nontemporal_load(cp + 1) : cp[1];
-    st.a_self = isv ? x.z : x.x; st.a12 = x.y; st.bb = isv ? y.x : x.w; st.hr = y.y; st.vb = y.z; st.vt = y.w;
+    st.a_self = isv ? y.x : x.x; st.a12 = x.y; st.bb = isv ? x.w : x.z; st.hr = y.y; st.vb = y.z; st.vt = y.w;
   };
   constexpr int CHK = 4;
   const int rpd2 = 2 * RPD;
@@ -868,7 +869,10 @@ __device__ __forceinline__ void sor_rows_wave(const VrArgs &a, int pair, float o
 // Waves that do not solve (copy helpers, the other waves of the fused kernel) only count barriers.
 // CL: the system cells come from an LDS copy `lc` of the pair's skewed C (the fused kernel's data phase writes it there)
 // instead of the register-ring prefetch from global memory.
-template <int P, int U, bool NT, int M, bool CL = false>
+// PK: the (du,dv) pair as packed f32 (v_pk_mul_f32 / v_pk_add_f32 round each half like the scalar op): 15 instead of 28
+// arithmetic instructions per step.  Measured: a win when every solver wave has a SIMD to itself (fused levels, 3 waves:
+// -13 %), a loss when two solver waves share a SIMD (level 4, 6 waves: +8 %; the packed ops occupy the SIMD twice as long).
+template <int P, int U, bool NT, int M, bool CL = false, bool PK = false>
 __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float omega, int wv, int lane, const float4 *lc = nullptr)
 {
   constexpr int UT = P;                                          // unroll of the tail loop
@@ -929,10 +933,20 @@ __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float o
     asm volatile("" : "+v"(dx), "+v"(dy));
     const float2 top = first_row ? tpl : make_float2(dx, dy);
     // sor_update()'s expression order
-    const float a11 = st.c0.x, a12 = st.c0.y, a22 = st.c0.z, b1 = st.c0.w, b2 = st.c1.x, hr = st.c1.y, vb = st.c1.z, vt = st.c1.w;
-    float s1 = hr * nxr.x, s2 = hr * nxr.y;
-    s1 = s1 + vt * top.x;  s2 = s2 + vt * top.y;
-    s1 = s1 + vb * nxb.x;  s2 = s2 + vb * nxb.y;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const float a11 = st.c0.x, a12 = st.c0.y, b1 = st.c0.z, b2 = st.c0.w, a22 = st.c1.x, hr = st.c1.y, vb = st.c1.z, vt = st.c1.w;
+    float s1, s2;
+    if constexpr (PK) {
+      const v2f vnxr = {nxr.x, nxr.y}, vnxb = {nxb.x, nxb.y}, vtop = {top.x, top.y};
+      v2f sv = hr * vnxr;
+      sv = sv + vt * vtop;
+      sv = sv + vb * vnxb;
+      s1 = sv.x; s2 = sv.y;
+    } else {
+      s1 = hr * nxr.x;       s2 = hr * nxr.y;
+      s1 = s1 + vt * top.x;  s2 = s2 + vt * top.y;
+      s1 = s1 + vb * nxb.x;  s2 = s2 + vb * nxb.y;
+    }
     if (u % M == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(s1), "+v"(s2) :: "memory");   // tied to (s1,s2): placed here
     float2 nr, nb, tp;
     if (!TAIL) {
@@ -947,11 +961,23 @@ __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float o
       if (!TAIL || s + 1 <= S) lc += RP;
       cnx.c0 = lc[0]; cnx.c1 = lc[lc_pl];
     }
-    s1 = s1 + b1;          s2 = s2 + b2;
-    const float B1 = hl * prev.x + s1, B2 = hl * prev.y + s2;
     float2 res;
-    res.x = own.x + om * (a11 * B1 + a12 * B2 - own.x);
-    res.y = own.y + om * (a12 * B1 + a22 * B2 - own.y);
+    if constexpr (PK) {
+      const v2f a1 = {a11, a12}, bb = {b1, b2}, vprev = {prev.x, prev.y}, vown = {own.x, own.y};
+      v2f sv = {s1, s2};
+      sv = sv + bb;
+      const v2f B = hl * vprev + sv;                             // (B1, B2)
+      const v2f pa = a1 * B;                                     // (a11 B1, a12 B2)
+      v2f t = {pa.x + pa.y, a12 * B.x + a22 * B.y};
+      t = t - vown;
+      const v2f rs = vown + om * t;
+      res = make_float2(rs.x, rs.y);
+    } else {
+      s1 = s1 + b1;          s2 = s2 + b2;
+      const float B1 = hl * prev.x + s1, B2 = hl * prev.y + s2;
+      res.x = own.x + om * (a11 * B1 + a12 * B2 - own.x);
+      res.y = own.y + om * (a12 * B1 + a22 * B2 - own.y);
+    }
     lds_d_st((!TAIL || s < S) ? lrow : (S + 1) * RPD + r, res);
     prev = res; hl = hr; own = nxr; nxr = nr; nxb = nb; tpl = tp;
     if constexpr (!CL) {
@@ -1166,7 +1192,7 @@ __global__ __launch_bounds__(640) void vr_sor_stream_kernel(VrArgs a, float omeg
     float dx = dpp_wave_shr1(prev.x), dy = dpp_wave_shr1(prev.y);
     asm volatile("" : "+v"(dx), "+v"(dy));
     const float2 top = first_row ? tpl : make_float2(dx, dy);
-    const float a11 = c0.x, a12 = c0.y, a22 = c0.z, b1 = c0.w, b2 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
+    const float a11 = c0.x, a12 = c0.y, b1 = c0.z, b2 = c0.w, a22 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
     float s1 = hr * nxr.x, s2 = hr * nxr.y;
     s1 = s1 + vt * top.x;  s2 = s2 + vt * top.y;
     s1 = s1 + vb * nxb.x;  s2 = s2 + vb * nxb.y;
@@ -1313,7 +1339,7 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
     }
     sor_pipe_reset_progress();
     __syncthreads();                                             // also drains the C stores (vmcnt(0)) before the solver reads them
-    if constexpr (BANDED == 3) sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M, CL>(a, pair, omega, wv, lane, lc);
+    if constexpr (BANDED == 3) sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M, CL, true>(a, pair, omega, wv, lane, lc);
     else if constexpr (BANDED) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
     else { if (wv < a.nsweeps) sor_pipe_wave<K, P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
     __syncthreads();
