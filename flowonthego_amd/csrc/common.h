@@ -33,6 +33,22 @@ __host__ __device__ inline int reflect101(int i, int n) { return i < 0 ? -i : (i
 //   xor 8    : row_mirror                 xor 16: row_bcast:15 into rows 1,3   xor 32: row_bcast:31 into rows 2,3
 // After the last step lane 63 holds ((r3+r2)+(r1+r0)) == the tree's value; it is returned wave-uniform (SGPR).
 // All six steps are VALU DPP operations -- no LDS round trips on the LK loop's critical path.
+// XCD-aware placement for grids of (work items, images): workgroups are dealt round-robin to the 8 XCDs by linear id
+// (x fastest), and a one-workgroup-per-image kernel (grid = images) puts image p on XCD p % 8.  Re-deal the (x, y)
+// workgroups so that everything of image p runs on XCD p % 8: each stage then finds what the previous one wrote in the L2
+// of its own XCD (L2 is per XCD; a miss goes to the Infinity Cache).  Needs gridDim.y % 8 == 0, otherwise plain order.
+struct WgId { int x, y; };
+__device__ __forceinline__ WgId xcd_local_wg()
+{
+  WgId id = {(int)blockIdx.x, (int)blockIdx.y};
+  if ((gridDim.y & 7) == 0) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, q = lin >> 3;
+    id.y = (q / (int)gridDim.x) * 8 + xcd;
+    id.x = q % (int)gridDim.x;
+  }
+  return id;
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #define FOTG_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rmask, 0xF, false))

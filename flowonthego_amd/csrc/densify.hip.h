@@ -69,9 +69,10 @@ template <int PS, int NOC>
 __global__ __launch_bounds__(256) void densify_kernel(const float *__restrict__ p_iter, const float *__restrict__ pweight,
                                                       float *__restrict__ flowout, long flow_stride, LevelGeom g)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const WgId wg = xcd_local_wg();
+  const int idx = wg.x * blockDim.x + threadIdx.x;
   if (idx >= g.w * g.h) return;
-  const int pair = blockIdx.y;
+  const int pair = wg.y;
   float we = 0.f, f0 = 0.f, f1 = 0.f;
   gather_own<PS, NOC>(p_iter, pweight, pair, idx % g.w, idx / g.w, g, we, f0, f1);
   if (we > 0) { f0 /= we; f1 /= we; }
@@ -95,9 +96,10 @@ __global__ __launch_bounds__(256) void densify_fb_kernel(const float *__restrict
   constexpr int LB = -PS / 2, UB = PS / 2 - 1;
   __shared__ int list[256];
   __shared__ int wave_cnt[4];
-  const int pair = blockIdx.y;
+  const WgId wg = xcd_local_wg();
+  const int pair = wg.y;
   const int tiles_x = (g.w + 15) >> 4;
-  const int tx0 = (blockIdx.x % tiles_x) << 4, ty0 = (blockIdx.x / tiles_x) << 4;
+  const int tx0 = (wg.x % tiles_x) << 4, ty0 = (wg.x / tiles_x) << 4;
   const int xt = tx0 + (threadIdx.x & 15), yt = ty0 + (threadIdx.x >> 4);
   const bool live = xt < g.w && yt < g.h;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

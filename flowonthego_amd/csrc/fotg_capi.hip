@@ -571,11 +571,12 @@ static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hip
   return true;
 }
 
+static long g_stream_launches = 0;      // fotg_debug_counter("sor_stream"): tests assert the opt-in kernel really ran
 // streaming solver (vr_sor_stream_kernel): diagonals travel through LDS rings.  Instantiated for 64..69 rows (1080p level 4).
 // FOTG_VR_STREAM=1 selects it (tests).
 static bool launch_sor_stream(const VrArgs &b, int n, float omega, hipStream_t s)
 {
-  constexpr int RD = 70, RCW = 70, M = FOTG_SYNC_M, U = 32;
+  constexpr int RD = 72, RCW = 70, M = FOTG_SYNC_M, U = 32;
   using GEO = StreamGeom<RD, RCW>;
   const char *e = getenv("FOTG_VR_STREAM");                      // opt-in: measured equal to the resident kernel at 1080p (see the kernel's header)
   if (!e || !atoi(e)) return false;
@@ -595,6 +596,7 @@ static bool launch_sor_stream(const VrArgs &b, int n, float omega, hipStream_t s
     max_set = lds;
   }
   vr_sor_stream_kernel<RD, RCW, M, U><<<n, 640, lds, s>>>(b, omega);
+  ++g_stream_launches;
   return true;
 }
 
@@ -993,6 +995,12 @@ int fotg_calc_sequence_u8(fotg_ctx *c, int n_frames, const unsigned char *frames
   if (!c || !frames || !outflow) return FOTG_ERR_ARG;
   if (n_frames < 2 || n_frames - 1 > c->max_batch) return FOTG_ERR_BATCH;
   return calc_range<unsigned char>(c, n_frames - 1, frames, nullptr, initflow, outflow, (hipStream_t)stream);
+}
+
+long fotg_debug_counter(const char *name)
+{
+  if (name && !strcmp(name, "sor_stream")) return g_stream_launches;
+  return -1;
 }
 
 int fotg_calc(fotg_ctx *c, const float *I0, const float *I1, const float *initflow, float *outflow_host)

@@ -57,9 +57,10 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
   __shared__ float win_all[4][NP][WIN * WIN * NOC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gid = lane / G;
-  const int ipw = (blockIdx.x * 4 + wave) * NP;      // first patch of this wave
+  const WgId wg = xcd_local_wg();                    // all patches of a pair on the XCD of its refinement workgroup
+  const int ipw = (wg.x * 4 + wave) * NP;            // first patch of this wave
   if (ipw >= a.g.nop) return;                        // wave-uniform
-  const int pair = blockIdx.y;
+  const int pair = wg.y;
   const int tw = a.g.tw;
   const float *I0 = a.I0 + (size_t)pair * a.img_stride;
   const float *I0x = a.I0x + (size_t)pair * a.img_stride;

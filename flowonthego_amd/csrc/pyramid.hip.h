@@ -27,11 +27,12 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int strips = (Wp + 255) >> 8;
-  const int tile = blockIdx.x * 4 + wave;
+  const WgId wg = xcd_local_wg();            // image k (pair k % n) on XCD k % 8, where pyr_finish and the per-pair kernels run
+  const int tile = wg.x * 4 + wave;
   const int oh = Hp >> LV;
   if (tile >= strips * oh) return;
   const int strip = tile % strips, oy = tile / strips;
-  const int which = blockIdx.y >= n_per_src, img = blockIdx.y - (which ? n_per_src : 0);   // I0 batch first, then I1 batch
+  const int which = wg.y >= n_per_src, img = wg.y - (which ? n_per_src : 0);   // I0 batch first, then I1 batch
   const T *src = (which ? frames1 : frames0) + (size_t)img * frame_stride;
   float *dst = which ? dst1 : dst0;
   const int x0 = strip * 256 + lane * 4;     // first of this lane's 4 source pixels (padded coords)

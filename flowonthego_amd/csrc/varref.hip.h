@@ -132,25 +132,28 @@ __global__ __launch_bounds__(256) void vr_prep_kernel(VrArgs a, const float *__r
                                                       long img_stride, int tw, int pad,
                                                       const float *__restrict__ flow, long flow_stride)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const WgId wg = xcd_local_wg();
+  const int idx = wg.x * blockDim.x + threadIdx.x;
   if (idx >= a.w * a.h) return;
-  prep_pixel<NOC>(a, blockIdx.y, idx % a.w, idx / a.w, I0, I1, img_stride, tw, pad, flow, flow_stride);
+  prep_pixel<NOC>(a, wg.y, idx % a.w, idx / a.w, I0, I1, img_stride, tw, pad, flow, flow_stride);
 }
 
 template <int NOC>
 __global__ __launch_bounds__(256) void vr_deriv1_kernel(VrArgs a)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const WgId wg = xcd_local_wg();
+  const int idx = wg.x * blockDim.x + threadIdx.x;
   if (idx >= a.w * a.h) return;
-  deriv1_pixel<NOC>(a, blockIdx.y, idx % a.w, idx / a.w);
+  deriv1_pixel<NOC>(a, wg.y, idx % a.w, idx / a.w);
 }
 
 template <int NOC>
 __global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const WgId wg = xcd_local_wg();
+  const int idx = wg.x * blockDim.x + threadIdx.x;
   if (idx >= a.w * a.h) return;
-  deriv2_pixel<NOC>(a, blockIdx.y, idx % a.w, idx / a.w);
+  deriv2_pixel<NOC>(a, wg.y, idx % a.w, idx / a.w);
 }
 
 // smoothness weight from the 3x3 cross of (uu,vv): compute_smoothness first half (opticalflow_aux.c:126-139);
@@ -318,9 +321,11 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_al
   constexpr int UW = FOTG_TW + 4, UH = FOTG_TH + 4, SW = FOTG_TW + 2, SH = FOTG_TH + 2;
   __shared__ float2 uv[UW * UH];
   __shared__ float sm[SW * SH];
-  const int pair = blockIdx.y, st = a.st, w = a.w, h = a.h;
+  const int st = a.st, w = a.w, h = a.h;
   const int tiles_x = (w + FOTG_TW - 1) / FOTG_TW;
-  const int x0 = (blockIdx.x % tiles_x) * FOTG_TW, y0 = (blockIdx.x / tiles_x) * FOTG_TH;
+  const WgId wg = xcd_local_wg();                                // all tiles of a pair on the XCD its solver workgroup runs on
+  const int pair = wg.y, tile = wg.x;
+  const int x0 = (tile % tiles_x) * FOTG_TW, y0 = (tile / tiles_x) * FOTG_TH;
   const int lx = threadIdx.x % FOTG_TW, ly = threadIdx.x / FOTG_TW;
   const int i = x0 + lx, j = y0 + ly, o = j * st + i;
   const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
@@ -1384,9 +1389,10 @@ __global__ __launch_bounds__(1024) void vr_sor_redblack_kernel(VrArgs a, int ite
 
 __global__ __launch_bounds__(256) void vr_finish_kernel(VrArgs a, float *__restrict__ flow, long flow_stride)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const WgId wg = xcd_local_wg();
+  const int idx = wg.x * blockDim.x + threadIdx.x;
   if (idx >= a.w * a.h) return;
-  const int pair = blockIdx.y, i = idx % a.w, j = idx / a.w, o = j * a.st + i;
+  const int pair = wg.y, i = idx % a.w, j = idx / a.w, o = j * a.st + i;
   float *f = flow + (size_t)pair * flow_stride + 2 * (size_t)idx;
   const float2 d = a.Dp(pair)[a.didx(i, j)];
   f[0] = a.single(pair, P_WX)[o] + d.x;

@@ -141,6 +141,8 @@ int fotg_varref(fotg_ctx *ctx, int level, int n, const float *I0, const float *I
  * name: "wx","wy","mask","du","dv","sh","sv","a11","a12","a22" (block inverse),"b1","b2","avg","Iz","Ix","Iy","Ixx","Ixy","Iyy","Ixz","Iyz" */
 int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, float *host_out);
 
+/* test tap: how often an opt-in kernel variant was launched by this process ("sor_stream"); -1 for unknown names */
+long fotg_debug_counter(const char *name);
 const char *fotg_strerror(int status);
 int fotg_last_hip_error(void);
 const char *fotg_version(void);

@@ -199,6 +199,7 @@ def test_streaming_solver_kernel(monkeypatch):
     1080p pair (68-row finest level, 2 row bands) and on a 66-row level with a different width"""
     F, OFClass, _, O = _mods()
     monkeypatch.setenv("FOTG_VR_STREAM", "1")
+    before = F.lib().fotg_debug_counter(b"sor_stream")
     for w, h in ((1920, 1080), (1280, 1050)):
         f0, f1 = synth_pair(h, w, seed=9)
         op = F.operating_point(2, 1920, 1)                   # scales 6-5-4 for both sizes
@@ -207,6 +208,7 @@ def test_streaming_solver_kernel(monkeypatch):
         p = oracle_params(O, op)
         a, b = O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f)
         assert np.array_equal(out[0], O.flow(a, b, p, 0)) and np.array_equal(out[1], O.flow(b, a, p, 0)), (w, h)
+    assert F.lib().fotg_debug_counter(b"sor_stream") == before + 2 * 5       # 5 inner iterations at level 4, both sizes
 
 
 def test_fused_level_system_in_global_memory(alley, monkeypatch):
