@@ -574,14 +574,14 @@ static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hip
 static long g_stream_launches = 0;      // fotg_debug_counter("sor_stream"): tests assert the opt-in kernel really ran
 // streaming solver (vr_sor_stream_kernel): diagonals travel through LDS rings.  Instantiated for 64..69 rows (1080p level 4).
 // FOTG_VR_STREAM=1 selects it (tests).
-static bool launch_sor_stream(const VrArgs &b, int n, float omega, hipStream_t s)
+template <int K, int RD, int RCW>
+static bool launch_sor_stream_k(const VrArgs &b, int n, float omega, hipStream_t s)
 {
-  constexpr int RD = 72, RCW = 70, M = FOTG_SYNC_M, U = 32;
+  constexpr int M = FOTG_SYNC_M, U = 32;
   using GEO = StreamGeom<RD, RCW>;
-  const char *e = getenv("FOTG_VR_STREAM");                      // opt-in: measured equal to the resident kernel at 1080p (see the kernel's header)
-  if (!e || !atoi(e)) return false;
-  const int NB = b.nbands > 0 ? b.nbands : 1;
-  if (b.RP < 64 || b.RP + 1 > RCW || b.RPD > RD || (b.RPD & 1) || b.nsweeps * NB + 3 > 10 || b.S < 2 * U) return false;
+  const int NB = K == 2 ? 1 : (b.nbands > 0 ? b.nbands : 1);
+  if (b.RP < 64 || b.RP + 1 > RCW || b.RPD > RD || (b.RPD & 1) || b.S < 2 * U) return false;
+  if (K == 2 ? (b.nsweeps > 3 || b.h + 2 > b.RPD) : (b.nsweeps * NB + 3 > 12)) return false;
   const int DS = NB > 1 ? ((2 * M + 2 + M - 1) / M) * M : ((M + 2 + M - 1) / M) * M;
   const int omax = b.nsweeps > 0 ? (b.nsweeps - 1) * DS + (NB - 1) * M : 0;
   const int RDN = M * (GEO::LI + omax / M + 1 + 1), RCN = RDN - M;
@@ -589,15 +589,26 @@ static bool launch_sor_stream(const VrArgs &b, int n, float omega, hipStream_t s
   if (lds > 160 * 1024) return false;
   static int max_set = 0;
   if (lds > max_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_sor_stream_kernel<RD, RCW, M, U>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_sor_stream_kernel<RD, RCW, M, U, K>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
     max_set = lds;
   }
-  vr_sor_stream_kernel<RD, RCW, M, U><<<n, 640, lds, s>>>(b, omega);
+  vr_sor_stream_kernel<RD, RCW, M, U, K><<<n, 768, lds, s>>>(b, omega);
   ++g_stream_launches;
   return true;
+}
+
+// Levels of 65..96 rows (1080p level 4: 68): FOTG_VR_STREAM unset / 2 = two rows per lane + packed arithmetic [default],
+// 1 = one row per lane in row bands, 0 = the resident-D kernel.  Two geometries: <= 69 rows and <= 97 rows per diagonal.
+static bool launch_sor_stream(const VrArgs &b, int n, float omega, hipStream_t s)
+{
+  const char *e = getenv("FOTG_VR_STREAM");
+  const int mode = e ? atoi(e) : 2;
+  if (mode == 2) return launch_sor_stream_k<2, 72, 70>(b, n, omega, s) || launch_sor_stream_k<2, 100, 98>(b, n, omega, s);
+  if (mode == 1) return launch_sor_stream_k<1, 72, 70>(b, n, omega, s);
+  return false;
 }
 
 // sweep-pipelined LDS solver when it applies: <= 4 sweeps (one wave each), (du,dv) of the level fit in LDS
@@ -605,16 +616,15 @@ static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, h
 {
   if (const char *e = getenv("FOTG_DEBUG_SWEEPS")) sweeps = atoi(e);                    // timing experiments only (wrong results)
   const int lds = 128 + (a.S + 2) * a.RPD * (int)sizeof(float2);
-  if (sweeps < 1 || sweeps > 4 || lds > 150 * 1024 || a.S < 24) return false;
+  if (sweeps < 1 || sweeps > 4 || a.S < 24) return false;
   VrArgs b = a;
   b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
   set_bands(b, sweeps, 16);
+  if (b.band_mode == 3 && launch_sor_stream(b, n, omega, s)) return true;     // 65..96 rows, any width: diagonals stream through LDS rings
+  if (lds > 150 * 1024) return false;                            // the kernels below keep the whole (du,dv) in LDS
   if (b.band_mode == 1) return launch_sor_pipe<1, 8, 1>(a, n, sweeps, omega, s, b, sweeps * b.nbands * 64);
   if (b.band_mode == 2) return launch_sor_pipe<1, 8, 2>(a, n, sweeps, omega, s, b, (sweeps * b.nbands < 4 ? 4 : sweeps * b.nbands) * 64);
-  if (b.band_mode == 3) {
-    if (launch_sor_stream(b, n, omega, s)) return true;
-    return launch_sor_pipe<1, 8, 3>(a, n, sweeps, omega, s, b, 1024);     // all 16 waves copy D in and out
-  }
+  if (b.band_mode == 3) return launch_sor_pipe<1, 8, 3>(a, n, sweeps, omega, s, b, 1024);     // all 16 waves copy D in and out
   switch (a.K) {
     case 1: return launch_sor_pipe<1, 8, 0>(a, n, sweeps, omega, s, b, 256);
     case 2: return launch_sor_pipe<2, 8, 0>(a, n, sweeps, omega, s, b, 256);

@@ -1048,26 +1048,25 @@ __global__ __launch_bounds__(BANDED == 1 || BANDED == 3 ? 1024 : BANDED == 2 ? 5
 // the anti-diagonals travel through two LDS rings, one slot per diagonal: the D ring (RD cells of 8 B per slot) and the C
 // ring (two planes of RCW 16-byte cells per slot).  Besides the barrier-stepped solver waves (sor_sync_wave's schedule,
 // M steps per barrier) the workgroup has
-//   * two LOADER waves (A: D row + plane 0 of C, B: plane 1 of C): in barrier interval I they issue the direct-to-LDS
-//     loads (global_load_lds_dwordx4, no VGPRs) of the M diagonals of chunk I + LI and, before the next barrier, wait
-//     (counted vmcnt) until only the G-1 newest chunks are in flight, so chunk c is visible to everybody from interval
-//     c - LI + G on.  The first solver wave reads diagonal s+2 <= M*I + M + 1 in interval I  ->  LI = G + 1.  G-1 = 4
-//     chunks in flight cover the ~1.2 us the data kernel's output takes to arrive from another XCD's L2 / the MALL.
+//   * two LOADER waves (A: D row + plane 0 of C, B: plane 1 of C): in barrier interval I they first wait for the direct-to-
+//     LDS loads (global_load_lds_dwordx4, no VGPRs) they issued in interval I-1, then issue those of the M diagonals of
+//     chunk I + LI.  A chunk is thus known complete after barrier I+1 and visible to everybody from interval c - 1 on; the
+//     first solver wave reads diagonal s+2 <= M*I + M + 1 in interval I  ->  LI = 3.  (With the XCD-local placement of the
+//     data kernel the loads are L2 hits; deeper windows of loads in flight measured no faster.)
 //   * a WRITER wave: in interval J it copies the D rows of chunk J - WO back to global memory, WO = omax/M + 1 (the last
 //     sweep relaxed them in interval J - 1 at the latest, and its stores landed before barrier J).
-// A D slot therefore lives LI + WO + 1 intervals and a C slot LI + omax/M + 1: 60 + 56 slots = 160 KB for 120x68 with
-// 3 sweeps x 2 bands.  Compared with vr_sor_pipe_kernel this removes the D copy-in / copy-out phases (they overlap the
+// A D slot therefore lives LI + WO + 1 intervals and a C slot LI + omax/M + 1: 36 + 32 slots = 93 KB for 120x68 with
+// 3 sweeps of two rows per lane (K = 2).  Compared with vr_sor_pipe_kernel this removes the D copy-in / copy-out phases (they overlap the
 // solve) and the two global loads per solver wave and step (the system now comes out of LDS), and the LDS footprint no
 // longer grows with the level's width.
-// MEASURED (MI355X, 64 x 1080p level 4): 41.8 us per call against 41.6 us for the resident kernel -- the loaders keep up
-// (9 us per call with the solver waves switched off), but a solver step costs the same whether its 32 bytes of system come
-// through the LDS port or the texture-address path; six lock-stepped in-order solver waves on four SIMDs are the limit
-// either way.  So this kernel is opt-in (FOTG_VR_STREAM=1) and kept for levels too wide for a resident D.
+// MEASURED (MI355X, 64 x 1080p level 4, XCD-local placement): 29.5 us per call with K = 2 (one solver wave per sweep, two
+// rows per lane, packed f32; 115 ns per diagonal) against 35.5 us for vr_sor_pipe_kernel (six solver waves on four SIMDs)
+// and 34 us for K = 1 here.  The LDS footprint does not grow with the level's width.
 // ------------------------------------------------------------------------------------------------------------------
 template <int RD, int RCW>
 struct StreamGeom {
   static constexpr int DB = RD * 8, CB = RCW * 16, CSLOT = 2 * CB;         // bytes
-  static constexpr int G = 5, LI = G + 1;                                  // chunks in flight + 1, load lead (intervals)
+  static constexpr int LI = 3;                                             // load lead in barrier intervals (see the loaders)
 };
 
 __device__ __forceinline__ char *lds_bytes() { return reinterpret_cast<char *>(fotg_lds64); }
@@ -1080,16 +1079,20 @@ __device__ __forceinline__ void glds16(const void *src, unsigned lds_dst_byte)
   __builtin_amdgcn_global_load_lds((gvoid *)src, (lvoid *)(lds_bytes() + lds_dst_byte), 16, 0, 0);
 }
 
-template <int RD, int RCW, int M, int U>
-__global__ __launch_bounds__(640) void vr_sor_stream_kernel(VrArgs a, float omega)
+// K = 2: one solver wave per sweep, two consecutive rows per lane, packed-f32 arithmetic.  With the system in LDS a
+// second row costs no prefetch registers, its top neighbour is the lane's own previous result, the two rows are
+// independent within a step (better issue than one dependent chain), and three solver waves have a SIMD each (the
+// loaders and the writer sit on the fourth).
+template <int RD, int RCW, int M, int U, int K>
+__global__ __launch_bounds__(768) void vr_sor_stream_kernel(VrArgs a, float omega)
 {
   using GEO = StreamGeom<RD, RCW>;
-  constexpr int DB = GEO::DB, CB = GEO::CB, CSLOT = GEO::CSLOT, G = GEO::G, LI = GEO::LI;
+  constexpr int DB = GEO::DB, CB = GEO::CB, CSLOT = GEO::CSLOT, LI = GEO::LI;
   constexpr int UT = 8;
   static_assert(U % M == 0 && UT % M == 0, "barrier phase is a compile-time property of the unrolled step");
   static_assert(RCW > 64 && RCW <= 128, "two direct loads per C plane and diagonal");
   const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int NB = a.nbands > 0 ? a.nbands : 1;
+  const int NB = K == 2 ? 1 : (a.nbands > 0 ? a.nbands : 1);
   constexpr int DBS = M, DS1 = ((M + 2 + M - 1) / M) * M, DSB = ((2 * M + 2 + M - 1) / M) * M;
   const int DS = NB > 1 ? DSB : DS1;
   const int S = a.S, RP = a.RP, RPD = a.RPD;
@@ -1101,6 +1104,8 @@ __global__ __launch_bounds__(640) void vr_sor_stream_kernel(VrArgs a, float omeg
   const int RDN = M * (LI + WO + 1), RCN = RDN - M;               // ring slots
   const int NI = (E + omax) / M + 1;                              // barrier intervals every wave goes through
   const int nsolver = a.nsweeps * NB;
+  // roles: K = 1: solver waves, then loader A, loader B, writer.  K = 2: solver waves 0..2, helpers on SIMD 3 (waves 3, 7, 11)
+  const int wvA = K == 2 ? 3 : nsolver, wvB = K == 2 ? 7 : nsolver + 1, wvW = K == 2 ? 11 : nsolver + 2;
   const unsigned CRING = (unsigned)RCN * CSLOT, DRING = (unsigned)RDN * DB;     // bytes
   const unsigned DBASE = CRING, DUMP = CRING + DRING;             // C ring | D ring | one spare D row for the no-op tail steps
   char *Dg = reinterpret_cast<char *>(a.Dp(pair));
@@ -1109,52 +1114,53 @@ __global__ __launch_bounds__(640) void vr_sor_stream_kernel(VrArgs a, float omeg
   auto st_f2 = [&](unsigned off, float2 v) { *reinterpret_cast<float2 *>(lds_bytes() + off) = v; };
   auto ld_f4 = [&](unsigned off) { return *reinterpret_cast<const float4 *>(lds_bytes() + off); };
 
-  // direct loads of the next M diagonals (diagonals past S re-read the all-zero diagonal S); running diagonal / slot offsets.
+  // direct loads of the next M diagonals (diagonals past S re-read the all-zero diagonal S); running source pointers / slot offsets.
   // Loader A: D row + C plane 0 (3 loads per diagonal), loader B: C plane 1 (2 loads).
   int ld = 0;
   unsigned ldslot = 0, lcslot = 0;
+  const char *pD = Dg + lane * 16;                                // lane's 16 bytes of the D row
+  const char *pC = Cg + lane * 32 + (wv == wvA ? 0 : 16);         // lane's row of the C plane this loader owns
+  const size_t dstep = (size_t)RPD * 8, cstep = (size_t)RP * 32;
+  const bool inD = lane < RPD / 2, inC1 = lane <= RP, inC2 = lane + 64 <= RP;
   auto issue_chunk = [&](auto which) {
     constexpr bool A = decltype(which)::value;
 #pragma unroll
     for (int k = 0; k < M; ++k) {
-      const int ds = ld < S ? ld : S;
-      const char *crow = Cg + ((size_t)ds * RP) * 32 + (A ? 0 : 16);
       const unsigned cdst = lcslot + (A ? 0 : CB);
-      if (A) { if (lane < RPD / 2) glds16(Dg + ((size_t)ds * RPD) * 8 + lane * 16, DBASE + ldslot); }
-      if (lane <= RP) glds16(crow + lane * 32, cdst);             // rows 0 .. RP (row RP = what the idle lanes read; finite)
-      if (lane + 64 <= RP) glds16(crow + (lane + 64) * 32, cdst + 1024);
+      if (A) { if (inD) glds16(pD, DBASE + ldslot); }
+      if (inC1) glds16(pC, cdst);                                 // rows 0 .. RP (row RP = what the idle lanes read; finite)
+      if (inC2) glds16(pC + 64 * 32, cdst + 1024);
+      if (ld < S) { pD += dstep; pC += cstep; }
       ++ld;
       ldslot += DB; if (ldslot == DRING) ldslot = 0;
       lcslot += CSLOT; if (lcslot == CRING) lcslot = 0;
     }
   };
-  constexpr int NGA = M * 3, NGB = M * 2;                         // direct loads per chunk
-  static_assert(NGA * (G - 1) <= 63, "vmcnt is a 6-bit counter");
-
-  if (wv == nsolver) { for (int c = 0; c < LI; ++c) issue_chunk(std::true_type{}); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-  if (wv == nsolver + 1) { for (int c = 0; c < LI; ++c) issue_chunk(std::false_type{}); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  // A loader waits for ALL its outstanding loads right after a barrier and only then issues the next chunk: the chunk issued
+  // in interval I has the whole interval to land, is known complete after barrier I+1 and published by barrier I+2 (LI = 3).
+  // No counting of load instructions (a counted vmcnt would have to know how many of the exec-masked loads were issued).
+  if (wv == wvA) { for (int c = 0; c < LI; ++c) issue_chunk(std::true_type{}); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  if (wv == wvB) { for (int c = 0; c < LI; ++c) issue_chunk(std::false_type{}); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   if (threadIdx.x < RD) st_f2(DUMP + threadIdx.x * 8, make_float2(0.f, 0.f));
   __syncthreads();
 
-  if (wv == nsolver) {                                            // ---------------- loader A ----------------
+  if (wv == wvA) {                                                // ---------------- loader A ----------------
     for (int I = 0; I < NI; ++I) {
-      asm volatile("s_barrier" ::: "memory");
+      asm volatile("s_barrier\n\ts_waitcnt vmcnt(0)" ::: "memory");
       issue_chunk(std::true_type{});
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NGA * (G - 1)) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may land after the workgroup's LDS is released
     return;
   }
-  if (wv == nsolver + 1) {                                        // ---------------- loader B ----------------
+  if (wv == wvB) {                                                // ---------------- loader B ----------------
     for (int I = 0; I < NI; ++I) {
-      asm volatile("s_barrier" ::: "memory");
+      asm volatile("s_barrier\n\ts_waitcnt vmcnt(0)" ::: "memory");
       issue_chunk(std::false_type{});
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NGB * (G - 1)) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
-  if (wv == nsolver + 2) {                                        // ---------------- writer ----------------
+  if (wv == wvW) {                                                // ---------------- writer ----------------
     int wd = 0;
     unsigned wslot = 0;
     for (int I = 0; I < NI; ++I) {
@@ -1170,11 +1176,71 @@ __global__ __launch_bounds__(640) void vr_sor_stream_kernel(VrArgs a, float omeg
     }
     return;
   }
-  if (wv > nsolver + 2) {                                         // spare waves only count barriers
+  if (wv >= nsolver) {                                            // spare waves only count barriers
     for (int I = 0; I < NI; ++I) asm volatile("s_barrier" ::: "memory");
     return;
   }
 
+  if constexpr (K == 2) {
+    // ---------------- solver wave of sweep n, rows 2L and 2L+1 per lane ----------------
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int off = wv * DS;
+    const int nl = (a.h + 1) >> 1;                                // lanes with rows; the others stay disabled for the whole solve
+    const float om0 = omega, om1 = (2 * lane + 1 < a.h) ? omega : 0.f;
+    const unsigned vD = DBASE + (unsigned)lane * 16, vC = (unsigned)lane * 32;
+    for (int t = 0; t < off / M; ++t) asm volatile("s_barrier" ::: "memory");
+    if (lane < nl) {
+      unsigned d0 = 0, d1 = DB, d2 = 2 * DB, c1o = CSLOT;
+      float4 ow = ld_f4(d0 + vD);                                 // own values of rows 2L, 2L+1 (diagonal s)
+      float4 nx = ld_f4(d1 + vD);                                 // diagonal s+1: rows 2L, 2L+1 = right of both rows, bottom of row 2L
+      float2 nb = ld_f2(d1 + vD + 16);                            // diagonal s+1, row 2L+2: bottom of row 2L+1
+      float4 ca0 = ld_f4(vC), cb0 = ld_f4(vC + 16), ca1 = ld_f4(vC + CB), cb1 = ld_f4(vC + CB + 16);   // cells (plane 0 | plane 1) of both rows
+      v2f p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
+      float hl0 = 0.f, hl1 = 0.f;
+      auto relax = [&](v2f own, float4 c0, float4 c1, float hl, v2f left, v2f top, v2f right, v2f bottom, float om) {
+        const v2f a1 = {c0.x, c0.y}, bb = {c0.z, c0.w};
+        const float a22 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
+        v2f sv = hr * right;
+        sv = sv + vt * top;
+        sv = sv + vb * bottom;
+        sv = sv + bb;
+        const v2f B = hl * left + sv;
+        const v2f pa = a1 * B;
+        v2f t = {pa.x + pa.y, c0.y * B.x + a22 * B.y};
+        t = t - own;
+        return own + om * t;
+      };
+      auto step2 = [&](auto tail_tag, int u, int s) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        const float o0 = (!TAIL || s < S) ? om0 : 0.f, o1 = (!TAIL || s < S) ? om1 : 0.f;
+        // top of row 2L: row 2L-1's result of the previous step, in lane L-1 (lane 0: no row above, 0)
+        const v2f top0 = {dpp_wave_shr1(p1.x), dpp_wave_shr1(p1.y)};
+        if (u % M == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const float4 nnx = ld_f4(d2 + vD);                        // diagonal s+2
+        const float2 nnb = ld_f2(d2 + vD + 16);
+        const float4 na0 = ld_f4(c1o + vC), nb0 = ld_f4(c1o + vC + 16), na1 = ld_f4(c1o + vC + CB), nb1 = ld_f4(c1o + vC + CB + 16);
+        const v2f own0 = {ow.x, ow.y}, own1 = {ow.z, ow.w}, r0 = {nx.x, nx.y}, r1 = {nx.z, nx.w}, bt1 = {nb.x, nb.y};
+        const v2f q0 = relax(own0, ca0, ca1, hl0, p0, top0, r0, r1, o0);
+        const v2f q1 = relax(own1, cb0, cb1, hl1, p1, p0, r1, bt1, o1);      // its top (s-1, 2L) is this lane's previous row-0 result
+        *reinterpret_cast<float4 *>(lds_bytes() + ((!TAIL || s < S) ? d0 + vD : DUMP + (unsigned)lane * 16)) = make_float4(q0.x, q0.y, q1.x, q1.y);
+        hl0 = ca1.y; hl1 = cb1.y;
+        p0 = q0; p1 = q1; ow = nx; nx = nnx; nb = nnb; ca0 = na0; cb0 = nb0; ca1 = na1; cb1 = nb1;
+        d0 = d1; d1 = d2; d2 += DB; if (d2 == DRING) d2 = 0;
+        c1o += CSLOT; if (c1o == CRING) c1o = 0;
+      };
+      int t0 = 0;
+      for (; t0 + U <= S; t0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) step2(std::false_type{}, u, t0 + u);
+      }
+      for (; t0 < S; t0 += UT) {
+#pragma unroll
+        for (int u = 0; u < UT; ++u) step2(std::true_type{}, u, t0 + u);
+      }
+    }
+    for (int t = off / M; t < omax / M + 1; ++t) asm volatile("s_barrier" ::: "memory");
+    return;
+  }
   // ---------------- solver wave (sweep n, band b): sor_sync_wave's schedule on the rings ----------------
   const int n = wv / NB, b = wv % NB, off = n * DS + b * DBS;
   const int rb = b * a.band_rows, nrows = NB > 1 ? (rb + a.band_rows <= a.h ? a.band_rows : a.h - rb) : a.h;

@@ -193,22 +193,29 @@ def test_solver_fallback_paths(path, bands, alley, monkeypatch):
         assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (path, case)
 
 
-def test_streaming_solver_kernel(monkeypatch):
-    """FOTG_VR_STREAM=1: the 64..69-row level is solved by vr_sor_stream_kernel ((du,dv) and the system travel through LDS
-    rings filled by direct-to-LDS loads, results written back by a writer wave while the solve runs): same bits, on a
-    1080p pair (68-row finest level, 2 row bands) and on a 66-row level with a different width"""
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_streaming_solver_kernel(mode, monkeypatch):
+    """levels of 65..96 rows are solved by vr_sor_stream_kernel: (du,dv) and the system travel through LDS rings filled by
+    direct-to-LDS loads, results are written back by a writer wave while the solve runs.  FOTG_VR_STREAM: 2 (default) two
+    rows per lane + packed f32, 1 one row per lane in two row bands, 0 the resident-D kernel -- same bits.  Sizes: 1080p
+    (68-row level), a narrower 68-row level, a 75-row level (second LDS geometry) and an odd row count (67)"""
     F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_VR_STREAM", "1")
+    monkeypatch.setenv("FOTG_VR_STREAM", mode)
     before = F.lib().fotg_debug_counter(b"sor_stream")
-    for w, h in ((1920, 1080), (1280, 1050)):
+    sizes = ((1920, 1080), (1280, 1050), (1600, 1200), (1904, 1072 - 8))
+    expect = 0
+    for w, h in sizes:
         f0, f1 = synth_pair(h, w, seed=9)
-        op = F.operating_point(2, 1920, 1)                   # scales 6-5-4 for both sizes
+        op = F.operating_point(2, 1920, 1)                   # scales 6-5-4 for all sizes
         ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
         out = ofc.calc_batch(dev(np.stack([f0, f1])), dev(np.stack([f1, f0]))).cpu().numpy()
         p = oracle_params(O, op)
         a, b = O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f)
         assert np.array_equal(out[0], O.flow(a, b, p, 0)) and np.array_equal(out[1], O.flow(b, a, p, 0)), (w, h)
-    assert F.lib().fotg_debug_counter(b"sor_stream") == before + 2 * 5       # 5 inner iterations at level 4, both sizes
+        rows = a.shape[0] >> 4
+        expect += 5 if (mode == "2" and 65 <= rows <= 96) or (mode == "1" and 65 <= rows <= 69) else 0     # 5 inner iterations at level 4
+        ofc.close()
+    assert F.lib().fotg_debug_counter(b"sor_stream") == before + expect
 
 
 def test_fused_level_system_in_global_memory(alley, monkeypatch):
