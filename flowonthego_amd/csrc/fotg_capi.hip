@@ -361,6 +361,7 @@ int fotg_pyramid(fotg_ctx *c, int n, const float *I, int which, void *stream)
 {
   if (!c || !I || (which != 0 && which != 1)) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  HIPCHK(hipSetDevice(c->device));
   const float *I0 = which == 0 ? I : nullptr, *I1 = which == 1 ? I : nullptr;
   return c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, (hipStream_t)stream) : pyramid_impl<3>(c, n, I0, I1, (hipStream_t)stream);
 }
@@ -369,6 +370,7 @@ int fotg_pyramid_pair(fotg_ctx *c, int n, const float *I0, const float *I1, int 
 {
   if (!c || !I0 || !I1 || !(stages & 3)) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  HIPCHK(hipSetDevice(c->device));
   return c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, (hipStream_t)stream, stages) : pyramid_impl<3>(c, n, I0, I1, (hipStream_t)stream, stages);
 }
 
@@ -433,6 +435,7 @@ int fotg_grid_set_trace(fotg_ctx *c, int l, float *trace_host)
 int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
 {
   int st = check_level(c, l, n); if (st) return st;
+  HIPCHK(hipSetDevice(c->device));
   GridState &gs = c->gs[l];
   if (!gs.I0 || !gs.I1) return FOTG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -498,6 +501,7 @@ int fotg_grid_aggregate(fotg_ctx *c, int l, int n, float *flowout, void *stream)
 {
   int st = check_level(c, l, n); if (st) return st;
   if (!flowout) return FOTG_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
   return aggregate_impl(c, l, n, c->p_iter[l], c->pweight[l], nullptr, nullptr, flowout, (hipStream_t)stream);
 }
 
@@ -554,19 +558,24 @@ static void set_bands(VrArgs &b, int sweeps, int max_waves)
   b.band_mode = mode;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: cache what was set per device
+static bool ensure_dyn_lds(const void *fn, int lds, int (&set)[32])
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) { (void)hipGetLastError(); dev = 0; }
+  if (lds <= set[dev]) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { (void)hipGetLastError(); return false; }
+  set[dev] = lds;
+  return true;
+}
+
 template <int K, int P, int BANDED>
 static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s, const VrArgs &b, int threads)
 {
   constexpr int U = (P >= 8) ? 32 : 8 * P;
-  static int max_set = 0;
   const int lds = 128 + (a.S + 2) * a.RPD * (int)sizeof(float2);
-  if (lds > max_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_sor_pipe_kernel<K, P, U, BANDED>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    max_set = lds;
-  }
+  static int lds_set[32] = {0};
+  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_sor_pipe_kernel<K, P, U, BANDED>), lds, lds_set)) return false;
   vr_sor_pipe_kernel<K, P, U, BANDED><<<n, threads, lds, s>>>(b, omega);
   return true;
 }
@@ -587,14 +596,8 @@ static bool launch_sor_stream_k(const VrArgs &b, int n, float omega, hipStream_t
   const int RDN = M * (GEO::LI + omax / M + 1 + 1), RCN = RDN - M;
   const int lds = RCN * GEO::CSLOT + RDN * GEO::DB + GEO::DB;
   if (lds > 160 * 1024) return false;
-  static int max_set = 0;
-  if (lds > max_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_sor_stream_kernel<RD, RCW, M, U, K>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    max_set = lds;
-  }
+  static int lds_set[32] = {0};
+  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_sor_stream_kernel<RD, RCW, M, U, K>), lds, lds_set)) return false;
   vr_sor_stream_kernel<RD, RCW, M, U, K><<<n, 768, lds, s>>>(b, omega);
   ++g_stream_launches;
   return true;
@@ -644,15 +647,9 @@ static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, floa
                                const float *I0, const float *I1, long img_stride, int tw, int pad)
 {
   constexpr int U = (P >= 8) ? 32 : 8 * P;
-  static int max_set = 0;
   const int lds = fused_lds_bytes(b, CL);
-  if (lds > max_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    max_set = lds;
-  }
+  static int lds_set[32] = {0};
+  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL, RES>), lds, lds_set)) return false;
   vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL, RES><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
   return true;
 }
@@ -766,6 +763,7 @@ int fotg_varref(fotg_ctx *c, int l, int n, const float *I0, const float *I1, lon
   int st = check_level(c, l, n); if (st) return st;
   if (!I0 || !I1 || !flow || !c->vr) return FOTG_ERR_ARG;
   if (c->geom[l].h < 5 || c->geom[l].w < 3) return FOTG_ERR_UNSUPPORTED;
+  HIPCHK(hipSetDevice(c->device));
   return c->noc == 1 ? varref_impl<1>(c, l, n, I0, I1, pair_stride, flow, (hipStream_t)stream)
                      : varref_impl<3>(c, l, n, I0, I1, pair_stride, flow, (hipStream_t)stream);
 }
@@ -947,6 +945,7 @@ int fotg_calc_batch(fotg_ctx *c, int n, const float *I0, const float *I1, const 
 {
   if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  HIPCHK(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
   bool tracing = false;
   for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) tracing |= c->gs[l].trace_host != nullptr;
@@ -990,6 +989,7 @@ int fotg_calc_batch_u8(fotg_ctx *c, int n, const unsigned char *I0, const unsign
 {
   if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  HIPCHK(hipSetDevice(c->device));
   return calc_range<unsigned char>(c, n, I0, I1, initflow, outflow, (hipStream_t)stream);
 }
 
@@ -998,12 +998,14 @@ int fotg_calc_sequence(fotg_ctx *c, int n_frames, const float *frames, const flo
 {
   if (!c || !frames || !outflow) return FOTG_ERR_ARG;
   if (n_frames < 2 || n_frames - 1 > c->max_batch) return FOTG_ERR_BATCH;
+  HIPCHK(hipSetDevice(c->device));
   return calc_range<float>(c, n_frames - 1, frames, nullptr, initflow, outflow, (hipStream_t)stream);
 }
 int fotg_calc_sequence_u8(fotg_ctx *c, int n_frames, const unsigned char *frames, const float *initflow, float *outflow, void *stream)
 {
   if (!c || !frames || !outflow) return FOTG_ERR_ARG;
   if (n_frames < 2 || n_frames - 1 > c->max_batch) return FOTG_ERR_BATCH;
+  HIPCHK(hipSetDevice(c->device));
   return calc_range<unsigned char>(c, n_frames - 1, frames, nullptr, initflow, outflow, (hipStream_t)stream);
 }
 
@@ -1027,6 +1029,7 @@ int fotg_upsample_crop(fotg_ctx *c, int n, const float *flow, float *out, void *
 {
   if (!c || !flow || !out) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  HIPCHK(hipSetDevice(c->device));
   const LevelGeom &g = c->geom[c->p.sc_l];
   dim3 grid((c->w_org * c->h_org + 255) / 256, n), block(256);
   upsample_crop_kernel<<<grid, block, 0, (hipStream_t)stream>>>(flow, (long)g.w * g.h * 2, g.w, g.h, c->p.sc_l, c->padw / 2, c->padh / 2,
