@@ -270,6 +270,15 @@ def main():
             del seq
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(I0, I1)
+            # the same leg also checks the timed batch's result against the oracle ("EPE vs kroeger CPU")
+            from oracle import oracle as O
+            p = O.op_point(OP_POINT, W, 1)
+            ofc.calc_batch(I0, I1, None, out)
+            got = out[:2].cpu().numpy()
+            ref = [O.flow(O.pad_frame(I0[k].cpu().numpy(), p.sc_f), O.pad_frame(I1[k].cpu().numpy(), p.sc_f), p, a.sor_mode) for k in range(2)]
+            d = np.stack(ref) - got
+            res["cpu_baseline"]["parity"] = {"pairs_checked": 2, "mean_epe_px": float(np.sqrt((d ** 2).sum(-1)).mean()),
+                                             "max_abs_diff": float(np.abs(d).max()), "bit_identical": bool((d == 0).all())}
         print(json.dumps(res))
     if dist:
         td.barrier()
