@@ -737,12 +737,19 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     return FOTG_OK;
   }
   HIPCHK(hipMemsetAsync(a.D, 0, (size_t)n * a.d_pair_stride * sizeof(float2), s));      // image_erase(du), image_erase(dv) (:185-186)
-  vr_prep_kernel<NOC><<<grid, block, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
-  LAUNCHCHK();
-  vr_deriv1_kernel<NOC><<<grid, block, 0, s>>>(a);
-  LAUNCHCHK();
-  vr_deriv2_kernel<NOC><<<grid, block, 0, s>>>(a);
-  LAUNCHCHK();
+  const char *esetup = getenv("FOTG_VR_SETUP");
+  if (!esetup || atoi(esetup)) {
+    // warp + first + second derivatives in one tiled launch (FOTG_VR_SETUP=0: the three plane-at-a-time launches; tests)
+    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
+    LAUNCHCHK();
+  } else {
+    vr_prep_kernel<NOC><<<grid, block, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
+    LAUNCHCHK();
+    vr_deriv1_kernel<NOC><<<grid, block, 0, s>>>(a);
+    LAUNCHCHK();
+    vr_deriv2_kernel<NOC><<<grid, block, 0, s>>>(a);
+    LAUNCHCHK();
+  }
   for (int it = 0; it < inner; ++it) {
     vr_data_kernel<NOC><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(a, quarter_alpha, half_delta_over3, half_gamma_over3);
     LAUNCHCHK();

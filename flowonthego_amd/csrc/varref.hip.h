@@ -73,19 +73,21 @@ __device__ __forceinline__ float conv_v5(const float *__restrict__ col, int j, i
 
 // per-pixel bodies of the three set-up stages (shared by the wide kernels and the fused per-pair kernel)
 template <int NOC>
-__device__ __forceinline__ void prep_pixel(const VrArgs &a, int pair, int i, int j, const float *__restrict__ I0, const float *__restrict__ I1,
-                                           long img_stride, int tw, int pad, const float *__restrict__ flow, long flow_stride)
+struct PrepVal { float wx, wy, mask, avg[NOC], iz[NOC]; };
+
+template <int NOC>
+__device__ __forceinline__ PrepVal<NOC> prep_values(const VrArgs &a, int pair, int i, int j, const float *__restrict__ I0, const float *__restrict__ I1,
+                                                    long img_stride, int tw, int pad, const float *__restrict__ flow, long flow_stride)
 {
-  const int o = j * a.st + i;
+  PrepVal<NOC> v;
   const float *f = flow + (size_t)pair * flow_stride + 2 * (size_t)(j * a.w + i);
   const float wx = f[0], wy = f[1];
-  a.single(pair, P_WX)[o] = wx;
-  a.single(pair, P_WY)[o] = wy;
+  v.wx = wx; v.wy = wy;
   // image_warp (opticalflow_aux.c:18-60)
   const float xx = i + wx, yy = j + wy;
   const int x = (int)floorf(xx), y = (int)floorf(yy);
   const float dx = xx - x, dy = yy - y;
-  a.single(pair, P_MASK)[o] = (xx >= 0 && xx <= a.w - 1 && yy >= 0 && yy <= a.h - 1) ? 1.f : 0.f;
+  v.mask = (xx >= 0 && xx <= a.w - 1 && yy >= 0 && yy <= a.h - 1) ? 1.f : 0.f;
   const int x1 = clampi(x, a.w), x2 = clampi(x + 1, a.w), y1 = clampi(y, a.h), y2 = clampi(y + 1, a.h);
   const float *s1 = I1 + (size_t)pair * img_stride, *s0 = I0 + (size_t)pair * img_stride;
 #pragma unroll
@@ -95,9 +97,28 @@ __device__ __forceinline__ void prep_pixel(const VrArgs &a, int pair, int i, int
                      SRC(y2, x1) * (1.0f - dx) * dy + SRC(y2, x2) * dx * dy;
 #undef SRC
     const float i1 = s0[((size_t)(j + pad) * tw + (i + pad)) * NOC + c];
-    a.color(pair, C_AVG, c)[o] = 0.5f * (wv + i1);        // get_derivatives :81
-    a.color(pair, C_IZ, c)[o] = wv - i1;                  // :82
+    v.avg[c] = 0.5f * (wv + i1);                          // get_derivatives :81
+    v.iz[c] = wv - i1;                                    // :82
   }
+  return v;
+}
+
+template <int NOC>
+__device__ __forceinline__ void prep_store(const VrArgs &a, int pair, int i, int j, const PrepVal<NOC> &v)
+{
+  const int o = j * a.st + i;
+  a.single(pair, P_WX)[o] = v.wx;
+  a.single(pair, P_WY)[o] = v.wy;
+  a.single(pair, P_MASK)[o] = v.mask;
+#pragma unroll
+  for (int c = 0; c < NOC; ++c) { a.color(pair, C_AVG, c)[o] = v.avg[c]; a.color(pair, C_IZ, c)[o] = v.iz[c]; }
+}
+
+template <int NOC>
+__device__ __forceinline__ void prep_pixel(const VrArgs &a, int pair, int i, int j, const float *__restrict__ I0, const float *__restrict__ I1,
+                                           long img_stride, int tw, int pad, const float *__restrict__ flow, long flow_stride)
+{
+  prep_store<NOC>(a, pair, i, j, prep_values<NOC>(a, pair, i, j, I0, I1, img_stride, tw, pad, flow, flow_stride));
 }
 
 template <int NOC>
@@ -159,6 +180,66 @@ __global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
 // smoothness weight from the 3x3 cross of (uu,vv): compute_smoothness first half (opticalflow_aux.c:126-139);
 // 3-tap {-0.5,-0,0.5} with the border rows of convolve_vert_fast_3 / replicate columns of convolve_horiz_fast_3
 // (image.c:376-399,436-464).  l,c,r = left/centre/right, t,b = top/bottom (t or b unused on the border rows).
+// The three set-up stages of a level in ONE launch for levels too large for the fused per-pair kernel: one workgroup per 32x8
+// tile recomputes what it needs of the neighbouring tiles instead of meeting them in global memory -- warp / average /
+// difference on the tile + 4 pixels (the second derivatives reach 2 + 2 pixels), first derivatives on the tile + 2.  Halo
+// entries outside the image hold the values of the clamped coordinate, exactly what the reference's replicate indexing
+// reads, and the 5-tap helpers index the LDS tiles through pointers biased to global coordinates.
+template <int NOC>
+__global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__restrict__ I0, const float *__restrict__ I1,
+                                                       long img_stride, int tw, int pad,
+                                                       const float *__restrict__ flow, long flow_stride)
+{
+  constexpr int TW_ = 32, TH_ = 8, XW = TW_ + 8, XH = TH_ + 8, YW = TW_ + 4, YH = TH_ + 4;
+  __shared__ float Xa[NOC][XH * XW], Xz[NOC][XH * XW], Yx[NOC][YH * YW], Yy[NOC][YH * YW];
+  const WgId wg = xcd_local_wg();
+  const int pair = wg.y, w = a.w, h = a.h;
+  const int tiles_x = (w + TW_ - 1) / TW_;
+  const int tx0 = (wg.x % tiles_x) * TW_, ty0 = (wg.x / tiles_x) * TH_;
+  // stage A: warp + mask + average / difference at the clamped coordinate of every tile+4 position
+  for (int e = threadIdx.x; e < XW * XH; e += 256) {
+    const int cx = tx0 - 4 + e % XW, cy = ty0 - 4 + e / XW;
+    const int gx = clampi(cx, w), gy = clampi(cy, h);
+    const PrepVal<NOC> v = prep_values<NOC>(a, pair, gx, gy, I0, I1, img_stride, tw, pad, flow, flow_stride);
+#pragma unroll
+    for (int c = 0; c < NOC; ++c) { Xa[c][e] = v.avg[c]; Xz[c][e] = v.iz[c]; }
+    if (cx >= tx0 && cx < tx0 + TW_ && cy >= ty0 && cy < ty0 + TH_ && cx < w && cy < h) prep_store<NOC>(a, pair, cx, cy, v);
+  }
+  __syncthreads();
+  // stage B: first derivatives at the clamped coordinate of every tile+2 position (get_derivatives :84-93)
+  for (int e = threadIdx.x; e < YW * YH; e += 256) {
+    const int cx = tx0 - 2 + e % YW, cy = ty0 - 2 + e / YW;
+    const int gx = clampi(cx, w), gy = clampi(cy, h);
+    const bool own = cx >= tx0 && cx < tx0 + TW_ && cy >= ty0 && cy < ty0 + TH_ && cx < w && cy < h;
+#pragma unroll
+    for (int c = 0; c < NOC; ++c) {
+      // row / column pointers biased so that GLOBAL indices address the tile: X position of global (x, y) = (y - ty0 + 4) * XW + x - tx0 + 4
+      const float *arow = Xa[c] + (gy - ty0 + 4) * XW - tx0 + 4, *acol = Xa[c] + (4 - ty0) * XW + gx - tx0 + 4;
+      const float *zrow = Xz[c] + (gy - ty0 + 4) * XW - tx0 + 4, *zcol = Xz[c] + (4 - ty0) * XW + gx - tx0 + 4;
+      const float ix = conv_h5(arow, gx, w), iy = conv_v5(acol, gy, h, XW);
+      const float ixz = conv_h5(zrow, gx, w), iyz = conv_v5(zcol, gy, h, XW);
+      Yx[c][e] = ix; Yy[c][e] = iy;
+      if (own) {
+        const int o = cy * a.st + cx;
+        a.color(pair, C_IX, c)[o] = ix; a.color(pair, C_IY, c)[o] = iy; a.color(pair, C_IXZ, c)[o] = ixz; a.color(pair, C_IYZ, c)[o] = iyz;
+      }
+    }
+  }
+  __syncthreads();
+  // stage C: second derivatives of the tile's own pixels (:95-99)
+  const int i = tx0 + (threadIdx.x % TW_), j = ty0 + (threadIdx.x / TW_);
+  if (i < w && j < h) {
+    const int o = j * a.st + i;
+#pragma unroll
+    for (int c = 0; c < NOC; ++c) {
+      const float *xrow = Yx[c] + (j - ty0 + 2) * YW - tx0 + 2, *xcol = Yx[c] + (2 - ty0) * YW + i - tx0 + 2, *ycol = Yy[c] + (2 - ty0) * YW + i - tx0 + 2;
+      a.color(pair, C_IXX, c)[o] = conv_h5(xrow, i, w);
+      a.color(pair, C_IXY, c)[o] = conv_v5(xcol, j, h, YW);
+      a.color(pair, C_IYY, c)[o] = conv_v5(ycol, j, h, YW);
+    }
+  }
+}
+
 __device__ __forceinline__ float smooth_w(float2 l, float2 c, float2 r, float2 t, float2 b, int j, int h, float quarter_alpha)
 {
   const float c0 = -0.5f, c1 = -0.0f, c2 = 0.5f;

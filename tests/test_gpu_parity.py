@@ -218,6 +218,22 @@ def test_streaming_solver_kernel(mode, monkeypatch):
     assert F.lib().fotg_debug_counter(b"sor_stream") == before + expect
 
 
+def test_plane_at_a_time_setup_stages(alley, monkeypatch):
+    """FOTG_VR_SETUP=0: warp, first and second derivatives as three launches through global memory instead of the tiled
+    single launch (levels that are not refined on chip): same planes, same flow"""
+    F, OFClass, VarRefClass, O = _mods()
+    monkeypatch.setenv("FOTG_VR_SETUP", "0")
+    monkeypatch.setenv("FOTG_VR_PATH", "2")                  # no on-chip levels: every level takes the unfused sequence
+    for case, op_point in (("alley", 2), ("synth_rgb", 2), ("synth_odd", 3)):
+        f0, f1, noc = frames(case, alley)
+        h, w = f0.shape[:2]
+        op = F.operating_point(op_point, w, noc)
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        p = oracle_params(O, op)
+        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
+
+
 def test_fused_level_system_in_global_memory(alley, monkeypatch):
     """the on-chip levels keep the linear system in LDS when it fits; FOTG_VR_CLDS=0 forces the variant that streams it
     through global memory (what larger levels use): same bits"""
