@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the built libraries are git-ignored: a fresh checkout builds them once (hipcc cross-compiles gfx950 without a GPU)
+    if not os.path.exists(os.path.join(ROOT, "flowonthego_amd", "libfotg.so")):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "flowonthego_amd", "csrc")], check=False)
 
 
 @pytest.fixture(scope="session")
