@@ -1,0 +1,75 @@
+// examples/run_dense_min.cpp -- the shape of the reference's run_dense (src/run_dense.cpp:120-305) over the C++ shim:
+// two raw float32 frames in, one Middlebury .flo out.  No OpenCV: frames are raw interleaved float32 (w*h*channels), the way
+// the reference holds them after cv::imread + convertTo(CV_32F) (src/run_dense.cpp:137-145).
+//
+//   hipcc -O2 -Iinclude examples/run_dense_min.cpp -Lflowonthego_amd -lfotg -Wl,-rpath,$PWD/flowonthego_amd -o examples/run_dense_min
+//   examples/run_dense_min frame0.raw frame1.raw W H C out.flo [op-point 1..4]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "fotg/oflow.h"
+
+static std::vector<float> read_raw(const char *path, size_t n)
+{
+  std::vector<float> v(n);
+  FILE *f = fopen(path, "rb");
+  if (!f || fread(v.data(), sizeof(float), n, f) != n) { fprintf(stderr, "cannot read %zu floats from %s\n", n, path); exit(1); }
+  fclose(f);
+  return v;
+}
+
+// SaveFlowFile (src/run_dense.cpp:26-67): "PIEH", width, height, then (u,v) float32 row-major
+static void save_flo(const char *path, const float *uv, int w, int h)
+{
+  FILE *f = fopen(path, "wb");
+  if (!f) { fprintf(stderr, "cannot write %s\n", path); exit(1); }
+  fprintf(f, "PIEH");
+  fwrite(&w, sizeof(int), 1, f);
+  fwrite(&h, sizeof(int), 1, f);
+  fwrite(uv, sizeof(float), (size_t)2 * w * h, f);
+  fclose(f);
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 7) { fprintf(stderr, "usage: %s frame0.raw frame1.raw W H C out.flo [op-point]\n", argv[0]); return 2; }
+  const int W = atoi(argv[3]), H = atoi(argv[4]), C = atoi(argv[5]), oppt = argc > 7 ? atoi(argv[7]) : 2;
+  const size_t n = (size_t)W * H * C;
+  const std::vector<float> f0 = read_raw(argv[1], n), f1 = read_raw(argv[2], n);
+
+  // operating point (src/run_dense.cpp:166-227) -- evaluated by the library, copied into the reference's struct
+  fotg_params p;
+  OFC::fotgCheck(fotg_op_point(oppt, W, C, &p), "fotg_op_point");
+  OFC::opt_params op;
+  op.coarsest_scale = p.sc_f; op.finest_scale = p.sc_l; op.patch_size = p.ps; op.patch_stride = p.patove;
+  op.use_mean_normalization = p.patnorm != 0; op.grad_descent_iter = p.max_iter;
+  op.dp_thresh = p.dp_thresh; op.dr_thresh = p.dr_thresh; op.res_thresh = p.res_thresh;
+  op.use_var_ref = p.usetvref != 0; op.var_ref_iter = p.tv_solverit; op.var_ref_alpha = p.tv_alpha; op.var_ref_gamma = p.tv_gamma;
+  op.var_ref_delta = p.tv_delta; op.var_ref_sor_weight = p.tv_sor; op.verbosity = 0; op.channels = C;
+  OFC::img_params iparams;
+  iparams.width = W; iparams.height = H; iparams.padding = op.patch_size;       // unpadded: the library pads inside its pyramid kernel
+
+  float *d0 = nullptr, *d1 = nullptr, *dflow = nullptr, *dfull = nullptr;
+  if (hipMalloc(&d0, n * 4) != hipSuccess || hipMalloc(&d1, n * 4) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
+  hipMemcpy(d0, f0.data(), n * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d1, f1.data(), n * 4, hipMemcpyHostToDevice);
+
+  OFC::OFClass ofc(op, iparams);                                                    // src/run_dense.cpp:277
+  int ow, oh;
+  OFC::fotgCheck(fotg_out_size(ofc.handle(), &ow, &oh), "fotg_out_size");
+  std::vector<float> coarse((size_t)2 * ow * oh);
+  ofc.calc(d0, d1, iparams, nullptr, coarse.data());                                // src/run_dense.cpp:286
+
+  // post-processing of src/run_dense.cpp:293-303 on the device: x 2^finest, bilinear upsample, crop the padding
+  hipMalloc(&dflow, coarse.size() * 4);
+  hipMalloc(&dfull, (size_t)2 * W * H * 4);
+  hipMemcpy(dflow, coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice);
+  OFC::fotgCheck(fotg_upsample_crop(ofc.handle(), 1, dflow, dfull, nullptr), "fotg_upsample_crop");
+  std::vector<float> full((size_t)2 * W * H);
+  hipMemcpy(full.data(), dfull, full.size() * 4, hipMemcpyDeviceToHost);
+  save_flo(argv[6], full.data(), W, H);
+  printf("%s: %dx%d flow written (finest scale %dx%d, op-point %d)\n", argv[6], W, H, ow, oh, oppt);
+  hipFree(d0); hipFree(d1); hipFree(dflow); hipFree(dfull);
+  return 0;
+}

@@ -80,3 +80,21 @@ def test_flo_writer_matches_reference_file_layout(tmp_path, alley_golden_flow):
     open(path, "wb").write(b"PIEX" + raw[4:])
     with pytest.raises(ValueError):
         read_flo(path)
+
+
+def _build_example(tmpdir):
+    import subprocess
+    exe = os.path.join(str(tmpdir), "run_dense_min")
+    libdir = os.path.join(ROOT, "flowonthego_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "run_dense_min.cpp"),
+                           "-L" + libdir, "-lfotg", "-Wl,-rpath," + libdir, "-o", exe], stderr=subprocess.DEVNULL)
+    return exe
+
+
+def test_cpp_shim_example_builds(tmp_path):
+    """the reference-side binding (include/fotg/{params,patchgrid,oflow}.h) compiles and links
+    against libfotg.so as a run_dense-shaped C++ program"""
+    import flowonthego_amd as F
+    F.lib()
+    exe = _build_example(tmp_path)
+    assert os.path.exists(exe)
