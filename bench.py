@@ -188,7 +188,7 @@ def main():
     a = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
-    dist = world > 1
+    dist = world > 1 or bool(os.environ.get("FOTG_BENCH_FORCE_DIST"))      # the switch exercises the RCCL path on a 1-GPU box
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
