@@ -27,12 +27,6 @@ struct LevelGeom {
 __host__ __device__ inline int clampi(int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); }
 __host__ __device__ inline int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-// Wave reduction in the order of the oracle's dis_sum(): the balanced tree v[i] += v[i^1], ^2, ^4, ^8, ^16, ^32.
-// a+b == b+a in IEEE, so a lane may add its partner's partial on either side and get the same bits.
-//   xor 1, 2 : DPP quad_perm              xor 4 : row_half_mirror (the lanes of a quad already agree)
-//   xor 8    : row_mirror                 xor 16: row_bcast:15 into rows 1,3   xor 32: row_bcast:31 into rows 2,3
-// After the last step lane 63 holds ((r3+r2)+(r1+r0)) == the tree's value; it is returned wave-uniform (SGPR).
-// All six steps are VALU DPP operations -- no LDS round trips on the LK loop's critical path.
 // XCD-aware placement for grids of (work items, images): workgroups are dealt round-robin to the 8 XCDs by linear id
 // (x fastest), and a one-workgroup-per-image kernel (grid = images) puts image p on XCD p % 8.  Re-deal the (x, y)
 // workgroups so that everything of image p runs on XCD p % 8: each stage then finds what the previous one wrote in the L2
@@ -49,6 +43,12 @@ __device__ __forceinline__ WgId xcd_local_wg()
   return id;
 }
 
+// Wave reduction in the order of the oracle's dis_sum(): the balanced tree v[i] += v[i^1], ^2, ^4, ^8, ^16, ^32.
+// a+b == b+a in IEEE, so a lane may add its partner's partial on either side and get the same bits.
+//   xor 1, 2 : DPP quad_perm              xor 4 : row_half_mirror (the lanes of a quad already agree)
+//   xor 8    : row_mirror                 xor 16: row_bcast:15 into rows 1,3   xor 32: row_bcast:31 into rows 2,3
+// After the last step lane 63 holds ((r3+r2)+(r1+r0)) == the tree's value; it is returned wave-uniform (SGPR).
+// All six steps are VALU DPP operations -- no LDS round trips on the LK loop's critical path.
 __device__ __forceinline__ float wave_sum(float v)
 {
 #define FOTG_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rmask, 0xF, false))
