@@ -1395,12 +1395,53 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
   for (int k = threadIdx.x; k < ncell; k += blockDim.x) lds_d_st(k, make_float2(0.f, 0.f));     // image_erase(du), (dv) (:185-186)
   for (int k = threadIdx.x; k < nlc; k += blockDim.x) lc[k] = make_float4(0.f, 0.f, 0.f, 0.f);  // cells outside the image stay zero
   // set-up stages of the level (refine_variational.cpp:182-183): warp + mask + mean/difference, then the derivative planes
-  for (int px = threadIdx.x; px < w * h; px += blockDim.x) prep_pixel<NOC>(a, pair, px % w, px / w, I0, I1, img_stride, tw, pad, flow, flow_stride);
-  __syncthreads();
-  for (int px = threadIdx.x; px < w * h; px += blockDim.x) deriv1_pixel<NOC>(a, pair, px % w, px / w);
-  __syncthreads();
-  for (int px = threadIdx.x; px < w * h; px += blockDim.x) deriv2_pixel<NOC>(a, pair, px % w, px / w);
-  __syncthreads();
+  const int npx0 = w * h;
+  if (CL && 4 * NOC * npx0 <= 4 * nlc) {
+    // the planes the 5-tap filters read (average, difference, Ix, Iy) are staged in the still unused LDS area of the system C,
+    // pitch w: no global round trip between the three stages.  Everything is also stored to the global planes (later loads, taps).
+    float *sa = reinterpret_cast<float *>(lc);
+    __syncthreads();                                             // (the zero fill of lc above is redone below)
+    for (int px = threadIdx.x; px < npx0; px += blockDim.x) {
+      const int i = px % w, j = px / w;
+      const PrepVal<NOC> v = prep_values<NOC>(a, pair, i, j, I0, I1, img_stride, tw, pad, flow, flow_stride);
+      prep_store<NOC>(a, pair, i, j, v);
+#pragma unroll
+      for (int c = 0; c < NOC; ++c) { sa[c * npx0 + px] = v.avg[c]; sa[(NOC + c) * npx0 + px] = v.iz[c]; }
+    }
+    __syncthreads();
+    for (int px = threadIdx.x; px < npx0; px += blockDim.x) {
+      const int i = px % w, j = px / w, o = j * st + i;
+#pragma unroll
+      for (int c = 0; c < NOC; ++c) {
+        const float *A = sa + c * npx0, *Z = sa + (NOC + c) * npx0;
+        const float ix = conv_h5(A + j * w, i, w), iy = conv_v5(A + i, j, h, w);
+        a.color(pair, C_IX, c)[o] = ix; a.color(pair, C_IY, c)[o] = iy;
+        a.color(pair, C_IXZ, c)[o] = conv_h5(Z + j * w, i, w); a.color(pair, C_IYZ, c)[o] = conv_v5(Z + i, j, h, w);
+        sa[(2 * NOC + c) * npx0 + px] = ix; sa[(3 * NOC + c) * npx0 + px] = iy;
+      }
+    }
+    __syncthreads();
+    for (int px = threadIdx.x; px < npx0; px += blockDim.x) {
+      const int i = px % w, j = px / w, o = j * st + i;
+#pragma unroll
+      for (int c = 0; c < NOC; ++c) {
+        const float *X = sa + (2 * NOC + c) * npx0, *Y = sa + (3 * NOC + c) * npx0;
+        a.color(pair, C_IXX, c)[o] = conv_h5(X + j * w, i, w);
+        a.color(pair, C_IXY, c)[o] = conv_v5(X + i, j, h, w);
+        a.color(pair, C_IYY, c)[o] = conv_v5(Y + i, j, h, w);
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nlc; k += blockDim.x) lc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+  } else {
+    for (int px = threadIdx.x; px < w * h; px += blockDim.x) prep_pixel<NOC>(a, pair, px % w, px / w, I0, I1, img_stride, tw, pad, flow, flow_stride);
+    __syncthreads();
+    for (int px = threadIdx.x; px < w * h; px += blockDim.x) deriv1_pixel<NOC>(a, pair, px % w, px / w);
+    __syncthreads();
+    for (int px = threadIdx.x; px < w * h; px += blockDim.x) deriv2_pixel<NOC>(a, pair, px % w, px / w);
+    __syncthreads();
+  }
   constexpr int B = 4;                                           // pixels per thread whose global loads are in flight together
   const int npx = w * h, nth = blockDim.x;
   // Gray levels of at most B pixels per thread: everything the loop reads from global memory (mask, derivative planes,
