@@ -1457,6 +1457,20 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
       rp[q] = data_load<NOC>(a, pair, px % w, px / w);
     }
   }
+  // resident variant: the pixels' index arithmetic is the same in every inner iteration -- (du,dv) cell, system cell, image
+  // index and border flags are computed once (the compiler does not hoist them out of the divergent pixel loops by itself)
+  int pdc[RES ? B : 1], plc[RES ? B : 1], ppx[RES ? B : 1];      // D cell of the pixel, C cell, px | flags << 24
+  if constexpr (resident) {
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+      const int px = threadIdx.x + q * nth;
+      const bool ok = px < npx;
+      const int pc = ok ? px : npx - 1, i = pc % w, j = pc / w;
+      pdc[q] = (i + j) * RPD + j;
+      plc[q] = (i + j) * a.RP + j;
+      ppx[q] = pc | (ok ? 1 << 24 : 0) | (i > 0 ? 1 << 25 : 0) | (i < w - 1 ? 1 << 26 : 0) | (j > 0 ? 1 << 27 : 0) | (j < h - 1 ? 1 << 28 : 0);
+    }
+  }
   for (int it = 0; it < inner; ++it) {
     if constexpr (resident) {
       // opaque to the optimiser: otherwise every loop-invariant product of compute_data is hoisted and kept live too
@@ -1469,6 +1483,21 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
         asm volatile("" : "+v"(r.m), "+v"(r.wxc), "+v"(r.wxl), "+v"(r.wxr), "+v"(r.wxt), "+v"(r.wxb), "+v"(r.wyc), "+v"(r.wyl), "+v"(r.wyr), "+v"(r.wyt), "+v"(r.wyb));
       }
     }
+    if constexpr (resident) {                                    // compute_smoothness first half (:126-139), indices precomputed
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const int f = ppx[q];
+        if (!(f & (1 << 24))) continue;
+        const PixIn<NOC> &r = rp[q];
+        const int c = pdc[q];
+        const int cl = (f & (1 << 25)) ? c - RPD : c, cr = (f & (1 << 26)) ? c + RPD : c;      // clamped neighbours (replicate)
+        const int ct = (f & (1 << 27)) ? c - RPD - 1 : c, cb = (f & (1 << 28)) ? c + RPD + 1 : c;
+        const float2 d0 = lds_d_ld(c), dl = lds_d_ld(cl), dr = lds_d_ld(cr), dt = lds_d_ld(ct), db = lds_d_ld(cb);
+        const int px = f & 0xFFFFFF, j = (f & (1 << 27)) ? ((f & (1 << 28)) ? 1 : h - 1) : 0;   // smooth_w only tests j == 0 / j == h-1
+        sm[px] = smooth_w(make_float2(r.wxl + dl.x, r.wyl + dl.y), make_float2(r.wxc + d0.x, r.wyc + d0.y), make_float2(r.wxr + dr.x, r.wyr + dr.y),
+                          make_float2(r.wxt + dt.x, r.wyt + dt.y), make_float2(r.wxb + db.x, r.wyb + db.y), j, h, quarter_alpha);
+      }
+    } else
     for (int k0 = threadIdx.x; k0 < npx; k0 += B * nth) {        // compute_smoothness first half (:126-139)
       float gx[B][5], gy[B][5];                                  // wx, wy at centre, left, right, top, bottom (clamped)
       int qi[B], qj[B];
@@ -1502,6 +1531,26 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
       }
     }
     __syncthreads();
+    if constexpr (resident) {                                    // second half (:141-163) + data term + laplacian + inverse
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const int f = ppx[q];
+        if (!(f & (1 << 24))) continue;
+        const int px = f & 0xFFFFFF;
+        const float s_o = sm[px];
+        const float hr = (f & (1 << 26)) ? s_o + sm[px + 1] : 0.0f;
+        const float hl = (f & (1 << 25)) ? sm[px - 1] + s_o : 0.0f;
+        const float vb = (f & (1 << 28)) ? s_o + sm[px + w] : 0.0f;
+        const float vt = (f & (1 << 27)) ? sm[px - w] + s_o : 0.0f;
+        const float2 duv = lds_d_ld(pdc[q]);
+        // data_term_cell only tests i > 0, i < w-1, j > 0, j < h-1: hand it border-equivalent coordinates
+        const int ii = (f & (1 << 25)) ? ((f & (1 << 26)) ? 1 : w - 1) : 0, jj = (f & (1 << 27)) ? ((f & (1 << 28)) ? 1 : h - 1) : 0;
+        float4 c0, c1;
+        data_term_cell<NOC>(a, ii, jj, rp[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3, c0, c1);
+        lc[plc[q]] = c0;
+        lc[plc[q] + a.SC * a.RP + 1] = c1;
+      }
+    } else
     for (int k0 = threadIdx.x; k0 < npx; k0 += B * nth) {        // second half (:141-163) + data term + laplacian + inverse
       PixIn<NOC> pin[B];
 #pragma unroll
