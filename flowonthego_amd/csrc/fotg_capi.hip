@@ -667,6 +667,7 @@ static bool dispatch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, 
   b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
   set_bands(b, sweeps, 8);
   if (b.band_mode == 2) { b.nbands = 0; b.band_mode = 0; }      // the fused kernel has no mode 2: plain waves
+  if (b.band_mode == 3 && b.nbands > 1) return false;           // the fused kernel's barrier-stepped waves assume a single band (<= 64 rows)
   if (b.band_mode == 3) {
     // system cells in LDS as well when they fit (FOTG_VR_CLDS=0: keep them in global memory; tests)
     const char *e = getenv("FOTG_VR_CLDS");

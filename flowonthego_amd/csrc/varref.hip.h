@@ -958,7 +958,9 @@ __device__ __forceinline__ void sor_rows_wave(const VrArgs &a, int pair, float o
 // PK: the (du,dv) pair as packed f32 (v_pk_mul_f32 / v_pk_add_f32 round each half like the scalar op): 15 instead of 28
 // arithmetic instructions per step.  Measured: a win when every solver wave has a SIMD to itself (fused levels, 3 waves:
 // -13 %), a loss when two solver waves share a SIMD (level 4, 6 waves: +8 %; the packed ops occupy the SIMD twice as long).
-template <int P, int U, bool NT, int M, bool CL = false, bool PK = false>
+// NOB: the caller guarantees a single band (nbands <= 1): the row above the wave's first row does not exist, lane 0's DPP
+// source is out of range and reads 0 (bound_ctrl) -- no top value from LDS, no select.
+template <int P, int U, bool NT, int M, bool CL = false, bool PK = false, bool NOB = false>
 __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float omega, int wv, int lane, const float4 *lc = nullptr)
 {
   constexpr int UT = P;                                          // unroll of the tail loop
@@ -1017,7 +1019,7 @@ __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float o
     // bound_ctrl would drop the two selects, but ties the DPP to the LDS load of tpl: measured 3 % slower.)
     float dx = dpp_wave_shr1(prev.x), dy = dpp_wave_shr1(prev.y);
     asm volatile("" : "+v"(dx), "+v"(dy));
-    const float2 top = first_row ? tpl : make_float2(dx, dy);
+    const float2 top = NOB ? make_float2(dx, dy) : (first_row ? tpl : make_float2(dx, dy));
     // sor_update()'s expression order
     typedef float v2f __attribute__((ext_vector_type(2)));
     const float a11 = st.c0.x, a12 = st.c0.y, b1 = st.c0.z, b2 = st.c0.w, a22 = st.c1.x, hr = st.c1.y, vb = st.c1.z, vt = st.c1.w;
@@ -1034,14 +1036,14 @@ __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float o
       s1 = s1 + vb * nxb.x;  s2 = s2 + vb * nxb.y;
     }
     if (u % M == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(s1), "+v"(s2) :: "memory");   // tied to (s1,s2): placed here
-    float2 nr, nb, tp;
+    float2 nr, nb, tp = make_float2(0.f, 0.f);
     if (!TAIL) {
       nr = lds_d_ld(lrow + rpd2); nb = lds_d_ld(lrow + rpd2 + 1);  // diagonal s+2: right / bottom of step s+1
-      tp = lds_d_ld(trow);                                         // (diagonal s, row above the band): top of step s+1
+      if constexpr (!NOB) tp = lds_d_ld(trow);                     // (diagonal s, row above the band): top of step s+1
     } else {
       const int d2 = s + 2 < S + 1 ? s + 2 : S + 1, d0 = s < S ? s : S;
       nr = lds_d_ld(d2 * RPD + r); nb = lds_d_ld(d2 * RPD + r + 1);
-      tp = lds_d_ld(d0 * RPD + (b > 0 ? rb - 1 : RP));
+      if constexpr (!NOB) tp = lds_d_ld(d0 * RPD + (b > 0 ? rb - 1 : RP));
     }
     if constexpr (CL) {                                          // cells of diagonal s+1 (diagonal S is all zero)
       if (!TAIL || s + 1 <= S) lc += RP;
@@ -1581,7 +1583,7 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
     }
     sor_pipe_reset_progress();
     __syncthreads();                                             // also drains the C stores (vmcnt(0)) before the solver reads them
-    if constexpr (BANDED == 3) sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M, CL, true>(a, pair, omega, wv, lane, lc);
+    if constexpr (BANDED == 3) sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M, CL, true, true>(a, pair, omega, wv, lane, lc);   // host: single band only
     else if constexpr (BANDED) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
     else { if (wv < a.nsweeps) sor_pipe_wave<K, P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
     __syncthreads();
