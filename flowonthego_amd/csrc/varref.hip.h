@@ -963,7 +963,7 @@ __device__ __forceinline__ void sor_rows_wave(const VrArgs &a, int pair, float o
 template <int P, int U, bool NT, int M, bool CL = false, bool PK = false, bool NOB = false>
 __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float omega, int wv, int lane, const float4 *lc = nullptr)
 {
-  constexpr int UT = P;                                          // unroll of the tail loop
+  constexpr int UT = CL ? 2 * P : P;                             // unroll of the tail loop (no prefetch ring with CL: longer, fewer back edges)
   static_assert(U % M == 0 && UT % M == 0 && U % P == 0, "barrier phase must be a compile-time property of the unrolled step");
   const int NB = a.nbands > 0 ? a.nbands : 1;
   constexpr int DB = M, DS1 = ((M + 2 + M - 1) / M) * M, DSB = ((2 * M + 2 + M - 1) / M) * M;
