@@ -598,7 +598,7 @@ static bool launch_sor_stream_k(const VrArgs &b, int n, float omega, hipStream_t
   if (lds > 160 * 1024) return false;
   static int lds_set[32] = {0};
   if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_sor_stream_kernel<RD, RCW, M, U, K>), lds, lds_set)) return false;
-  vr_sor_stream_kernel<RD, RCW, M, U, K><<<n, 768, lds, s>>>(b, omega);
+  vr_sor_stream_kernel<RD, RCW, M, U, K><<<n, 1024, lds, s>>>(b, omega);
   ++g_stream_launches;
   return true;
 }

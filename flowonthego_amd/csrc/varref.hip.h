@@ -1167,7 +1167,7 @@ __device__ __forceinline__ void glds16(const void *src, unsigned lds_dst_byte)
 // independent within a step (better issue than one dependent chain), and three solver waves have a SIMD each (the
 // loaders and the writer sit on the fourth).
 template <int RD, int RCW, int M, int U, int K>
-__global__ __launch_bounds__(768) void vr_sor_stream_kernel(VrArgs a, float omega)
+__global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float omega)
 {
   using GEO = StreamGeom<RD, RCW>;
   constexpr int DB = GEO::DB, CB = GEO::CB, CSLOT = GEO::CSLOT, LI = GEO::LI;
@@ -1187,8 +1187,8 @@ __global__ __launch_bounds__(768) void vr_sor_stream_kernel(VrArgs a, float omeg
   const int RDN = M * (LI + WO + 1), RCN = RDN - M;               // ring slots
   const int NI = (E + omax) / M + 1;                              // barrier intervals every wave goes through
   const int nsolver = a.nsweeps * NB;
-  // roles: K = 1: solver waves, then loader A, loader B, writer.  K = 2: solver waves 0..2, helpers on SIMD 3 (waves 3, 7, 11)
-  const int wvA = K == 2 ? 3 : nsolver, wvB = K == 2 ? 7 : nsolver + 1, wvW = K == 2 ? 11 : nsolver + 2;
+  // roles: K = 1: solver waves, then three loaders and the writer.  K = 2: solver waves 0..2, helpers on SIMD 3 (waves 3, 7, 11, 15)
+  const int wvL0 = K == 2 ? 3 : nsolver, wvL1 = K == 2 ? 7 : nsolver + 1, wvL2 = K == 2 ? 11 : nsolver + 2, wvW = K == 2 ? 15 : nsolver + 3;
   const unsigned CRING = (unsigned)RCN * CSLOT, DRING = (unsigned)RDN * DB;     // bytes
   const unsigned DBASE = CRING, DUMP = CRING + DRING;             // C ring | D ring | one spare D row for the no-op tail steps
   char *Dg = reinterpret_cast<char *>(a.Dp(pair));
@@ -1197,52 +1197,54 @@ __global__ __launch_bounds__(768) void vr_sor_stream_kernel(VrArgs a, float omeg
   auto st_f2 = [&](unsigned off, float2 v) { *reinterpret_cast<float2 *>(lds_bytes() + off) = v; };
   auto ld_f4 = [&](unsigned off) { return *reinterpret_cast<const float4 *>(lds_bytes() + off); };
 
-  // direct loads of the next M diagonals (diagonals past S re-read the all-zero diagonal S); running source pointers / slot offsets.
-  // Loader A: D row + C plane 0 (3 loads per diagonal), loader B: C plane 1 (2 loads).
+  // Direct loads of the next M diagonals (diagonals past S re-read the all-zero diagonal S), split over three loader waves
+  // so that none of them issues more than 2 loads per diagonal (an LDS-DMA load costs its wave ~27 ns of issue):
+  //   loader 0: the D row, C plane 0 rows 0..63      loader 1: C plane 1 rows 0..63, C plane 0 rows 64..RP
+  //   loader 2: C plane 1 rows 64..RP                (row RP = what the idle lanes read; finite)
+  // Every load has at least one active lane (RP >= 64 is a launch condition), so the per-chunk instruction counts are exact
+  // and a counted vmcnt can leave the newest chunk in flight across the barrier.
+  const int lrole = wv == wvL0 ? 0 : wv == wvL1 ? 1 : 2;
   int ld = 0;
   unsigned ldslot = 0, lcslot = 0;
   const char *pD = Dg + lane * 16;                                // lane's 16 bytes of the D row
-  const char *pC = Cg + lane * 32 + (wv == wvA ? 0 : 16);         // lane's row of the C plane this loader owns
+  const char *pC = Cg + lane * 32;                                // lane's row of C (both planes interleaved in global memory)
   const size_t dstep = (size_t)RPD * 8, cstep = (size_t)RP * 32;
-  const bool inD = lane < RPD / 2, inC1 = lane <= RP, inC2 = lane + 64 <= RP;
-  auto issue_chunk = [&](auto which) {
-    constexpr bool A = decltype(which)::value;
+  const bool inD = lane < RPD / 2, inC2 = lane + 64 <= RP;
+  auto issue_chunk = [&](auto role_tag) {
+    constexpr int ROLE = decltype(role_tag)::value;
 #pragma unroll
     for (int k = 0; k < M; ++k) {
-      const unsigned cdst = lcslot + (A ? 0 : CB);
-      if (A) { if (inD) glds16(pD, DBASE + ldslot); }
-      if (inC1) glds16(pC, cdst);                                 // rows 0 .. RP (row RP = what the idle lanes read; finite)
-      if (inC2) glds16(pC + 64 * 32, cdst + 1024);
+      if (ROLE == 0) { if (inD) glds16(pD, DBASE + ldslot); glds16(pC, lcslot); }
+      if (ROLE == 1) { glds16(pC + 16, lcslot + CB); if (inC2) glds16(pC + 64 * 32, lcslot + 1024); }
+      if (ROLE == 2) { if (inC2) glds16(pC + 64 * 32 + 16, lcslot + CB + 1024); }
       if (ld < S) { pD += dstep; pC += cstep; }
       ++ld;
       ldslot += DB; if (ldslot == DRING) ldslot = 0;
       lcslot += CSLOT; if (lcslot == CRING) lcslot = 0;
     }
   };
-  // A loader waits for ALL its outstanding loads right after a barrier and only then issues the next chunk: the chunk issued
-  // in interval I has the whole interval to land, is known complete after barrier I+1 and published by barrier I+2 (LI = 3).
-  // No counting of load instructions (a counted vmcnt would have to know how many of the exec-masked loads were issued).
-  if (wv == wvA) { for (int c = 0; c < LI; ++c) issue_chunk(std::true_type{}); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-  if (wv == wvB) { for (int c = 0; c < LI; ++c) issue_chunk(std::false_type{}); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-  if (threadIdx.x < RD) st_f2(DUMP + threadIdx.x * 8, make_float2(0.f, 0.f));
-  __syncthreads();
-
-  if (wv == wvA) {                                                // ---------------- loader A ----------------
+  // Interval I of a loader: barrier I, issue chunk I + LI, wait until only that newest chunk is still in flight.  Chunk c is
+  // thus complete before barrier c - LI + 2 and visible to everybody from interval c - LI + 2 = c - 1 on (LI = 3).
+  auto loader = [&](auto role_tag) {
+    constexpr int ROLE = decltype(role_tag)::value;
+    constexpr int NG = M * (ROLE == 2 ? 1 : 2);                   // loads per chunk of this loader
+    for (int c = 0; c < LI; ++c) issue_chunk(role_tag);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int I = 0; I < NI; ++I) {
-      asm volatile("s_barrier\n\ts_waitcnt vmcnt(0)" ::: "memory");
-      issue_chunk(std::true_type{});
+      asm volatile("s_barrier" ::: "memory");
+      issue_chunk(role_tag);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NG) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may land after the workgroup's LDS is released
-    return;
-  }
-  if (wv == wvB) {                                                // ---------------- loader B ----------------
-    for (int I = 0; I < NI; ++I) {
-      asm volatile("s_barrier\n\ts_waitcnt vmcnt(0)" ::: "memory");
-      issue_chunk(std::false_type{});
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
-  }
+  };
+  if (threadIdx.x < RD) st_f2(DUMP + threadIdx.x * 8, make_float2(0.f, 0.f));
+  if (wv == wvL0) { loader(std::integral_constant<int, 0>{}); return; }
+  if (wv == wvL1) { loader(std::integral_constant<int, 1>{}); return; }
+  if (wv == wvL2) { loader(std::integral_constant<int, 2>{}); return; }
+  __syncthreads();
+  (void)lrole;
+
   if (wv == wvW) {                                                // ---------------- writer ----------------
     int wd = 0;
     unsigned wslot = 0;
