@@ -1131,11 +1131,11 @@ __global__ __launch_bounds__(BANDED == 1 || BANDED == 3 ? 1024 : BANDED == 2 ? 5
 // the anti-diagonals travel through two LDS rings, one slot per diagonal: the D ring (RD cells of 8 B per slot) and the C
 // ring (two planes of RCW 16-byte cells per slot).  Besides the barrier-stepped solver waves (sor_sync_wave's schedule,
 // M steps per barrier) the workgroup has
-//   * two LOADER waves (A: D row + plane 0 of C, B: plane 1 of C): in barrier interval I they first wait for the direct-to-
-//     LDS loads (global_load_lds_dwordx4, no VGPRs) they issued in interval I-1, then issue those of the M diagonals of
-//     chunk I + LI.  A chunk is thus known complete after barrier I+1 and visible to everybody from interval c - 1 on; the
-//     first solver wave reads diagonal s+2 <= M*I + M + 1 in interval I  ->  LI = 3.  (With the XCD-local placement of the
-//     data kernel the loads are L2 hits; deeper windows of loads in flight measured no faster.)
+//   * three LOADER waves (the D row + rows 0..63 of C plane 0 | rows 0..63 of plane 1 + rows 64.. of plane 0 | rows 64.. of
+//     plane 1): in barrier interval I they issue the direct-to-LDS loads (global_load_lds_dwordx4, no VGPRs) of the M diagonals
+//     of chunk I + LI and then wait (counted vmcnt) until only that newest chunk is in flight.  A chunk is thus complete
+//     before barrier I+2 and visible to everybody from interval c - 1 on; the first solver wave reads diagonal
+//     s+2 <= M*I + M + 1 in interval I  ->  LI = 3.
 //   * a WRITER wave: in interval J it copies the D rows of chunk J - WO back to global memory, WO = omax/M + 1 (the last
 //     sweep relaxed them in interval J - 1 at the latest, and its stores landed before barrier J).
 // A D slot therefore lives LI + WO + 1 intervals and a C slot LI + omax/M + 1: 36 + 32 slots = 93 KB for 120x68 with
