@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time the video entry point fotg_calc_sequence (off by default: "
                     "its half-size pyramid launches would blur the per-kernel averages of a rocprofv3 --stats run of this command)")
+    ap.add_argument("--scatter-gather", action="store_true", help="multi-rank runs: also time rank 0 scattering the frames of all "
+                    "ranks over RCCL and gathering the flows back (SURVEY 8e); reported beside `value`, never part of it")
     ap.add_argument("--sor-mode", type=int, default=0, help="0 lexicographic (reference order, parity mode), 1 red-black")
     a = ap.parse_args()
 
@@ -280,6 +282,26 @@ def main():
             res["cpu_baseline"]["parity"] = {"pairs_checked": 2, "mean_epe_px": float(np.sqrt((d ** 2).sum(-1)).mean()),
                                              "max_abs_diff": float(np.abs(d).max()), "bit_identical": bool((d == 0).all())}
         print(json.dumps(res))
+    if dist and a.scatter_gather:
+        # end to end with the frames starting on rank 0 and the flows ending there (RCCL over xGMI: scatter + gather only)
+        from flowonthego_amd.shard import gather_flows, scatter_pairs
+        G0 = G1 = None
+        if rank == 0:
+            G0, G1 = I0.repeat((world,) + (1,) * (I0.dim() - 1)), I1.repeat((world,) + (1,) * (I1.dim() - 1))
+        barrier()
+        t0 = time.perf_counter()
+        S0, S1, _ = scatter_pairs(G0, G1, td, src=0, device=dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ofc.calc_batch(S0.contiguous(), S1.contiguous(), None, out)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        full = gather_flows(out, world * a.batch, td, dst=0)
+        barrier()
+        t3 = time.perf_counter()
+        if rank == 0:
+            print(json.dumps({"scatter_gather": {"scatter_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3, "gather_ms": (t3 - t2) * 1e3,
+                                                 "end_to_end_pairs_per_s": world * a.batch / (t3 - t0), "gathered_shape": list(full.shape)}}))
     if dist:
         td.barrier()
         td.destroy_process_group()
