@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""One-off robustness sweep (not part of the test suite): random frame sizes / operating points / channels / switches,
+GPU result against the oracle, bit for bit.  usage: python tools/fuzz_sizes.py [n_cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from conftest import synth_pair
+import flowonthego_amd as F
+from flowonthego_amd.oflow import OFClass
+from oracle import oracle as O
+from test_gpu_parity import oracle_params
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+bad = 0
+for k in range(n):
+    w, h = int(rng.integers(120, 2000)), int(rng.integers(100, 1200))
+    op_point, noc = int(rng.integers(1, 4)), 1 + 2 * int(rng.integers(0, 2))
+    if w * h * noc > 2.2e6:
+        noc = 1
+    f0, f1 = synth_pair(h, w, seed=1000 + k, noc=noc)
+    op = F.operating_point(op_point, w, noc)
+    op.cost_func = int(rng.integers(0, 3)); op.use_fbcon = bool(rng.integers(0, 4) == 0)
+    try:
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    except F.FotgError as e:
+        print(k, (w, h, op_point, noc), "refused:", e); continue
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = ofc.calc(dv(f0), dv(f1)).cpu().numpy()
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    ok = np.array_equal(out, ref)
+    bad += not ok
+    print(k, (w, h, op_point, noc, op.cost_func, op.use_fbcon), "rows@finest", ref.shape[0], "OK" if ok else "MISMATCH max %g" % np.abs(out - ref).max(), flush=True)
+    ofc.close()
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
