@@ -37,48 +37,43 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
   float *dst = which ? dst1 : dst0;
   const int x0 = strip * 256 + lane * 4;     // first of this lane's 4 source pixels (padded coords)
   const bool active = x0 < Wp;               // Wp is a multiple of 4 whenever LV >= 2
-  float v[R][C];
-  if (active) {
+  // one source row (clamped: replicate padding) -> 4 pixels x NOC floats of this lane
+  auto load_row = [&](int r, float (&dstv)[C]) {
+    const int sy = clampi(oy * R + r - top, h_org);
+    const T *row = src + (size_t)sy * w_org * NOC;
+    if constexpr (FAST && sizeof(T) == 1) {
+      // 8-bit frames ("next" row f2 of SURVEY 8f): 4 pixels x NOC bytes = NOC dwords per lane and row; u8 -> f32 is exact
+      const unsigned *p32 = reinterpret_cast<const unsigned *>(row + (size_t)x0 * NOC);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int sy = clampi(oy * R + r - top, h_org);
-      const T *row = src + (size_t)sy * w_org * NOC;
-      if constexpr (FAST && sizeof(T) == 1) {
-        // 8-bit frames ("next" row f2 of SURVEY 8f): 4 pixels x NOC bytes = NOC dwords per lane and row; u8 -> f32 is exact
-        const unsigned *p32 = reinterpret_cast<const unsigned *>(row + (size_t)x0 * NOC);
+      for (int k = 0; k < NOC; ++k) {
+        const unsigned t = NOC == 1 ? __builtin_nontemporal_load(p32 + k) : p32[k];
+        dstv[4 * k] = (float)(t & 0xffu); dstv[4 * k + 1] = (float)((t >> 8) & 0xffu);
+        dstv[4 * k + 2] = (float)((t >> 16) & 0xffu); dstv[4 * k + 3] = (float)(t >> 24);
+      }
+    } else if constexpr (FAST) {
+      // streamed once, never re-read: nontemporal 16-B loads keep the frames out of L2/MALL
+      typedef float vf4 __attribute__((ext_vector_type(4)));
+      const vf4 *p4 = reinterpret_cast<const vf4 *>(reinterpret_cast<const float *>(row) + (size_t)x0 * NOC);
 #pragma unroll
-        for (int k = 0; k < NOC; ++k) {
-          const unsigned t = __builtin_nontemporal_load(p32 + k);
-          v[r][4 * k] = (float)(t & 0xffu); v[r][4 * k + 1] = (float)((t >> 8) & 0xffu);
-          v[r][4 * k + 2] = (float)((t >> 16) & 0xffu); v[r][4 * k + 3] = (float)(t >> 24);
-        }
-      } else if constexpr (FAST) {
-        // streamed once, never re-read: nontemporal 16-B loads keep the frames out of L2/MALL
-        typedef float vf4 __attribute__((ext_vector_type(4)));
-        const vf4 *p4 = reinterpret_cast<const vf4 *>(reinterpret_cast<const float *>(row) + (size_t)x0 * NOC);
+      for (int k = 0; k < NOC; ++k) {
+        // (three channels: a lane's three 16-byte pieces share cache lines with its neighbours' -- keep them cacheable)
+        const vf4 t = NOC == 1 ? __builtin_nontemporal_load(p4 + k) : p4[k];
+        dstv[4 * k] = t.x; dstv[4 * k + 1] = t.y; dstv[4 * k + 2] = t.z; dstv[4 * k + 3] = t.w;
+      }
+    } else {
 #pragma unroll
-        for (int k = 0; k < NOC; ++k) {
-          const vf4 t = __builtin_nontemporal_load(p4 + k);
-          v[r][4 * k] = t.x; v[r][4 * k + 1] = t.y; v[r][4 * k + 2] = t.z; v[r][4 * k + 3] = t.w;
-        }
-      } else {
+      for (int px = 0; px < 4; ++px) {
+        const int sx = clampi(x0 + px - left, w_org);
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          const int sx = clampi(x0 + px - left, w_org);
-#pragma unroll
-          for (int c = 0; c < NOC; ++c) v[r][px * NOC + c] = (float)row[(size_t)sx * NOC + c];
-        }
+        for (int c = 0; c < NOC; ++c) dstv[px * NOC + c] = (float)row[(size_t)sx * NOC + c];
       }
     }
-  } else {
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int k = 0; k < C; ++k) v[r][k] = 0.f;
-  }
+  };
   float *out = dst + (size_t)img * dst_stride;
   if constexpr (LV == 0) {
     if (active) {
+      float v[1][C];
+      load_row(0, v[0]);
 #pragma unroll
       for (int px = 0; px < 4; ++px)
         if (x0 + px < Wp)
@@ -87,18 +82,36 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
     }
     return;
   } else {
-    // level 1: 2 px per lane
+    // level 1: 2 px per lane.  The rows are loaded in groups of 4 (one level-2 row); with three channels at most 8 rows
+    // (24 16-byte loads) are kept in flight per lane -- all 16 would need 192 VGPRs and leave 2 waves per SIMD
+    constexpr int RG = R >= 4 ? 4 : R;                               // rows per group
+    constexpr int NGRP = R / RG;
+    constexpr int GROUPS_IN_FLIGHT = (NOC == 1 || sizeof(T) == 1) ? NGRP : 2;
     float l1[R / 2][2 * NOC];
 #pragma unroll
-    for (int y = 0; y < R / 2; ++y)
+    for (int g = 0; g < NGRP; ++g) {
+      float v[RG][C];
+      if (active) {
 #pragma unroll
-      for (int px = 0; px < 2; ++px)
+        for (int r = 0; r < RG; ++r) load_row(g * RG + r, v[r]);
+      } else {
 #pragma unroll
-        for (int c = 0; c < NOC; ++c) {
-          const float a = v[2 * y][(2 * px) * NOC + c], b = v[2 * y][(2 * px + 1) * NOC + c];
-          const float cc = v[2 * y + 1][(2 * px) * NOC + c], d = v[2 * y + 1][(2 * px + 1) * NOC + c];
-          l1[y][px * NOC + c] = ((a + cc) + (b + d)) * 0.25f;
-        }
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+          for (int k = 0; k < C; ++k) v[r][k] = 0.f;
+      }
+#pragma unroll
+      for (int y = 0; y < RG / 2; ++y)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+          for (int c = 0; c < NOC; ++c) {
+            const float a = v[2 * y][(2 * px) * NOC + c], b = v[2 * y][(2 * px + 1) * NOC + c];
+            const float cc = v[2 * y + 1][(2 * px) * NOC + c], d = v[2 * y + 1][(2 * px + 1) * NOC + c];
+            l1[g * (RG / 2) + y][px * NOC + c] = ((a + cc) + (b + d)) * 0.25f;
+          }
+      if ((g + 1) % GROUPS_IN_FLIGHT == 0 && g + 1 < NGRP) asm volatile("" ::: "memory");   // later rows' loads stay behind this point
+    }
     if constexpr (LV == 1) {
       if (active) {
         const int ox = x0 >> 1;
