@@ -270,6 +270,22 @@ def main():
             res["sequence_mode"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
                                     "note": "%d consecutive f32 frames -> %d flows, one pyramid per frame; informational" % (a.batch + 1, a.batch)}
             del seq
+            # interleaved RGB frames, the layout of the reference's src/ path (channels = 3): own context, same batch
+            op3 = F.operating_point(OP_POINT, W, 3, sor_mode=a.sor_mode)
+            ofc3 = OFClass(op3, F.img_params(width=W, height=H, padding=op3.patch_size), max_batch=a.batch, device=local)
+            R0 = torch.stack([I0, I0.roll(3, 2), I0.roll(5, 1)], -1).contiguous()
+            R1 = torch.stack([I1, I1.roll(3, 2), I1.roll(5, 1)], -1).contiguous()
+            for _ in range(2):
+                ofc3.calc_batch(R0, R1, None, out)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                ofc3.calc_batch(R0, R1, None, out)
+            torch.cuda.synchronize()
+            res["rgb_frames"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
+                                 "note": "same workload with 3-channel interleaved f32 frames (3x the input bytes); informational"}
+            ofc3.close()
+            del R0, R1
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(I0, I1)
             # the same leg also checks the timed batch's result against the oracle ("EPE vs kroeger CPU")
