@@ -181,6 +181,7 @@ dis_grid *dis_grid_new(int w, int h, int lvl, const dis_params *p)
 {
   dis_grid *g = (dis_grid *)calloc(1, sizeof(dis_grid));
   g->w = w; g->h = h; g->ps = p->ps; g->noc = p->noc; g->lvl = lvl;
+  g->depth = p->depth; g->camlr = 0;
   int steps = (int)floor(p->ps * (1 - p->patove));               /* oflow.cpp:91 */
   g->steps = steps > 1 ? steps : 1;
   g->pad = p->ps; g->tmp_w = w + 2 * p->ps;
@@ -236,9 +237,14 @@ void dis_grid_init(dis_grid *g, const dis_params *p, const float *I0, const floa
       for (int e = 0; e < nv; ++e) T[e] -= m;
     }
     float h00 = dis_dot(Tx, Tx, nv, noc, scr);                      /* patch.cpp:74-77 */
-    float h01 = dis_dot(Tx, Ty, nv, noc, scr);
-    float h11 = dis_dot(Ty, Ty, nv, noc, scr);
-    if (h00 * h11 - h01 * h01 == 0) { h00 += 1e-10; h11 += 1e-10; } /* :78-82 (float += double -> float) */
+    float h01 = 0.0f, h11 = 0.0f;
+    if (g->depth) {                                                 /* :83-87: 1x1 Hessian */
+      if (h00 == 0) h00 += 1e-10;
+    } else {
+      h01 = dis_dot(Tx, Ty, nv, noc, scr);
+      h11 = dis_dot(Ty, Ty, nv, noc, scr);
+      if (h00 * h11 - h01 * h01 == 0) { h00 += 1e-10; h11 += 1e-10; } /* :78-82 (float += double -> float) */
+    }
     g->hes[3 * ip] = h00; g->hes[3 * ip + 1] = h01; g->hes[3 * ip + 2] = h11;
     g->p_init[2 * ip] = 0; g->p_init[2 * ip + 1] = 0;               /* patchgrid.cpp:113 */
   }
@@ -252,6 +258,7 @@ void dis_grid_init_from_coarser(dis_grid *g, const float *flow_prev)
     int x = (int)floor(g->pt_ref[2 * ip] / 2);
     int y = (int)floor(g->pt_ref[2 * ip + 1] / 2);
     int i = y * (g->w / 2) + x;
+    if (g->depth) { g->p_init[2 * ip] = flow_prev[i] * 2; continue; }   /* :207-208 */
     g->p_init[2 * ip] = flow_prev[2 * i] * 2;
     g->p_init[2 * ip + 1] = flow_prev[2 * i + 1] * 2;
   }
@@ -314,6 +321,11 @@ void dis_grid_optimize(dis_grid *g, const dis_params *p, const float *I1, float 
     while (!conv) {
       cnt++;
       dp0 = dis_dot(Tx, pdiff, nv, noc, scr);                        /* :178-179 */
+      if (g->depth) {                                                /* :181, :184 with the 1x1 Hessian: L = sqrt(H) */
+        float l00 = sqrtf(h00);
+        float y0 = dp0 / l00;
+        dp0 = y0 / l00; dp1 = 0.0f;
+      } else {
       dp1 = dis_dot(Ty, pdiff, nv, noc, scr);
       {                                                              /* :184 Hes.llt().solve() */
         float l00 = sqrtf(h00);
@@ -325,7 +337,12 @@ void dis_grid_optimize(dis_grid *g, const dis_params *p, const float *I1, float 
         float x0 = (y0 - l10 * x1) / l00;
         dp0 = x0; dp1 = x1;
       }
+      }
       p0 -= dp0; p1 -= dp1;                                          /* :186 */
+      if (g->depth) {                                                /* :188-193: std::min / std::max with 0 */
+        if (g->camlr == 0) p0 = (0.0f < p0) ? 0.0f : p0;
+        else p0 = (p0 < 0.0f) ? 0.0f : p0;
+      }
       ptx = rx + p0; pty = ry + p1;
       {
         float ddx = stx - ptx, ddy = sty - pty;
@@ -376,8 +393,9 @@ void dis_grid_aggregate_fb(const dis_grid *g, const dis_grid *cg, const dis_para
 {
   const int ps = g->ps, noc = g->noc, nv = ps * ps * noc, w = g->w, h = g->h;
   const float minerr = 2.0f;                                         /* oflow.h:62 */
+  const int np = g->depth ? 1 : 2;                                   /* op->nop (oflow.cpp:76-80) */
   float *we = (float *)calloc((size_t)w * h, sizeof(float));
-  memset(flowout, 0, sizeof(float) * 2 * (size_t)w * h);
+  memset(flowout, 0, sizeof(float) * np * (size_t)w * h);
   (void)p;
   for (int ip = 0; ip < g->nop; ++ip) {
     const float f0 = g->p_iter[2 * ip], f1 = g->p_iter[2 * ip + 1];
@@ -399,6 +417,7 @@ void dis_grid_aggregate_fb(const dis_grid *g, const dis_grid *cg, const dis_para
           absw = 1.0f / absw;
         }
         we[i] += absw;
+        if (np == 1) { flowout[i] += f0 * absw; continue; }          /* :268 */
         flowout[2 * i] += f0 * absw;
         flowout[2 * i + 1] += f1 * absw;
       }
@@ -429,6 +448,10 @@ void dis_grid_aggregate_fb(const dis_grid *g, const dis_grid *cg, const dis_para
         const float n0 = f0 * absw, n1 = f1 * absw;
         const int cc = xt + yt * w, fc = (xt - 1) + yt * w, cf = xt + (yt - 1) * w, ff = (xt - 1) + (yt - 1) * w;
         we[cc] += wb0 * absw; we[fc] += wb1 * absw; we[cf] += wb2 * absw; we[ff] += wb3 * absw;
+        if (np == 1) {                                               /* :365-368 */
+          flowout[cc] -= wb0 * n0; flowout[fc] -= wb1 * n0; flowout[cf] -= wb2 * n0; flowout[ff] -= wb3 * n0;
+          continue;
+        }
         flowout[2 * cc] -= wb0 * n0; flowout[2 * cc + 1] -= wb0 * n1;
         flowout[2 * fc] -= wb1 * n0; flowout[2 * fc + 1] -= wb1 * n1;
         flowout[2 * cf] -= wb2 * n0; flowout[2 * cf + 1] -= wb2 * n1;
@@ -436,7 +459,10 @@ void dis_grid_aggregate_fb(const dis_grid *g, const dis_grid *cg, const dis_para
       }
     }
   }
-  for (int i = 0; i < w * h; ++i) if (we[i] > 0) { flowout[2 * i] /= we[i]; flowout[2 * i + 1] /= we[i]; }
+  for (int i = 0; i < w * h; ++i) if (we[i] > 0) {
+    if (np == 1) flowout[i] /= we[i];
+    else { flowout[2 * i] /= we[i]; flowout[2 * i + 1] /= we[i]; }
+  }
   free(we);
 }
 
@@ -781,6 +807,139 @@ void dis_varref(const float *I0, const float *I1, int w, int h, int lvl, const d
   free(buf); free(b2);
 }
 
+
+/* ------------------------------------------------------------------------------------------- */
+/* stereo depth (SELECTMODE 2) variants                                                        */
+/* ------------------------------------------------------------------------------------------- */
+
+/* FDF1.0.1/opticalflow_aux.c:446-540 compute_data_DE: only the horizontal increment du enters */
+void dis_compute_data_de(float *a11, float *b1, const float *mask, const float *du,
+                         const float *Ix, const float *Iy, const float *Iz, const float *Ixx,
+                         const float *Ixy, const float *Iyy, const float *Ixz, const float *Iyz,
+                         int w, int h, int noc, float half_delta_over3, float half_gamma_over3)
+{
+  const int st = dis_stride(w); const size_t pl = (size_t)st * h;
+  const float dnorm = 0.1f * 0.1f, epsc = 0.001f * 0.001f, epsg = 0.001f * 0.001f;
+  for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) {
+    const int o = j * st + i;
+    float A11 = 0, B1 = 0;
+    const float u = du[o], m = mask[o];
+    if (noc == 1) {
+      float tmp, tmp2, n1, n2;
+      if (half_delta_over3) {                                          /* :481-506 */
+        tmp = Iz[o] + Ix[o] * u;
+        n1 = Ix[o] * Ix[o] + Iy[o] * Iy[o] + dnorm;
+        tmp = m * half_delta_over3 / sqrtf(3 * tmp * tmp / n1 + epsc);
+        tmp /= n1;
+        A11 += tmp * Ix[o] * Ix[o];
+        B1 -= tmp * Iz[o] * Ix[o];
+      }
+      n1 = Ixx[o] * Ixx[o] + Ixy[o] * Ixy[o] + dnorm;                  /* :508-511 */
+      n2 = Iyy[o] * Iyy[o] + Ixy[o] * Ixy[o] + dnorm;
+      tmp = Ixz[o] + Ixx[o] * u;
+      tmp2 = Iyz[o] + Ixy[o] * u;
+      tmp = m * half_gamma_over3 / sqrtf(3 * tmp * tmp / n1 + 3 * tmp2 * tmp2 / n2 + epsg);   /* :524 */
+      tmp2 = tmp / n2; tmp /= n1;
+      A11 += tmp * Ixx[o] * Ixx[o] + tmp2 * Ixy[o] * Ixy[o];           /* :527-528 */
+      B1 -= tmp * Ixx[o] * Ixz[o] + tmp2 * Ixy[o] * Iyz[o];
+      A11 *= 3; B1 *= 3;                                               /* :537-540 */
+    } else {
+      float t[3], n[3];
+      if (half_delta_over3) {
+        for (int c = 0; c < 3; ++c) {
+          const size_t q = c * pl + o;
+          t[c] = Iz[q] + Ix[q] * u;
+          n[c] = Ix[q] * Ix[q] + Iy[q] * Iy[q] + dnorm;
+        }
+        float tmp = m * half_delta_over3 / sqrtf(t[0] * t[0] / n[0] + t[1] * t[1] / n[1] + t[2] * t[2] / n[2] + epsc);   /* :493 */
+        const float k3 = tmp / n[2], k2 = tmp / n[1]; tmp /= n[0];
+        const float k[3] = {tmp, k2, k3};
+        for (int c = 0; c < 3; ++c) {                                  /* :499-506: a11 += ..; b1 -= ..; channel by channel */
+          const size_t q = c * pl + o;
+          A11 += k[c] * Ix[q] * Ix[q];
+          B1 -= k[c] * Iz[q] * Ix[q];
+        }
+      }
+      float n1[3], n2[3], t1[3], t2[3];
+      for (int c = 0; c < 3; ++c) {
+        const size_t q = c * pl + o;
+        n1[c] = Ixx[q] * Ixx[q] + Ixy[q] * Ixy[q] + dnorm; n2[c] = Iyy[q] * Iyy[q] + Ixy[q] * Ixy[q] + dnorm;
+        t1[c] = Ixz[q] + Ixx[q] * u;                       t2[c] = Iyz[q] + Ixy[q] * u;
+      }
+      const float tmp = m * half_gamma_over3 / sqrtf(t1[0] * t1[0] / n1[0] + t2[0] * t2[0] / n2[0] + t1[1] * t1[1] / n1[1] +
+                                                     t2[1] * t2[1] / n2[1] + t1[2] * t1[2] / n1[2] + t2[2] * t2[2] / n2[2] + epsg);   /* :521 */
+      for (int c = 0; c < 3; ++c) {                                    /* :527-535 */
+        const size_t q = c * pl + o;
+        const float ka = tmp / n1[c], kb = tmp / n2[c];
+        A11 += ka * Ixx[q] * Ixx[q] + kb * Ixy[q] * Ixy[q];
+        B1 -= ka * Ixx[q] * Ixz[q] + kb * Ixy[q] * Iyz[q];
+      }
+    }
+    a11[o] = A11; b1[o] = B1;
+  }
+}
+
+/* FDF1.0.1/solver.c:428-466 sor_coupled_slow_but_readable_DE; the default build has no OpenMP, so the row loop is serial:
+ * lexicographic Gauss-Seidel.  Neighbour order of the sums: top, left, bottom, right. */
+void dis_sor_de(float *du, const float *a11, const float *b1, const float *horiz, const float *vert,
+                int w, int h, int iterations, float omega)
+{
+  const int st = dis_stride(w);
+  for (int it = 0; it < iterations; ++it)
+    for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) {
+      const int o = j * st + i;
+      float sigma_u = 0.0f, sum_dpsis = 0.0f;
+      if (j > 0)     { sigma_u -= vert[o - st] * du[o - st]; sum_dpsis += vert[o - st]; }
+      if (i > 0)     { sigma_u -= horiz[o - 1] * du[o - 1];  sum_dpsis += horiz[o - 1]; }
+      if (j < h - 1) { sigma_u -= vert[o] * du[o + st];      sum_dpsis += vert[o]; }
+      if (i < w - 1) { sigma_u -= horiz[o] * du[o + 1];      sum_dpsis += horiz[o]; }
+      const float A11 = a11[o] + sum_dpsis;
+      const float B1 = b1[o] - sigma_u;
+      du[o] = (1.0f - omega) * du[o] + omega * (B1 / A11);
+    }
+}
+
+/* kroeger/refine_variational.cpp:25-116 (ctor with noparam = 1), :243-330 RefLevelDE */
+void dis_varref_depth(const float *I0, const float *I1, int w, int h, int lvl, const dis_params *p,
+                      float *flow, int camlr)
+{
+  const int st = dis_stride(w), noc = p->noc, pad = p->ps, tmp_w = w + 2 * pad;
+  const size_t pl = (size_t)st * h;
+  const float quarter_alpha = 0.25f * p->tv_alpha;
+  const float half_gamma_over3 = p->tv_gamma * 0.5f / 3.0f;
+  const float half_delta_over3 = p->tv_delta * 0.5f / 3.0f;
+  const int inner = p->tv_innerit * (lvl + 1);
+  float *buf = (float *)calloc(pl * (9 + 11 * noc), sizeof(float));
+  float *wx = buf, *wy0 = wx + pl, *du = wy0 + pl, *mask = du + pl, *sh = mask + pl, *sv = sh + pl, *uu = sv + pl,
+        *a11 = uu + pl, *b1 = a11 + pl;
+  float *im1 = b1 + pl, *im2 = im1 + pl * noc, *w2 = im2 + pl * noc, *Ix = w2 + pl * noc,
+        *Iy = Ix + pl * noc, *Iz = Iy + pl * noc, *Ixx = Iz + pl * noc, *Ixy = Ixx + pl * noc,
+        *Iyy = Ixy + pl * noc, *Ixz = Iyy + pl * noc, *Iyz = Ixz + pl * noc;
+  for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) {
+    wx[j * st + i] = flow[j * w + i];                                 /* :58-66, noparam = 1 */
+    for (int c = 0; c < noc; ++c) {
+      size_t s = ((size_t)(j + pad) * tmp_w + (i + pad)) * noc + c;
+      im1[c * pl + j * st + i] = I0[s]; im2[c * pl + j * st + i] = I1[s];
+    }
+  }
+  dis_image_warp(w2, mask, im2, wx, wy0, w, h, noc);                  /* :273, wy_dummy = 0 */
+  dis_get_derivatives(im1, w2, w, h, noc, Ix, Iy, Iz, Ixx, Ixy, Iyy, Ixz, Iyz);
+  memcpy(uu, wx, pl * sizeof(float));
+  for (int it = 0; it < inner; ++it) {
+    dis_compute_smoothness(sh, sv, uu, wy0, w, h, quarter_alpha);     /* :288 */
+    dis_compute_data_de(a11, b1, mask, du, Ix, Iy, Iz, Ixx, Ixy, Iyy, Ixz, Iyz, w, h, noc, half_delta_over3, half_gamma_over3);
+    dis_sub_laplacian(b1, wx, sh, sv, w, h);
+    dis_sor_de(du, a11, b1, sh, sv, w, h, p->tv_solverit, p->tv_sor);
+    for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) {         /* :299-314 minps / maxps with zero */
+      const int o = j * st + i;
+      const float s = wx[o] + du[o];
+      uu[o] = camlr == 0 ? (s < 0.0f ? s : 0.0f) : (s > 0.0f ? s : 0.0f);
+    }
+  }
+  for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) flow[j * w + i] = uu[j * st + i];
+  free(buf);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* whole flow: kroeger/oflow.cpp:184-337                                                       */
 /* ------------------------------------------------------------------------------------------- */
@@ -788,15 +947,16 @@ void dis_varref(const float *I0, const float *I1, int w, int h, int lvl, const d
 void dis_flow_pyr(const dis_pyramid *P0, const dis_pyramid *P1, const dis_params *p,
                   const float *initflow, float *outflow, int sor_mode, float *level_dump)
 {
-  const int ns = p->sc_f - p->sc_l + 1, fb = p->usefbcon != 0;
+  const int ns = p->sc_f - p->sc_l + 1, fb = p->usefbcon != 0, np = p->depth ? 1 : 2;
   float **flow = (float **)calloc(ns, sizeof(float *)), **flow_bw = (float **)calloc(ns, sizeof(float *));
   size_t dump_off = 0;
   for (int sl = p->sc_f; sl >= p->sc_l; --sl) {
     const int ii = sl - p->sc_l, w = dis_level_w(P0, sl), h = dis_level_h(P0, sl);
     dis_grid *g = dis_grid_new(w, h, sl, p), *gb = fb ? dis_grid_new(w, h, sl, p) : NULL;   /* oflow.cpp:160-170 */
-    flow[ii] = (float *)malloc(sizeof(float) * 2 * (size_t)w * h);
+    flow[ii] = (float *)malloc(sizeof(float) * np * (size_t)w * h);
+    if (gb) gb->camlr = 1;                                            /* oflow.cpp:157,165 */
     dis_grid_init(g, p, P0->im[sl], P0->dx[sl], P0->dy[sl]);
-    if (fb) { flow_bw[ii] = (float *)malloc(sizeof(float) * 2 * (size_t)w * h); dis_grid_init(gb, p, P1->im[sl], P1->dx[sl], P1->dy[sl]); }   /* :193-197 */
+    if (fb) { flow_bw[ii] = (float *)malloc(sizeof(float) * np * (size_t)w * h); dis_grid_init(gb, p, P1->im[sl], P1->dx[sl], P1->dy[sl]); }   /* :193-197 */
     if (sl < p->sc_f) { dis_grid_init_from_coarser(g, flow[ii + 1]); if (fb) dis_grid_init_from_coarser(gb, flow_bw[ii + 1]); }   /* :209-216 */
     else if (initflow) dis_grid_init_from_coarser(g, initflow);
     dis_grid_optimize(g, p, P1->im[sl], NULL);
@@ -804,12 +964,15 @@ void dis_flow_pyr(const dis_pyramid *P0, const dis_pyramid *P1, const dis_params
     float *out = (sl == p->sc_l) ? outflow : flow[ii];
     dis_grid_aggregate_fb(g, gb, p, out);
     if (fb && sl > p->sc_l) dis_grid_aggregate_fb(gb, g, p, flow_bw[ii]);                 /* :269-270 */
-    if (level_dump) { memcpy(level_dump + dump_off, out, sizeof(float) * 2 * (size_t)w * h); dump_off += 2 * (size_t)w * h; }
-    if (p->usetvref) {
+    if (level_dump) { memcpy(level_dump + dump_off, out, sizeof(float) * np * (size_t)w * h); dump_off += np * (size_t)w * h; }
+    if (p->usetvref && p->depth) {                                    /* :287-294 with RefLevelDE */
+      dis_varref_depth(P0->im[sl], P1->im[sl], w, h, sl, p, out, 0);
+      if (fb && sl > p->sc_l) dis_varref_depth(P1->im[sl], P0->im[sl], w, h, sl, p, flow_bw[ii], 1);
+    } else if (p->usetvref) {
       dis_varref(P0->im[sl], P1->im[sl], w, h, sl, p, out, sor_mode);
       if (fb && sl > p->sc_l) dis_varref(P1->im[sl], P0->im[sl], w, h, sl, p, flow_bw[ii], sor_mode);   /* :291-294 */
     }
-    if (level_dump) { memcpy(level_dump + dump_off, out, sizeof(float) * 2 * (size_t)w * h); dump_off += 2 * (size_t)w * h; }
+    if (level_dump) { memcpy(level_dump + dump_off, out, sizeof(float) * np * (size_t)w * h); dump_off += np * (size_t)w * h; }
     dis_grid_free(g);
     if (gb) dis_grid_free(gb);
   }
@@ -830,6 +993,12 @@ void dis_flow(const float *I0, const float *I1, int wp, int hp, const dis_params
 void dis_upsample_crop(const float *flow, int wl, int hl, int sc_l, int padw, int padh,
                        int w_org, int h_org, float *out)
 {
+  dis_upsample_crop_n(flow, wl, hl, sc_l, padw, padh, w_org, h_org, 2, out);
+}
+
+void dis_upsample_crop_n(const float *flow, int wl, int hl, int sc_l, int padw, int padh,
+                         int w_org, int h_org, int nch, float *out)
+{
   const int s = 1 << sc_l, W = wl * s;
   const int x0 = padw / 2, y0 = padh / 2;
   const float scf = (float)s;
@@ -849,13 +1018,13 @@ void dis_upsample_crop(const float *flow, int wl, int hl, int sc_l, int padw, in
       if (sx >= wl - 1) { fx = 0; sx = wl - 1; }
       int sx1 = sx + 1 < wl ? sx + 1 : wl - 1;
       (void)W;
-      for (int c = 0; c < 2; ++c) {
-        float v00 = flow[2 * (sy * wl + sx) + c], v01 = flow[2 * (sy * wl + sx1) + c];
-        float v10 = flow[2 * (sy1 * wl + sx) + c], v11 = flow[2 * (sy1 * wl + sx1) + c];
+      for (int c = 0; c < nch; ++c) {
+        float v00 = flow[nch * (sy * wl + sx) + c], v01 = flow[nch * (sy * wl + sx1) + c];
+        float v10 = flow[nch * (sy1 * wl + sx) + c], v11 = flow[nch * (sy1 * wl + sx1) + c];
         if (sc_l != 0) { v00 *= scf; v01 *= scf; v10 *= scf; v11 *= scf; }
         float r0 = v00 * (1.f - fx) + v01 * fx;
         float r1 = v10 * (1.f - fx) + v11 * fx;
-        out[2 * ((size_t)y * w_org + x) + c] = r0 * (1.f - fy) + r1 * fy;
+        out[nch * ((size_t)y * w_org + x) + c] = r0 * (1.f - fy) + r1 * fy;
       }
     }
   }

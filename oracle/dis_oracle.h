@@ -44,6 +44,8 @@ typedef struct dis_params {
   int costfct;       /* oflow.h:45: 0 L2, 1 L1, 2 pseudo-Huber (patch.cpp:230-261); the operating points use 0 */
   float normoutlier; /* oflow.h:63: 5.0, Huber threshold b */
   int usefbcon;      /* oflow.h:44: merge forward and backward flow (patchgrid.cpp:278-375); the operating points use 0 */
+  int depth;         /* 0: optical flow (SELECTMODE 1); 1: stereo depth (SELECTMODE 2): one horizontal displacement per
+                        pixel/patch (oflow.cpp:76-80 nop = 1), flow arrays have ONE channel */
 } dis_params;
 
 /* kroeger/run_dense.cpp:180-183 and :225-268.  op in 1..4 (anything else -> 2). */
@@ -84,6 +86,9 @@ typedef struct dis_grid {
   float *p_iter;   /* nop x 2 : result */
   float *pweight;  /* nop x novals */
   int   *cnt;      /* nop : iterations run */
+  int depth;       /* copy of dis_params.depth */
+  int camlr;       /* oflow.h:28, oflow.cpp:153,157: 0 for the forward grid (displacement <= 0), 1 for the backward grid (>= 0);
+                      only read in depth mode (patch.cpp:188-193) */
 } dis_grid;
 dis_grid *dis_grid_new(int w, int h, int lvl, const dis_params *p);
 void dis_grid_free(dis_grid *g);
@@ -123,8 +128,20 @@ void dis_sor_coupled_redblack(float *du, float *dv, float *a11, float *a12, floa
 /* whole VarRefClass ctor: I0/I1 padded level images, flow w x h x 2 interleaved, in place */
 void dis_varref(const float *I0, const float *I1, int w, int h, int lvl, const dis_params *p,
                 float *flow, int sor_mode /*0 lexicographic (reference), 1 red-black*/);
+/* stereo depth (SELECTMODE 2): compute_data_DE (opticalflow_aux.c:446-540), sor_coupled_slow_but_readable_DE
+ * (solver.c:428-466, serial = lexicographic Gauss-Seidel) and RefLevelDE (refine_variational.cpp:243-330);
+ * flow is w x h x 1, camlr selects the sign clamp of the update (:299-314) */
+void dis_compute_data_de(float *a11, float *b1, const float *mask, const float *du,
+                         const float *Ix, const float *Iy, const float *Iz, const float *Ixx,
+                         const float *Ixy, const float *Iyy, const float *Ixz, const float *Iyz,
+                         int w, int h, int noc, float half_delta_over3, float half_gamma_over3);
+void dis_sor_de(float *du, const float *a11, const float *b1, const float *horiz, const float *vert,
+                int w, int h, int iterations, float omega);
+void dis_varref_depth(const float *I0, const float *I1, int w, int h, int lvl, const dis_params *p,
+                      float *flow, int camlr);
 
 /* ---- whole flow: OFClass ctor (kroeger/oflow.cpp:32-363) on prebuilt pyramids ---- */
+/* flows (initflow, outflow, level_dump) have 2 channels, or 1 in depth mode */
 void dis_flow_pyr(const dis_pyramid *P0, const dis_pyramid *P1, const dis_params *p,
                   const float *initflow, float *outflow, int sor_mode,
                   float *level_dump /* optional: concatenated pre/post-refinement flows */);
@@ -134,6 +151,9 @@ void dis_flow(const float *I0, const float *I1, int wp, int hp, const dis_params
 /* kroeger/run_dense.cpp:407-414: *2^sc_l, bilinear x2^sc_l (cv::resize INTER_LINEAR), crop */
 void dis_upsample_crop(const float *flow, int wl, int hl, int sc_l, int padw, int padh,
                        int w_org, int h_org, float *out);
+/* the same for nch interleaved channels (depth mode: 1, run_dense.cpp:387-388) */
+void dis_upsample_crop_n(const float *flow, int wl, int hl, int sc_l, int padw, int padh,
+                         int w_org, int h_org, int nch, float *out);
 
 #ifdef __cplusplus
 }

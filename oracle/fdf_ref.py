@@ -46,6 +46,10 @@ class FdfRef:
         L.compute_data.argtypes = [C.c_void_p] * 20 + [C.c_float] * 3
         L.sor_coupled.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_float]
         L.sor_coupled_slow_but_readable.argtypes = L.sor_coupled.argtypes
+        # stereo depth variants (SELECTMODE 2 callers, refine_variational.cpp:243-330); the FDF sources do not depend on
+        # SELECTMODE, so the same library carries them
+        L.compute_data_DE.argtypes = [C.c_void_p] * 14 + [C.c_float] * 3
+        L.sor_coupled_slow_but_readable_DE.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_float]
         d5 = (C.c_float * 3)(0.0, -8.0 / 12.0, 1.0 / 12.0)       # refine_variational.cpp:45-46
         d3 = (C.c_float * 2)(0.0, -0.5)                           # :47-48
         self.deriv = L.convolution_new(2, d5, 0)
@@ -143,3 +147,38 @@ class FdfRef:
         self.free(I1, I2, WX, WY, du, dv, mask, sh, sv, uu, vv, a11, a12, a22, b1, b2,
                   w2, Ix, Iy, Iz, Ixx, Ixy, Iyy, Ixz, Iyz)
         return ox, oy
+
+    # ---- kroeger/refine_variational.cpp:243-330 (SELECTMODE 2) ----
+    def ref_level_de(self, im1, im2, wx, lvl, camlr=0, alpha=10.0, gamma=10.0, delta=5.0, innerit=1,
+                     solverit=3, omega=1.6, dump=None):
+        """stereo depth refinement of one level: im1, im2 (noc,h,w); wx (h,w) horizontal displacement.  Every arithmetic
+        step except the clamped update uu = min/max(wx+du, 0) (:299-314, numpy float32) executes reference code."""
+        L, noc = self.L, self.noc
+        _, h, w = im1.shape
+        f = np.float32
+        qa = f(0.25) * f(alpha)
+        hg = f(gamma) * f(0.5) / f(3.0)
+        hd = f(delta) * f(0.5) / f(3.0)
+        I1, I2 = self.from_planar(im1), self.from_planar(im2)
+        WX = self.from_plane(wx)
+        du, wy0, mask, sh, sv, uu, a11, b1 = [self.new(w, h) for _ in range(8)]
+        w2, Ix, Iy, Iz, Ixx, Ixy, Iyy, Ixz, Iyz = [self.newc(w, h) for _ in range(9)]
+        L.image_warp(w2, mask, I2, WX, wy0)
+        L.get_derivatives(I1, w2, self.deriv, Ix, Iy, Iz, Ixx, Ixy, Iyy, Ixz, Iyz)
+        self.view(uu)[...] = self.view(WX)
+        inner = innerit * (lvl + 1)
+        for it in range(inner):
+            L.compute_smoothness(sh, sv, uu, wy0, self.deriv_flow, float(qa))
+            L.compute_data_DE(a11, b1, mask, WX, du, uu, Ix, Iy, Iz, Ixx, Ixy, Iyy, Ixz, Iyz, float(hd), 0.0, float(hg))
+            L.sub_laplacian(b1, WX, sh, sv)
+            if dump is not None and it == inner - 1:
+                for k, im in (("sh", sh), ("sv", sv), ("a11", a11), ("b1", b1), ("du_in", du)):
+                    dump[k] = self.view(im)[:, :w].copy()
+            L.sor_coupled_slow_but_readable_DE(du, a11, b1, sh, sv, solverit, float(omega))
+            s = self.view(WX) + self.view(du)
+            self.view(uu)[...] = np.where(s < 0, s, f(0)) if camlr == 0 else np.where(s > 0, s, f(0))
+        if dump is not None:
+            dump["du"] = self.view(du)[:, :w].copy()
+        ox = self.view(uu)[:, :w].copy()
+        self.free(I1, I2, WX, du, wy0, mask, sh, sv, uu, a11, b1, w2, Ix, Iy, Iz, Ixx, Ixy, Iyy, Ixz, Iyz)
+        return ox

@@ -23,7 +23,7 @@ class DisParams(C.Structure):
                 ("noc", C.c_int), ("usetvref", C.c_int), ("tv_alpha", C.c_float),
                 ("tv_gamma", C.c_float), ("tv_delta", C.c_float), ("tv_innerit", C.c_int),
                 ("tv_solverit", C.c_int), ("tv_sor", C.c_float),
-                ("costfct", C.c_int), ("normoutlier", C.c_float), ("usefbcon", C.c_int)]
+                ("costfct", C.c_int), ("normoutlier", C.c_float), ("usefbcon", C.c_int), ("depth", C.c_int)]
 
 
 class DisPyramid(C.Structure):
@@ -37,7 +37,7 @@ class DisGrid(C.Structure):
                 ("tmp_w", C.c_int), ("lvl", C.c_int), ("lb", C.c_float), ("ubw", C.c_float),
                 ("ubh", C.c_float), ("pt_ref", f32p), ("p_init", f32p), ("tmpl", f32p), ("tdx", f32p),
                 ("tdy", f32p), ("hes", f32p), ("p_iter", f32p), ("pweight", f32p),
-                ("cnt", C.POINTER(C.c_int))]
+                ("cnt", C.POINTER(C.c_int)), ("depth", C.c_int), ("camlr", C.c_int)]
 
 
 def build(force=False):
@@ -130,9 +130,11 @@ class Pyramid:
 
 
 class Grid:
-    def __init__(self, w, h, lvl, params):
+    def __init__(self, w, h, lvl, params, camlr=0):
         self.params = params
         self.ptr = lib().dis_grid_new(w, h, lvl, C.byref(params))
+        self.ptr.contents.camlr = camlr
+        self.np = 1 if params.depth else 2
         g = self.ptr.contents
         self.nop, self.nopw, self.noph, self.steps = g.nop, g.nopw, g.noph, g.steps
         self.nv = params.ps * params.ps * params.noc
@@ -158,8 +160,13 @@ class Grid:
         return tr
 
     def aggregate(self):
-        out = np.zeros((self.h, self.w, 2), np.float32)
+        out = np.zeros((self.h, self.w, self.np), np.float32)
         lib().dis_grid_aggregate(self.ptr, C.byref(self.params), P(out))
+        return out
+
+    def aggregate_fb(self, cg):
+        out = np.zeros((self.h, self.w, self.np), np.float32)
+        lib().dis_grid_aggregate_fb(self.ptr, cg.ptr, C.byref(self.params), P(out))
         return out
 
     @property
@@ -195,16 +202,25 @@ def varref(I0_lvl, I1_lvl, w, h, lvl, params, flow, sor_mode=0):
     return flow
 
 
+def varref_depth(I0_lvl, I1_lvl, w, h, lvl, params, flow, camlr=0):
+    """RefLevelDE on a (h, w, 1) displacement field"""
+    flow = f32(flow).copy()
+    a, b = f32(I0_lvl), f32(I1_lvl)
+    lib().dis_varref_depth(P(a), P(b), w, h, lvl, C.byref(params), P(flow), int(camlr))
+    return flow
+
+
 def flow_pyr(P0, P1, params, sor_mode=0, dump=False, initflow=None):
     """OFClass ctor on prebuilt pyramids -> finest-scale flow (h_l, w_l, 2) [+ per-level dump list]
     initflow: optional (h/2^(sc_f+1), w/2^(sc_f+1), 2) warm start (kroeger/oflow.cpp:217-220)"""
     w, h = P0.level_wh(params.sc_l)
+    nch = 1 if params.depth else 2
     if initflow is not None:
         initflow = f32(initflow)
-    out = np.zeros((h, w, 2), np.float32)
+    out = np.zeros((h, w, nch), np.float32)
     d = None
     if dump:
-        tot = sum(2 * 2 * (P0.w0 >> l) * (P0.h0 >> l) for l in range(params.sc_l, params.sc_f + 1))
+        tot = sum(2 * nch * (P0.w0 >> l) * (P0.h0 >> l) for l in range(params.sc_l, params.sc_f + 1))
         d = np.zeros(tot, np.float32)
     lib().dis_flow_pyr(P0.ptr, P1.ptr, C.byref(params), P(initflow) if initflow is not None else None, P(out), int(sor_mode),
                        P(d) if dump else None)
@@ -212,8 +228,8 @@ def flow_pyr(P0, P1, params, sor_mode=0, dump=False, initflow=None):
         return out
     lv, off = {}, 0
     for l in range(params.sc_f, params.sc_l - 1, -1):
-        n = 2 * (P0.w0 >> l) * (P0.h0 >> l)
-        shp = (P0.h0 >> l, P0.w0 >> l, 2)
+        n = nch * (P0.w0 >> l) * (P0.h0 >> l)
+        shp = (P0.h0 >> l, P0.w0 >> l, nch)
         lv[l] = (d[off:off + n].reshape(shp).copy(), d[off + n:off + 2 * n].reshape(shp).copy())
         off += 2 * n
     return out, lv
@@ -223,16 +239,16 @@ def flow(I0p, I1p, params, sor_mode=0):
     """padded frames (hp, wp[, noc]) -> finest-scale flow (pyramid + OFClass)"""
     I0p, I1p = f32(I0p), f32(I1p)
     hp, wp = I0p.shape[:2]
-    out = np.zeros((hp >> params.sc_l, wp >> params.sc_l, 2), np.float32)
+    out = np.zeros((hp >> params.sc_l, wp >> params.sc_l, 1 if params.depth else 2), np.float32)
     lib().dis_flow(P(I0p), P(I1p), wp, hp, C.byref(params), P(out), int(sor_mode))
     return out
 
 
 def upsample_crop(fl, sc_l, padw, padh, w_org, h_org):
     fl = f32(fl)
-    hl, wl = fl.shape[:2]
-    out = np.zeros((h_org, w_org, 2), np.float32)
-    lib().dis_upsample_crop(P(fl), wl, hl, sc_l, padw, padh, w_org, h_org, P(out))
+    hl, wl, nch = fl.shape
+    out = np.zeros((h_org, w_org, nch), np.float32)
+    lib().dis_upsample_crop_n(P(fl), wl, hl, sc_l, padw, padh, w_org, h_org, nch, P(out))
     return out
 
 

@@ -10,6 +10,7 @@ plain data and travel to the GPU box.
   fdf_ref_gray.npz      inputs and OUTPUTS OF THE REFERENCE'S OWN FDF1.0.1 CODE (oracle/_ref) for the
   fdf_ref_rgb.npz       variational-refinement chain (kroeger/refine_variational.cpp:153-241):
                         every intermediate plane of the last inner iteration + the refined flow
+  fdf_ref_depth_*.npz   the same inputs through the reference's stereo-depth chain (RefLevelDE, :243-330)
 """
 import os
 import sys
@@ -80,6 +81,25 @@ def fdf_cases(noc):
     return out
 
 
+def depth_cases(noc):
+    """stereo depth (SELECTMODE 2) refinement: same inputs as fdf_cases (read back from its fixture), outputs of the
+    reference's compute_data_DE / sor_coupled_slow_but_readable_DE chain (RefLevelDE) for both camera sides.
+    The start displacement is -|wx| for the left camera (camlr 0, disparity <= 0) and +|wx| for the right one."""
+    ref = R.FdfRef(noc)
+    z = np.load(os.path.join(OUT, "fdf_ref_%s.npz" % ("gray" if noc == 1 else "rgb")))
+    out = {}
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        im1, im2, wx, lvl = z[name + "/im1"], z[name + "/im2"], z[name + "/wx"], int(z[name + "/lvl"])
+        for camlr in (0, 1):
+            dump = {}
+            w0 = (-np.abs(wx) if camlr == 0 else np.abs(wx)).astype(np.float32)
+            ox = ref.ref_level_de(im1, im2, w0, lvl, camlr=camlr, dump=dump)
+            out["%s/out_de%d" % (name, camlr)] = ox
+            for k, v in dump.items():
+                out["%s/%s_de%d" % (name, k, camlr)] = v
+    return out
+
+
 def main():
     a0 = rgb(REF + "/images/alley_1/frame_0001.png")
     a1 = rgb(REF + "/images/alley_1/frame_0002.png")
@@ -89,6 +109,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "alley_0001_flo.npz"), flow=gold)
     np.savez_compressed(os.path.join(OUT, "fdf_ref_gray.npz"), **fdf_cases(1))
     np.savez_compressed(os.path.join(OUT, "fdf_ref_rgb.npz"), **fdf_cases(3))
+    np.savez_compressed(os.path.join(OUT, "fdf_ref_depth_gray.npz"), **depth_cases(1))
+    np.savez_compressed(os.path.join(OUT, "fdf_ref_depth_rgb.npz"), **depth_cases(3))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

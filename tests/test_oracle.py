@@ -206,3 +206,72 @@ def test_dis_sum_order():
         t = t + t[np.arange(64) ^ k]
         k <<= 1
     assert O.lib().dis_sum(O.P(v), 64, 1) == t[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stereo depth (SELECTMODE 2)
+# ---------------------------------------------------------------------------------------------------------------
+def depth_params(op, width, noc=1):
+    p = O.op_point(op, width, noc)
+    p.depth = 1
+    return p
+
+
+def _padlvl(a, ps=8):
+    return np.pad(a.transpose(1, 2, 0), ((ps, ps), (ps, ps), (0, 0)), mode="edge")
+
+
+@pytest.mark.parametrize("noc", [1, 3])
+def test_depth_fdf_golden_vectors(noc):
+    """oracle RefLevelDE restatement == outputs of the reference's own compute_data_DE / sor_coupled_slow_but_readable_DE
+    chain (tests/golden/fdf_ref_depth_*.npz, made by tests/golden/make_golden.py), bit for bit, both camera sides"""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "fdf_ref_depth_%s.npz" % ("gray" if noc == 1 else "rgb")))
+    p = depth_params(2, 1024, noc)
+    for name, c in load_fdf(noc).items():
+        im1, im2, wx, lvl = c["im1"], c["im2"], c["wx"], int(c["lvl"])
+        _, h, w = im1.shape
+        for camlr in (0, 1):
+            w0 = (-np.abs(wx) if camlr == 0 else np.abs(wx)).astype(np.float32)
+            out = O.varref_depth(_padlvl(im1), _padlvl(im2), w, h, lvl, p, w0[..., None], camlr)
+            assert np.array_equal(out[..., 0], z["%s/out_de%d" % (name, camlr)]), (name, camlr)
+            assert (out <= 0).all() if camlr == 0 else (out >= 0).all()
+
+
+@pytest.mark.skipif(not R.available(1), reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("noc,w,h,camlr", [(1, 30, 17, 0), (1, 37, 19, 1), (3, 33, 18, 0), (1, 120, 68, 0)])
+def test_depth_varref_vs_live_reference(noc, w, h, camlr):
+    rng = np.random.default_rng(w * 100 + h)
+    f0, f1 = synth_pair(h, w, seed=w, noc=noc, shift=(-0.7 if camlr == 0 else 0.7, 0.0))
+    im1 = f0.reshape(h, w, noc).transpose(2, 0, 1).copy()
+    im2 = f1.reshape(h, w, noc).transpose(2, 0, 1).copy()
+    wx = (0.7 + 0.3 * rng.standard_normal((h, w))).astype(np.float32)
+    wx = -np.abs(wx) if camlr == 0 else np.abs(wx)
+    dump = {}
+    ox = R.FdfRef(noc).ref_level_de(im1, im2, wx, 3, camlr=camlr, dump=dump)
+    p = depth_params(2, 1024, noc)
+    out = O.varref_depth(_padlvl(im1), _padlvl(im2), w, h, 3, p, wx[..., None], camlr)
+    assert np.array_equal(out[..., 0], ox)
+
+
+def test_depth_recovers_disparity():
+    """whole depth pipeline on a synthetic rectified pair: the second view is the first shifted left, so the disparity is
+    negative (left camera, camlr 0) and the clamp p <= 0 never binds at the solution"""
+    h, w = 272, 480
+    f0, _ = synth_pair(h, w, seed=5)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    d = -(4.0 + 2.0 * np.sin(yy / h * 3.0) * np.cos(xx / w * 2.0))       # disparity field (<= -2)
+    sx = np.clip(xx - d, 0, w - 1.001)
+    x0 = sx.astype(int)
+    ax = sx - x0
+    f1 = np.round(f0[yy.astype(int), x0] * (1 - ax) + f0[yy.astype(int), x0 + 1] * ax).astype(np.float32)
+    p = depth_params(2, w)
+    fl = O.full_flow(f0, f1, params=p)
+    assert fl.shape == (h, w, 1) and (fl <= 0).all()
+    err = np.abs(fl[20:-20, 20:-20, 0] - d[20:-20, 20:-20])
+    assert np.median(err) < 0.15 and err.mean() < 0.4
+    # forward-backward merge variant runs and agrees roughly
+    p.usefbcon = 1
+    fl2 = O.full_flow(f0, f1, params=p)
+    assert np.abs(fl2 - fl).mean() < 0.3
