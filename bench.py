@@ -286,6 +286,22 @@ def main():
                                  "note": "same workload with 3-channel interleaved f32 frames (3x the input bytes); informational"}
             ofc3.close()
             del R0, R1
+            # stereo depth mode (kroeger SELECTMODE=2): same frames as a rectified pair, one displacement channel
+            opd = F.operating_point(OP_POINT, W, 1, sor_mode=0)
+            opd.depth_mode = True
+            ofcd = OFClass(opd, F.img_params(width=W, height=H, padding=opd.patch_size), max_batch=a.batch, device=local)
+            outd = ofcd.new_outflow(a.batch)
+            for _ in range(2):
+                ofcd.calc_batch(I0, I1, None, outd)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                ofcd.calc_batch(I0, I1, None, outd)
+            torch.cuda.synchronize()
+            res["depth_mode"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
+                                 "note": "stereo depth mode (1-D displacement, RefLevelDE refinement) on the same frames; informational"}
+            ofcd.close()
+            del outd
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(I0, I1)
             # the same leg also checks the timed batch's result against the oracle ("EPE vs kroeger CPU")

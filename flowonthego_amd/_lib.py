@@ -17,7 +17,8 @@ class FotgParams(C.Structure):
                 ("res_thresh", C.c_float), ("patove", C.c_float), ("patnorm", C.c_int), ("noc", C.c_int),
                 ("usetvref", C.c_int), ("tv_alpha", C.c_float), ("tv_gamma", C.c_float),
                 ("tv_delta", C.c_float), ("tv_innerit", C.c_int), ("tv_solverit", C.c_int),
-                ("tv_sor", C.c_float), ("sor_mode", C.c_int), ("costfct", C.c_int), ("normoutlier", C.c_float), ("usefbcon", C.c_int)]
+                ("tv_sor", C.c_float), ("sor_mode", C.c_int), ("costfct", C.c_int), ("normoutlier", C.c_float), ("usefbcon", C.c_int),
+                ("depth", C.c_int)]
 
 
 # every symbol include/fotg.h declares: (name, restype, argtypes)
@@ -42,6 +43,7 @@ SYMBOLS = [
     ("fotg_grid_init", C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_long, vp]),
     ("fotg_grid_set_target", C.c_int, [vp, C.c_int, vp, C.c_long]),
     ("fotg_grid_init_from_coarser", C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    ("fotg_grid_set_camera", C.c_int, [vp, C.c_int, C.c_int]),
     ("fotg_grid_optimize", C.c_int, [vp, C.c_int, C.c_int, vp]),
     ("fotg_grid_aggregate", C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     ("fotg_grid_read", C.c_int, [vp, C.c_int, C.c_int] + [vp] * 7),

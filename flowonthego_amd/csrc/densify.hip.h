@@ -67,7 +67,7 @@ __device__ __forceinline__ void gather_own(const float *__restrict__ p_iter, con
 
 template <int PS, int NOC>
 __global__ __launch_bounds__(256) void densify_kernel(const float *__restrict__ p_iter, const float *__restrict__ pweight,
-                                                      float *__restrict__ flowout, long flow_stride, LevelGeom g)
+                                                      float *__restrict__ flowout, long flow_stride, LevelGeom g, int nch)
 {
   const WgId wg = xcd_local_wg();
   const int idx = wg.x * blockDim.x + threadIdx.x;
@@ -76,9 +76,10 @@ __global__ __launch_bounds__(256) void densify_kernel(const float *__restrict__ 
   float we = 0.f, f0 = 0.f, f1 = 0.f;
   gather_own<PS, NOC>(p_iter, pweight, pair, idx % g.w, idx / g.w, g, we, f0, f1);
   if (we > 0) { f0 /= we; f1 /= we; }
-  float *out = flowout + (size_t)pair * flow_stride + 2 * (size_t)idx;
+  // nch = 1: stereo depth mode, one displacement channel (patchgrid.cpp:268, :386-390); the patches' second slot is 0
+  float *out = flowout + (size_t)pair * flow_stride + nch * (size_t)idx;
   out[0] = f0;
-  out[1] = f1;
+  if (nch == 2) out[1] = f1;
 }
 
 // Forward-backward merge (usefbcon, patchgrid.cpp:278-375): after its own patches every pixel also receives the patches
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void densify_kernel(const float *__restrict__ 
 template <int PS, int NOC>
 __global__ __launch_bounds__(256) void densify_fb_kernel(const float *__restrict__ p_iter, const float *__restrict__ pweight,
                                                          const float *__restrict__ cg_p_iter, const float *__restrict__ cg_pweight,
-                                                         float *__restrict__ flowout, long flow_stride, LevelGeom g)
+                                                         float *__restrict__ flowout, long flow_stride, LevelGeom g, int nch)
 {
   constexpr int NV = PS * PS * NOC;
   constexpr int LB = -PS / 2, UB = PS / 2 - 1;
@@ -155,9 +156,9 @@ __global__ __launch_bounds__(256) void densify_fb_kernel(const float *__restrict
   }
   if (!live) return;
   if (we > 0) { f0 /= we; f1 /= we; }
-  float *out = flowout + (size_t)pair * flow_stride + 2 * ((size_t)yt * g.w + xt);
+  float *out = flowout + (size_t)pair * flow_stride + nch * ((size_t)yt * g.w + xt);
   out[0] = f0;
-  out[1] = f1;
+  if (nch == 2) out[1] = f1;
 }
 
 }  // namespace fotg

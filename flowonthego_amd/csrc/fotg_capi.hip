@@ -12,6 +12,7 @@
 #include "lk.hip.h"
 #include "densify.hip.h"
 #include "varref.hip.h"
+#include "varref_depth.hip.h"
 #include "upsample.hip.h"
 
 using namespace fotg;
@@ -30,11 +31,13 @@ struct GridState {
   long stride = 0;
   const float *flow_prev = nullptr;
   float *trace_host = nullptr;
+  int camlr = 0;                     // depth mode: camera side of this grid (kroeger/oflow.cpp:153,157)
 };
 
 struct fotg_ctx {
   fotg_params p;
   int w_org, h_org, Wp, Hp, padw, padh, device, max_batch, noc, ps;
+  int nch;                           // flow channels: 2, or 1 in stereo depth mode (op.nop, kroeger/oflow.cpp:76-80)
   int base_lv;                       // first level the pyramid materialises: min(sc_l, 4)
   LevelGeom geom[FOTG_MAXLEV];
   float *im[2][FOTG_MAXLEV];         // padded level images  [B][th][tw][noc]
@@ -172,12 +175,13 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   if (p->sc_l < 0 || p->sc_f < p->sc_l || p->sc_f >= FOTG_MAXLEV) return FOTG_ERR_ARG;
   if (p->max_iter < 0 || p->tv_solverit < 0 || p->tv_innerit < 0) return FOTG_ERR_ARG;
   if (p->costfct < 0 || p->costfct > 2 || (p->costfct == 2 && !(p->normoutlier > 0))) return FOTG_ERR_ARG;
+  if (p->depth && p->usetvref && p->sor_mode != FOTG_SOR_LEXICOGRAPHIC) return FOTG_ERR_UNSUPPORTED;
   HIPCHK(hipSetDevice(device));
   fotg_ctx *c = new (std::nothrow) fotg_ctx();
   if (!c) return FOTG_ERR_ARG;
   memset((void *)c, 0, sizeof(*c));
   c->p = *p; c->w_org = w_org; c->h_org = h_org; c->device = device; c->max_batch = max_batch;
-  c->noc = p->noc; c->ps = p->ps;
+  c->noc = p->noc; c->ps = p->ps; c->nch = p->depth ? 1 : 2;
   fotg_padded_size(w_org, h_org, p->sc_f, &c->Wp, &c->Hp, &c->padw, &c->padh);
   c->base_lv = p->sc_l < 4 ? p->sc_l : 4;
   const size_t B = (size_t)max_batch;
@@ -210,7 +214,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
     const LevelGeom &g = c->geom[p->sc_l];
     if (g.h > 1024 && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     if (g.w < 3 || c->geom[p->sc_f].h < 5 || c->geom[p->sc_f].w < 3) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
-    c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc);
+    c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc + (p->depth ? (int)DE_NPLANE : 0));
     ALLOC(c->vr, B * c->vr_pair_stride * sizeof(float));
     static const int ks[] = {1, 2, 3, 4, 6, 8, 12, 16};
     for (int l = p->sc_l; l <= p->sc_f; ++l) {
@@ -225,6 +229,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       a.S = gl.w + gl.h - 1; a.SC = a.S + 1;        // one spare (zero) row: idle lanes read past the last row
       a.c_pair_stride = (long)a.SC * a.RP * 2;
       a.d_pair_stride = (long)(a.S + 1) * a.RPD;
+      if (p->depth) continue;                        // depth mode solves on plain planes of the workspace (varref_depth.hip.h)
       // + slack: idle lanes of the solver read K cells past the row they are parked on, i.e. past the last pair's
       // last (spare) row
       const size_t cbytes = B * a.c_pair_stride * sizeof(float4) + 64 * 16 * 2 * sizeof(float4);
@@ -444,7 +449,8 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   memset(&a, 0, sizeof(a));
   a.I0 = gs.I0; a.I0x = gs.I0x; a.I0y = gs.I0y; a.I1 = gs.I1; a.img_stride = gs.stride;
   a.flow_prev = gs.flow_prev;
-  a.flow_prev_stride = (long)(g.w / 2) * (g.h / 2) * 2;
+  a.flow_prev_stride = (long)(g.w / 2) * (g.h / 2) * c->nch;
+  a.camlr = gs.camlr;
   a.p_iter = c->p_iter[l]; a.pweight = c->pweight[l];
   if (c->taps) { a.tmpl = c->tap_t[l]; a.tdx = c->tap_tx[l]; a.tdy = c->tap_ty[l]; a.hes = c->tap_hes[l]; a.cnt = c->tap_cnt[l]; }
   a.trace = gs.trace_host ? c->trace_dev[l] : nullptr;
@@ -460,11 +466,19 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   int np = ((long)n * g.nop >= 4096) ? 2 : 1;          // measured (MI355X, 64 x 1080p): NP 2 beats 1 and 4 at 8.6k and 32k patches, NP 1 wins at 2.5k
   if (const char *e = getenv("FOTG_LK_NP")) np = atoi(e);
 #define LK(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
-  if (c->ps == 8 && c->noc == 1) { if (np >= 4) LK(8, 1, 4); else if (np == 2) LK(8, 1, 2); else LK(8, 1, 1); }
+#define LKD(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_, true><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
+  if (c->p.depth) {
+    if (c->ps == 8 && c->noc == 1) { if (np >= 2) LKD(8, 1, 2); else LKD(8, 1, 1); }
+    else if (c->ps == 8) { if (np >= 2) LKD(8, 3, 2); else LKD(8, 3, 1); }
+    else if (c->noc == 1) { if (np >= 2) LKD(12, 1, 2); else LKD(12, 1, 1); }
+    else LKD(12, 3, 1);
+  }
+  else if (c->ps == 8 && c->noc == 1) { if (np >= 4) LK(8, 1, 4); else if (np == 2) LK(8, 1, 2); else LK(8, 1, 1); }
   else if (c->ps == 8) { if (np >= 2) LK(8, 3, 2); else LK(8, 3, 1); }
   else if (c->noc == 1) { if (np >= 2) LK(12, 1, 2); else LK(12, 1, 1); }
   else LK(12, 3, 1);
 #undef LK
+#undef LKD
   LAUNCHCHK();
   if (gs.trace_host) {
     HIPCHK(hipStreamSynchronize(s));
@@ -478,21 +492,22 @@ static int aggregate_impl(fotg_ctx *c, int l, int n, const float *p_iter, const 
                           const float *cg_pweight, float *flowout, hipStream_t s)
 {
   const LevelGeom &g = c->geom[l];
-  const long fs = (long)g.w * g.h * 2;
+  const long fs = (long)g.w * g.h * c->nch;
+  const int nch = c->nch;
   if (cg_p_iter) {
     dim3 grid(((g.w + 15) / 16) * ((g.h + 15) / 16), n), block(256);
-    if (c->ps == 8 && c->noc == 1) densify_fb_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g);
-    else if (c->ps == 8) densify_fb_kernel<8, 3><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g);
-    else if (c->noc == 1) densify_fb_kernel<12, 1><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g);
-    else densify_fb_kernel<12, 3><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g);
+    if (c->ps == 8 && c->noc == 1) densify_fb_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g, nch);
+    else if (c->ps == 8) densify_fb_kernel<8, 3><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g, nch);
+    else if (c->noc == 1) densify_fb_kernel<12, 1><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g, nch);
+    else densify_fb_kernel<12, 3><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g, nch);
     LAUNCHCHK();
     return FOTG_OK;
   }
   dim3 grid((g.w * g.h + 255) / 256, n), block(256);
-  if (c->ps == 8 && c->noc == 1) densify_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g);
-  else if (c->ps == 8) densify_kernel<8, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g);
-  else if (c->noc == 1) densify_kernel<12, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g);
-  else densify_kernel<12, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g);
+  if (c->ps == 8 && c->noc == 1) densify_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
+  else if (c->ps == 8) densify_kernel<8, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
+  else if (c->noc == 1) densify_kernel<12, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
+  else densify_kernel<12, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
   LAUNCHCHK();
   return FOTG_OK;
 }
@@ -765,15 +780,84 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   return FOTG_OK;
 }
 
-extern "C" {
-int fotg_varref(fotg_ctx *c, int l, int n, const float *I0, const float *I1, long pair_stride, float *flow, void *stream)
+// stereo depth mode: RefLevelDE (kroeger/refine_variational.cpp:243-330), flow has one channel
+static bool g_de_lds_set[32];
+template <int NOC>
+static int varref_depth_impl(fotg_ctx *c, int l, int n, const float *I0, const float *I1, long img_stride, float *flow, hipStream_t s, int camlr)
+{
+  const LevelGeom &g = c->geom[l];
+  const VrArgs &a = c->vra[l];
+  const long fs = (long)g.w * g.h;
+  dim3 grid((g.w * g.h + 255) / 256, n), block(256);
+  const float quarter_alpha = 0.25f * c->p.tv_alpha;
+  const float half_gamma_over3 = c->p.tv_gamma * 0.5f / 3.0f;
+  const float half_delta_over3 = c->p.tv_delta * 0.5f / 3.0f;
+  const int inner = c->p.tv_innerit * (l + 1);
+  vr_setup_kernel<NOC, 1><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
+  LAUNCHCHK();
+  vr_de_init_kernel<<<grid, block, 0, s>>>(a);
+  LAUNCHCHK();
+  const int threads = ((g.h + 63) / 64) * 64;
+  const int du_bytes = g.st * g.h * (int)sizeof(float);
+  const bool lds = du_bytes <= 128 * 1024;
+  if (lds && du_bytes > 64 * 1024) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 32 && !g_de_lds_set[dev]) {
+      HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      g_de_lds_set[dev] = true;
+    }
+  }
+  for (int it = 0; it < inner; ++it) {
+    vr_de_smooth_kernel<<<grid, block, 0, s>>>(a, quarter_alpha);
+    LAUNCHCHK();
+    vr_de_data_kernel<NOC><<<grid, block, 0, s>>>(a, half_delta_over3, half_gamma_over3);
+    LAUNCHCHK();
+    // the sweeps are sequential passes over du, so `k` single-sweep launches equal one k-sweep launch bit for bit; the
+    // operating points use 3.  (With 0 sweeps the clamped update still runs: uu = min/max(wx + du, 0).)
+    if (c->p.tv_solverit == 3) {
+      if (lds) vr_de_sor_kernel<3, true><<<n, threads, du_bytes, s>>>(a, c->p.tv_sor, camlr);
+      else vr_de_sor_kernel<3, false><<<n, threads, 0, s>>>(a, c->p.tv_sor, camlr);
+    } else {
+      for (int k = 0; k < c->p.tv_solverit; ++k) {
+        if (lds) vr_de_sor_kernel<1, true><<<n, threads, du_bytes, s>>>(a, c->p.tv_sor, camlr);
+        else vr_de_sor_kernel<1, false><<<n, threads, 0, s>>>(a, c->p.tv_sor, camlr);
+      }
+    }
+    LAUNCHCHK();
+  }
+  vr_de_finish_kernel<<<grid, block, 0, s>>>(a, flow, fs);
+  LAUNCHCHK();
+  return FOTG_OK;
+}
+
+static int varref_dispatch(fotg_ctx *c, int l, int n, const float *I0, const float *I1, long pair_stride, float *flow, hipStream_t stream, int camlr)
 {
   int st = check_level(c, l, n); if (st) return st;
   if (!I0 || !I1 || !flow || !c->vr) return FOTG_ERR_ARG;
   if (c->geom[l].h < 5 || c->geom[l].w < 3) return FOTG_ERR_UNSUPPORTED;
   HIPCHK(hipSetDevice(c->device));
-  return c->noc == 1 ? varref_impl<1>(c, l, n, I0, I1, pair_stride, flow, (hipStream_t)stream)
-                     : varref_impl<3>(c, l, n, I0, I1, pair_stride, flow, (hipStream_t)stream);
+  if (c->p.depth)
+    return c->noc == 1 ? varref_depth_impl<1>(c, l, n, I0, I1, pair_stride, flow, stream, camlr)
+                       : varref_depth_impl<3>(c, l, n, I0, I1, pair_stride, flow, stream, camlr);
+  return c->noc == 1 ? varref_impl<1>(c, l, n, I0, I1, pair_stride, flow, stream)
+                     : varref_impl<3>(c, l, n, I0, I1, pair_stride, flow, stream);
+}
+
+extern "C" {
+int fotg_varref(fotg_ctx *c, int l, int n, const float *I0, const float *I1, long pair_stride, float *flow, void *stream)
+{
+  if (!c || l < 0 || l >= FOTG_MAXLEV) return FOTG_ERR_ARG;
+  return varref_dispatch(c, l, n, I0, I1, pair_stride, flow, (hipStream_t)stream, c->gs[l].camlr);
+}
+
+int fotg_grid_set_camera(fotg_ctx *c, int l, int camlr)
+{
+  int st = check_level(c, l, 1); if (st) return st;
+  if (camlr != 0 && camlr != 1) return FOTG_ERR_ARG;
+  c->gs[l].camlr = camlr;
+  return FOTG_OK;
 }
 
 int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *host_out)
@@ -787,6 +871,14 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
   const VrArgs &a = c->vra[l];
   const size_t pl = (size_t)g.st * g.h;
   HIPCHK(hipDeviceSynchronize());
+  if (c->p.depth) {
+    static const char *de[] = {"du", "uu", "s", "a11", "b1", "sh", "sv"};        // VrDePlane order
+    for (int k = 0; k < DE_NPLANE; ++k)
+      if (!strcmp(name, de[k])) {
+        HIPCHK(hipMemcpy(host_out, de_plane(a, pair, k), pl * 4, hipMemcpyDeviceToHost));
+        return FOTG_OK;
+      }
+  }
   for (int i = 0; i < P_NSINGLE; ++i)
     if (!strcmp(name, singles[i])) {
       HIPCHK(hipMemcpy(host_out, c->vr + (size_t)pair * c->vr_pair_stride + i * pl, pl * 4, hipMemcpyDeviceToHost));
@@ -798,6 +890,7 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
                        pl * c->noc * 4, hipMemcpyDeviceToHost));
       return FOTG_OK;
     }
+  if (c->p.depth) return FOTG_ERR_ARG;
   // planes that live in the skewed solver arrays: copy and de-skew on the host
   for (int k = 0; k < 8; ++k)
     if (!strcmp(name, sys[k])) {
@@ -845,7 +938,11 @@ static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float 
     if (!vb) return FOTG_ERR_ARG;
     memcpy((void *)vb, (const void *)c, sizeof(fotg_ctx));
     vb->taps = false;
-    for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) { vb->p_iter[l] = c->p_iter_bw[l]; vb->pweight[l] = c->pweight_bw[l]; memset((void *)&vb->gs[l], 0, sizeof(GridState)); }
+    for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) {
+      vb->p_iter[l] = c->p_iter_bw[l]; vb->pweight[l] = c->pweight_bw[l];
+      memset((void *)&vb->gs[l], 0, sizeof(GridState));
+      vb->gs[l].camlr = 1;                                         // kroeger/oflow.cpp:157,165: the backward grid is the right camera
+    }
   }
   if (fb && !seq) {
     // both frames need gradients: two template-type pyramids (the second one into the frame-1 buffers)
@@ -878,8 +975,8 @@ static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float 
       if ((st = aggregate_impl(c, l, n, c->p_iter[l], c->pweight[l], c->p_iter_bw[l], c->pweight_bw[l], out, stream))) return st;
       if (l > c->p.sc_l && (st = aggregate_impl(c, l, n, c->p_iter_bw[l], c->pweight_bw[l], c->p_iter[l], c->pweight[l], c->flow_bw[l], stream))) return st;
       if (c->p.usetvref) {
-        if ((st = fotg_varref(c, l, n, c->im[0][l], tgt, ls, out, stream))) return st;
-        if (l > c->p.sc_l && (st = fotg_varref(c, l, n, tgt, c->im[0][l], ls, c->flow_bw[l], stream))) return st;
+        if ((st = varref_dispatch(c, l, n, c->im[0][l], tgt, ls, out, stream, 0))) return st;
+        if (l > c->p.sc_l && (st = varref_dispatch(c, l, n, tgt, c->im[0][l], ls, c->flow_bw[l], stream, 1))) return st;
       }
       continue;
     }
@@ -891,7 +988,7 @@ static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float 
     float *out = (l == c->p.sc_l) ? outflow : c->flow[l];
     if ((st = fotg_grid_aggregate(c, l, n, out, stream))) return st;
     if (c->p.usetvref)
-      if ((st = fotg_varref(c, l, n, c->im[0][l], tgt, c->lev_stride[l], out, stream))) return st;
+      if ((st = varref_dispatch(c, l, n, c->im[0][l], tgt, c->lev_stride[l], out, stream, 0))) return st;
   }
   return FOTG_OK;
 }
@@ -930,8 +1027,8 @@ static int calc_enqueue(fotg_ctx *c, int n, const float *I0, const float *I1, co
   const int nsub = (c->nsub > 1 && n >= 4 * c->nsub && !c->p.usefbcon) ? c->nsub : 1;    // >= 4 pairs per sub-batch
   if (nsub == 1) return calc_range(c, n, I0, I1, initflow, outflow, s);
   const LevelGeom &gf = c->geom[c->p.sc_l], &gc = c->geom[c->p.sc_f];
-  const size_t frame = (size_t)c->w_org * c->h_org * c->noc, oflow = (size_t)gf.w * gf.h * 2;
-  const size_t iflow = (size_t)(gc.w / 2) * (gc.h / 2) * 2;
+  const size_t frame = (size_t)c->w_org * c->h_org * c->noc, oflow = (size_t)gf.w * gf.h * c->nch;
+  const size_t iflow = (size_t)(gc.w / 2) * (gc.h / 2) * c->nch;
   HIPCHK(hipEventRecord(c->ev_fork, s));
   int status = FOTG_OK;
   for (int k = 0; k < nsub; ++k) {
@@ -1029,7 +1126,7 @@ int fotg_calc(fotg_ctx *c, const float *I0, const float *I1, const float *initfl
   const LevelGeom &g = c->geom[c->p.sc_l];
   int st = fotg_calc_batch(c, 1, I0, I1, initflow, c->flow[c->p.sc_l], nullptr);
   if (st) return st;
-  HIPCHK(hipMemcpy(outflow_host, c->flow[c->p.sc_l], (size_t)g.w * g.h * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(outflow_host, c->flow[c->p.sc_l], (size_t)g.w * g.h * c->nch * sizeof(float), hipMemcpyDeviceToHost));
   return FOTG_OK;
 }
 
@@ -1040,8 +1137,8 @@ int fotg_upsample_crop(fotg_ctx *c, int n, const float *flow, float *out, void *
   HIPCHK(hipSetDevice(c->device));
   const LevelGeom &g = c->geom[c->p.sc_l];
   dim3 grid((c->w_org * c->h_org + 255) / 256, n), block(256);
-  upsample_crop_kernel<<<grid, block, 0, (hipStream_t)stream>>>(flow, (long)g.w * g.h * 2, g.w, g.h, c->p.sc_l, c->padw / 2, c->padh / 2,
-                                                                 c->w_org, c->h_org, out, (long)c->w_org * c->h_org * 2);
+  upsample_crop_kernel<<<grid, block, 0, (hipStream_t)stream>>>(flow, (long)g.w * g.h * c->nch, g.w, g.h, c->p.sc_l, c->padw / 2, c->padh / 2,
+                                                                 c->w_org, c->h_org, out, (long)c->w_org * c->h_org * c->nch, c->nch);
   LAUNCHCHK();
   return FOTG_OK;
 }

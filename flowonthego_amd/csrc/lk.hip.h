@@ -32,7 +32,7 @@ struct LkArgs {
   int *cnt;                           // optional [n][nop]
   float *trace;                       // optional [nop][(max_iter+1)][4], pair 0 only
   LevelGeom g;
-  int ps_unused;
+  int camlr;                          // depth mode: 0 displacement <= 0 (forward grid), 1 displacement >= 0 (oflow.cpp:153,157)
   int max_iter, min_iter, patnorm, costfct;
   float dp_thresh_sq, dr_thresh, res_thresh, outlier, huber_bsq, huber_2bsq;
 };
@@ -44,7 +44,11 @@ struct LkArgs {
 // a square root are ~60 instructions).  So the scalars of the NP patches are PACKED: lanes [k*64/NP, (k+1)*64/NP)
 // carry the state of patch k, the scalar code runs once per iteration for all NP patches, and only the five values
 // the pixel work needs (window index, four bilinear weights) are read back per patch with v_readlane.
-template <int PS, int NOC, int NP>
+//
+// DEPTH: stereo depth mode (SELECTMODE 2): the parameter is ONE horizontal displacement per patch -- scalar Hessian
+// sum(Tx^2) (patch.cpp:83-87), one projection (:181), sign clamp after the update (:188-193), pt_iter.y stays at the
+// reference row (:218-220); flow_prev has one channel (patchgrid.cpp:207-208).  p_iter keeps two slots (second = 0).
+template <int PS, int NOC, int NP, bool DEPTH = false>
 __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
 {
   constexpr int NPIX = PS * PS;
@@ -139,14 +143,17 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
       for (int e = 0; e < NE; ++e) T[k][e] -= m;
     }
     h00u[k] = wave_sum(lane_dot(Tx[k], Tx[k]));
-    h01u[k] = wave_sum(lane_dot(Tx[k], Ty[k]));
-    h11u[k] = wave_sum(lane_dot(Ty[k], Ty[k]));
+    if constexpr (DEPTH) { h01u[k] = 0.f; h11u[k] = 0.f; }
+    else {
+      h01u[k] = wave_sum(lane_dot(Tx[k], Ty[k]));
+      h11u[k] = wave_sum(lane_dot(Ty[k], Ty[k]));
+    }
     float pin0 = 0.f, pin1 = 0.f;
     if (a.flow_prev) {
       const int fx = (int)floorf(rx / 2), fy = (int)floorf(ry / 2);
-      const float *fp = a.flow_prev + (size_t)pair * a.flow_prev_stride + 2 * (size_t)(fy * (a.g.w / 2) + fx);
+      const float *fp = a.flow_prev + (size_t)pair * a.flow_prev_stride + (DEPTH ? 1 : 2) * (size_t)(fy * (a.g.w / 2) + fx);
       pin0 = fp[0] * 2;
-      pin1 = fp[1] * 2;
+      if constexpr (!DEPTH) pin1 = fp[1] * 2;
     }
     pin0u[k] = pin0; pin1u[k] = pin1;
     // Stage the reachable window of I1 in LDS.  Every evaluated position is within ps/2 of the start in x and y, so
@@ -168,14 +175,16 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
   // ---- packed per-patch state ----
   float H00 = packf(h00u), H11 = packf(h11u);
   const float H01 = packf(h01u);
-  if (H00 * H11 - H01 * H01 == 0.f) {                    // :78-82  (float += 1e-10 in double, like the reference)
+  if constexpr (DEPTH) {
+    if (H00 == 0.f) H00 = (float)((double)H00 + 1e-10);  // :85-86
+  } else if (H00 * H11 - H01 * H01 == 0.f) {             // :78-82  (float += 1e-10 in double, like the reference)
     H00 = (float)((double)H00 + 1e-10);
     H11 = (float)((double)H11 + 1e-10);
   }
   // Cholesky factor of the (constant) Hessian, hoisted out of the loop: same values every iteration
   const float L00 = sqrtf(H00);
-  const float L10 = H01 / L00;
-  const float L11 = sqrtf(H11 - L10 * L10);
+  const float L10 = DEPTH ? 0.f : H01 / L00;
+  const float L11 = DEPTH ? 1.f : sqrtf(H11 - L10 * L10);
   const float RX = packf(rxu), RY = packf(ryu), PIN0 = packf(pin0u), PIN1 = packf(pin1u);
   const int WX0 = packi(wx0u), WY0 = packi(wy0u), IP = packi(ipu);
   const bool VALID = packi(validu) != 0;
@@ -200,15 +209,23 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         b0u[k] = wave_sum(lane_dot(Tx[k], r[k]));
-        b1u[k] = wave_sum(lane_dot(Ty[k], r[k]));
+        b1u[k] = DEPTH ? 0.f : wave_sum(lane_dot(Ty[k], r[k]));
       }
       const float B0 = packf(b0u), B1 = packf(b1u);
-      // 2x2 LLT solve (:184), packed
+      // 2x2 LLT solve (:184), packed; depth mode: the 1x1 system, L = sqrt(H)
       const float y0 = B0 / L00;
-      const float y1 = (B1 - L10 * y0) / L11;
-      const float x1 = y1 / L11;
-      const float x0 = (y0 - L10 * x1) / L00;
+      float x0, x1;
+      if constexpr (DEPTH) { x0 = y0 / L00; x1 = 0.f; }
+      else {
+        const float y1 = (B1 - L10 * y0) / L11;
+        x1 = y1 / L11;
+        x0 = (y0 - L10 * x1) / L00;
+      }
       float nP0 = P0 - x0, nP1 = P1 - x1;                // :186
+      if constexpr (DEPTH) {                             // :188-193 std::min / std::max with 0
+        if (a.camlr == 0) nP0 = (0.0f < nP0) ? 0.0f : nP0;
+        else nP0 = (nP0 < 0.0f) ? 0.0f : nP0;
+      }
       float nPTX = RX + nP0, nPTY = RY + nP1;
       const float ddx = STX - nPTX, ddy = STY - nPTY;
       const bool bad = !(isfinite(x0) && isfinite(x1));  // oracle definition D3

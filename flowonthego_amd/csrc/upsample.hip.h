@@ -9,7 +9,7 @@ namespace fotg {
 
 __global__ __launch_bounds__(256) void upsample_crop_kernel(const float *__restrict__ flow, long in_stride, int wl, int hl,
                                                             int sc_l, int x0, int y0, int w_org, int h_org,
-                                                            float *__restrict__ out, long out_stride)
+                                                            float *__restrict__ out, long out_stride, int nch)
 {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= w_org * h_org) return;
@@ -27,11 +27,10 @@ __global__ __launch_bounds__(256) void upsample_crop_kernel(const float *__restr
   if (sx < 0) { fx = 0; sx = 0; }
   if (sx >= wl - 1) { fx = 0; sx = wl - 1; }
   const int sx1 = sx + 1 < wl ? sx + 1 : wl - 1;
-  float *o = out + (size_t)pair * out_stride + 2 * (size_t)idx;
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    float v00 = f[2 * (sy * wl + sx) + c], v01 = f[2 * (sy * wl + sx1) + c];
-    float v10 = f[2 * (sy1 * wl + sx) + c], v11 = f[2 * (sy1 * wl + sx1) + c];
+  float *o = out + (size_t)pair * out_stride + nch * (size_t)idx;      // nch = 1: stereo depth (run_dense.cpp:387-388)
+  for (int c = 0; c < nch; ++c) {
+    float v00 = f[nch * (sy * wl + sx) + c], v01 = f[nch * (sy * wl + sx1) + c];
+    float v10 = f[nch * (sy1 * wl + sx) + c], v11 = f[nch * (sy1 * wl + sx1) + c];
     if (sc_l != 0) { v00 *= scf; v01 *= scf; v10 *= scf; v11 *= scf; }
     const float r0 = v00 * (1.f - fx) + v01 * fx;
     const float r1 = v10 * (1.f - fx) + v11 * fx;

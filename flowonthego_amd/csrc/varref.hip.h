@@ -75,13 +75,14 @@ __device__ __forceinline__ float conv_v5(const float *__restrict__ col, int j, i
 template <int NOC>
 struct PrepVal { float wx, wy, mask, avg[NOC], iz[NOC]; };
 
-template <int NOC>
+// NCH = 1: stereo depth mode, the flow has one channel and wy = 0 (wy_dummy, refine_variational.cpp:258,273)
+template <int NOC, int NCH = 2>
 __device__ __forceinline__ PrepVal<NOC> prep_values(const VrArgs &a, int pair, int i, int j, const float *__restrict__ I0, const float *__restrict__ I1,
                                                     long img_stride, int tw, int pad, const float *__restrict__ flow, long flow_stride)
 {
   PrepVal<NOC> v;
-  const float *f = flow + (size_t)pair * flow_stride + 2 * (size_t)(j * a.w + i);
-  const float wx = f[0], wy = f[1];
+  const float *f = flow + (size_t)pair * flow_stride + NCH * (size_t)(j * a.w + i);
+  const float wx = f[0], wy = NCH == 2 ? f[NCH - 1] : 0.f;
   v.wx = wx; v.wy = wy;
   // image_warp (opticalflow_aux.c:18-60)
   const float xx = i + wx, yy = j + wy;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
 // difference on the tile + 4 pixels (the second derivatives reach 2 + 2 pixels), first derivatives on the tile + 2.  Halo
 // entries outside the image hold the values of the clamped coordinate, exactly what the reference's replicate indexing
 // reads, and the 5-tap helpers index the LDS tiles through pointers biased to global coordinates.
-template <int NOC>
+template <int NOC, int NCH = 2>
 __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__restrict__ I0, const float *__restrict__ I1,
                                                        long img_stride, int tw, int pad,
                                                        const float *__restrict__ flow, long flow_stride)
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
   for (int e = threadIdx.x; e < XW * XH; e += 256) {
     const int cx = tx0 - 4 + e % XW, cy = ty0 - 4 + e / XW;
     const int gx = clampi(cx, w), gy = clampi(cy, h);
-    const PrepVal<NOC> v = prep_values<NOC>(a, pair, gx, gy, I0, I1, img_stride, tw, pad, flow, flow_stride);
+    const PrepVal<NOC> v = prep_values<NOC, NCH>(a, pair, gx, gy, I0, I1, img_stride, tw, pad, flow, flow_stride);
 #pragma unroll
     for (int c = 0; c < NOC; ++c) { Xa[c][e] = v.avg[c]; Xz[c][e] = v.iz[c]; }
     if (cx >= tx0 && cx < tx0 + TW_ && cy >= ty0 && cy < ty0 + TH_ && cx < w && cy < h) prep_store<NOC>(a, pair, cx, cy, v);

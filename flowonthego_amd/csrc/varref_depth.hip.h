@@ -1,0 +1,203 @@
+// varref_depth.hip.h -- variational refinement of one level in STEREO DEPTH mode (SELECTMODE 2):
+// VarRefClass::RefLevelDE (kroeger/refine_variational.cpp:243-330) driving compute_smoothness,
+// compute_data_DE (FDF1.0.1/opticalflow_aux.c:446-540), sub_laplacian and
+// sor_coupled_slow_but_readable_DE (FDF1.0.1/solver.c:428-466).
+//
+// One displacement component: the system is scalar per pixel (a11, b1), the solver is the plain point-SOR update
+//   du = (1-omega) du + omega (b1 - sigma) / (a11 + sum psi)
+// in row-major order (the reference's default build has no OpenMP, so its row loop is serial).  The set-up stages
+// (warp with wy = 0, derivatives) are the optical-flow ones (vr_setup_kernel<NOC, 1>).  Extra planes, FDF image_t
+// layout, appended to the workspace of varref.hip.h:
+//   du  uu  s (smoothness weight)  a11  b1  sh  sv
+// Kernels per inner iteration: smooth -> data -> sor (+ clamped update uu = min/max(wx + du, 0), :299-314).
+#pragma once
+#include "varref.hip.h"
+
+namespace fotg {
+
+enum VrDePlane { DE_DU = 0, DE_UU, DE_S, DE_A11, DE_B1, DE_SH, DE_SV, DE_NPLANE };
+
+__host__ __device__ inline float *de_plane(const VrArgs &a, int pair, int k)
+{
+  return a.base + (size_t)pair * a.pair_stride + (size_t)(P_NSINGLE + C_NCOLOR * a.noc + k) * a.pl;
+}
+
+// image_erase(du); uu = wx (refine_variational.cpp:277-280)
+__global__ __launch_bounds__(256) void vr_de_init_kernel(VrArgs a)
+{
+  const WgId wg = xcd_local_wg();
+  const int idx = wg.x * blockDim.x + threadIdx.x;
+  if (idx >= a.w * a.h) return;
+  const int pair = wg.y, o = (idx / a.w) * a.st + idx % a.w;
+  de_plane(a, pair, DE_DU)[o] = 0.f;
+  de_plane(a, pair, DE_UU)[o] = a.single(pair, P_WX)[o];
+}
+
+// compute_smoothness first half (opticalflow_aux.c:126-139) with vv = wy_dummy = 0 (refine_variational.cpp:288)
+__global__ __launch_bounds__(256) void vr_de_smooth_kernel(VrArgs a, float quarter_alpha)
+{
+  const WgId wg = xcd_local_wg();
+  const int idx = wg.x * blockDim.x + threadIdx.x;
+  if (idx >= a.w * a.h) return;
+  const int pair = wg.y, i = idx % a.w, j = idx / a.w, st = a.st, o = j * st + i;
+  const float *uu = de_plane(a, pair, DE_UU);
+  auto at = [&](int q) { return make_float2(uu[q], 0.f); };
+  const int ol = i > 0 ? o - 1 : o, orr = i < a.w - 1 ? o + 1 : o, ot = j > 0 ? o - st : o, ob = j < a.h - 1 ? o + st : o;
+  de_plane(a, pair, DE_S)[o] = smooth_w(at(ol), at(o), at(orr), at(ot), at(ob), j, a.h, quarter_alpha);
+}
+
+// compute_smoothness second half (:141-163), compute_data_DE (:446-540), sub_laplacian(b1, wx) (:172-199)
+template <int NOC>
+__global__ __launch_bounds__(256) void vr_de_data_kernel(VrArgs a, float half_delta_over3, float half_gamma_over3)
+{
+  const WgId wg = xcd_local_wg();
+  const int idx = wg.x * blockDim.x + threadIdx.x;
+  if (idx >= a.w * a.h) return;
+  const int pair = wg.y, w = a.w, h = a.h, i = idx % w, j = idx / w, st = a.st, o = j * st + i;
+  const PixIn<NOC> p = data_load<NOC>(a, pair, i, j);
+  const float *s = de_plane(a, pair, DE_S);
+  const float s_o = s[o];
+  const float hr = (i < w - 1) ? s_o + s[o + 1] : 0.0f;
+  const float hl = (i > 0) ? s[o - 1] + s_o : 0.0f;
+  const float vb = (j < h - 1) ? s_o + s[o + st] : 0.0f;
+  const float vt = (j > 0) ? s[o - st] + s_o : 0.0f;
+  const float u = de_plane(a, pair, DE_DU)[o];
+  const float dnorm = 0.1f * 0.1f, epsc = 0.001f * 0.001f, epsg = 0.001f * 0.001f;
+  const float m = p.m;
+  float A11 = 0, B1 = 0;
+  if constexpr (NOC == 1) {
+    const float Ix = p.Ix[0], Iy = p.Iy[0], Iz = p.Iz[0], Ixx = p.Ixx[0], Ixy = p.Ixy[0], Iyy = p.Iyy[0], Ixz = p.Ixz[0], Iyz = p.Iyz[0];
+    float tmp, tmp2, n1, n2;
+    if (half_delta_over3) {
+      tmp = Iz + Ix * u;
+      n1 = Ix * Ix + Iy * Iy + dnorm;
+      tmp = m * half_delta_over3 / sqrtf(3 * tmp * tmp / n1 + epsc);
+      tmp /= n1;
+      A11 += tmp * Ix * Ix;
+      B1 -= tmp * Iz * Ix;
+    }
+    n1 = Ixx * Ixx + Ixy * Ixy + dnorm;
+    n2 = Iyy * Iyy + Ixy * Ixy + dnorm;
+    tmp = Ixz + Ixx * u;
+    tmp2 = Iyz + Ixy * u;
+    tmp = m * half_gamma_over3 / sqrtf(3 * tmp * tmp / n1 + 3 * tmp2 * tmp2 / n2 + epsg);
+    tmp2 = tmp / n2; tmp /= n1;
+    A11 += tmp * Ixx * Ixx + tmp2 * Ixy * Ixy;
+    B1 -= tmp * Ixx * Ixz + tmp2 * Ixy * Iyz;
+    A11 *= 3; B1 *= 3;                                     // :537-540
+  } else {
+    if (half_delta_over3) {
+      float t[3], n[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { t[c] = p.Iz[c] + p.Ix[c] * u; n[c] = p.Ix[c] * p.Ix[c] + p.Iy[c] * p.Iy[c] + dnorm; }
+      const float tmp = m * half_delta_over3 / sqrtf(t[0] * t[0] / n[0] + t[1] * t[1] / n[1] + t[2] * t[2] / n[2] + epsc);
+      const float k[3] = {tmp / n[0], tmp / n[1], tmp / n[2]};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { A11 += k[c] * p.Ix[c] * p.Ix[c]; B1 -= k[c] * p.Iz[c] * p.Ix[c]; }
+    }
+    float n1[3], n2[3], t1[3], t2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      n1[c] = p.Ixx[c] * p.Ixx[c] + p.Ixy[c] * p.Ixy[c] + dnorm; n2[c] = p.Iyy[c] * p.Iyy[c] + p.Ixy[c] * p.Ixy[c] + dnorm;
+      t1[c] = p.Ixz[c] + p.Ixx[c] * u;                           t2[c] = p.Iyz[c] + p.Ixy[c] * u;
+    }
+    const float tmp = m * half_gamma_over3 / sqrtf(t1[0] * t1[0] / n1[0] + t2[0] * t2[0] / n2[0] + t1[1] * t1[1] / n1[1] +
+                                                   t2[1] * t2[1] / n2[1] + t1[2] * t1[2] / n1[2] + t2[2] * t2[2] / n2[2] + epsg);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float ka = tmp / n1[c], kb = tmp / n2[c];
+      A11 += ka * p.Ixx[c] * p.Ixx[c] + kb * p.Ixy[c] * p.Ixy[c];
+      B1 -= ka * p.Ixx[c] * p.Ixz[c] + kb * p.Ixy[c] * p.Iyz[c];
+    }
+  }
+  // sub_laplacian(b1, wx): -left, +right, -top, +bottom
+  if (i > 0)     B1 -= hl * (p.wxc - p.wxl);
+  if (i < w - 1) B1 += hr * (p.wxr - p.wxc);
+  if (j > 0)     B1 -= vt * (p.wxc - p.wxt);
+  if (j < h - 1) B1 += vb * (p.wxb - p.wxc);
+  de_plane(a, pair, DE_A11)[o] = A11;
+  de_plane(a, pair, DE_B1)[o] = B1;
+  de_plane(a, pair, DE_SH)[o] = hr;
+  de_plane(a, pair, DE_SV)[o] = vb;
+}
+
+// The sweeps of sor_coupled_slow_but_readable_DE as an anti-diagonal wavefront, one workgroup per pair, thread r = image
+// row r.  Pixel (i, j) of sweep n runs at step i + j + 2n: after its NEW top/left neighbours (same sweep, one step earlier)
+// and with the OLD bottom/right ones (previous sweep, also one step earlier) -- the dependencies of the serial row-major
+// loops, hence the same floats.  One barrier per step.  du lives in LDS when the level fits (LDS_DU), the coefficient
+// planes are read one step ahead of their use.  Afterwards: uu = min/max(wx + du, 0) (refine_variational.cpp:299-314).
+extern __shared__ float fotg_de_lds[];
+template <int SW, bool LDS_DU>
+__global__ __launch_bounds__(1024) void vr_de_sor_kernel(VrArgs a, float omega, int camlr)
+{
+  const int pair = blockIdx.x, w = a.w, h = a.h, st = a.st, j = threadIdx.x;
+  const float *__restrict__ a11 = de_plane(a, pair, DE_A11), *__restrict__ b1 = de_plane(a, pair, DE_B1);
+  const float *__restrict__ sh = de_plane(a, pair, DE_SH), *__restrict__ sv = de_plane(a, pair, DE_SV);
+  float *dug = de_plane(a, pair, DE_DU);
+  float *du = LDS_DU ? fotg_de_lds : dug;
+  if (LDS_DU) {
+    for (int k = threadIdx.x; k < st * h; k += blockDim.x) du[k] = dug[k];
+    __syncthreads();
+  }
+  struct Coef { float a, b, h, v, vt; };
+  const bool row = j < h;
+  auto load = [&](int i) {
+    Coef c = {1.f, 0.f, 0.f, 0.f, 0.f};
+    if (row && i >= 0 && i < w) {
+      const int o = j * st + i;
+      c.a = a11[o]; c.b = b1[o]; c.h = sh[o]; c.v = sv[o]; c.vt = j > 0 ? sv[o - st] : 0.f;
+    }
+    return c;
+  };
+  Coef cur[SW];
+  float hl[SW];                                   // sh of the previous pixel of the row (psi towards the left neighbour)
+#pragma unroll
+  for (int n = 0; n < SW; ++n) { cur[n] = load(0 - j - 2 * n); hl[n] = 0.f; }
+  const float om1 = 1.0f - omega;
+  const int T = w + h - 1 + 2 * (SW - 1);
+  for (int t = 0; t < T; ++t) {
+    Coef nxt[SW];
+#pragma unroll
+    for (int n = 0; n < SW; ++n) nxt[n] = load(t + 1 - j - 2 * n);
+#pragma unroll
+    for (int n = 0; n < SW; ++n) {
+      const int i = t - j - 2 * n;
+      if (row && i >= 0 && i < w) {
+        const int o = j * st + i;
+        const Coef c = cur[n];
+        float sigma_u = 0.0f, sum_dpsis = 0.0f;
+        if (j > 0)     { sigma_u -= c.vt * du[o - st];  sum_dpsis += c.vt; }
+        if (i > 0)     { sigma_u -= hl[n] * du[o - 1];  sum_dpsis += hl[n]; }
+        if (j < h - 1) { sigma_u -= c.v * du[o + st];   sum_dpsis += c.v; }
+        if (i < w - 1) { sigma_u -= c.h * du[o + 1];    sum_dpsis += c.h; }
+        const float A11 = c.a + sum_dpsis;
+        const float B1 = c.b - sigma_u;
+        du[o] = om1 * du[o] + omega * (B1 / A11);
+        hl[n] = c.h;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < SW; ++n) cur[n] = nxt[n];
+  }
+  const float *wx = a.single(pair, P_WX);
+  float *uu = de_plane(a, pair, DE_UU);
+  for (int k = threadIdx.x; k < w * h; k += blockDim.x) {
+    const int o = (k / w) * st + k % w;
+    const float d = du[o];
+    if (LDS_DU) dug[o] = d;
+    const float s = wx[o] + d;
+    uu[o] = camlr == 0 ? (s < 0.0f ? s : 0.0f) : (s > 0.0f ? s : 0.0f);
+  }
+}
+
+__global__ __launch_bounds__(256) void vr_de_finish_kernel(VrArgs a, float *__restrict__ flow, long flow_stride)
+{
+  const WgId wg = xcd_local_wg();
+  const int idx = wg.x * blockDim.x + threadIdx.x;
+  if (idx >= a.w * a.h) return;
+  const int pair = wg.y, o = (idx / a.w) * a.st + idx % a.w;
+  flow[(size_t)pair * flow_stride + idx] = de_plane(a, pair, DE_UU)[o];          // :316-317, one channel
+}
+
+}  // namespace fotg

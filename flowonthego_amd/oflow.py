@@ -59,6 +59,7 @@ class OFClass:
         if _i_params.padding not in (0, self.op.patch_size):
             raise FotgError("img_params.padding must equal patch_size (src/run_dense.cpp:263)")
         self.device = torch.device("cuda", device)
+        self.nch = 1 if self.op.depth_mode else 2          # flow channels (stereo depth: one displacement, kroeger/oflow.cpp:76-80)
         h = C.c_void_p()
         cp = self.op.to_c()
         check(lib().fotg_create(cp, self.width_org, self.height_org, device, self.max_batch, h))
@@ -83,7 +84,7 @@ class OFClass:
 
     def new_outflow(self, n=1):
         w, h = self.out_size()
-        return torch.empty((n, h, w, 2), dtype=torch.float32, device=self.device)
+        return torch.empty((n, h, w, self.nch), dtype=torch.float32, device=self.device)
 
     # -- the reference call ---------------------------------------------------------------------------------
     def calc(self, _I0, _I1, _iparams=None, initflow=None, outflow=None):
@@ -146,7 +147,7 @@ class OFClass:
         flow = _dev_f32(flow, "flow")
         n = flow.shape[0]
         if out is None:
-            out = torch.empty((n, self.height_org, self.width_org, 2), dtype=torch.float32, device=self.device)
+            out = torch.empty((n, self.height_org, self.width_org, self.nch), dtype=torch.float32, device=self.device)
         check(lib().fotg_upsample_crop(self._h, n, _ptr(flow), _ptr(out), _stream()))
         return out
 
@@ -240,12 +241,16 @@ class PatGridClass:
         self._keep.append(flow_prev)
         check(lib().fotg_grid_init_from_coarser(self._ofc._h, self.lvl, self._n, _ptr(flow_prev), _stream()))
 
+    def SetCamera(self, camlr):
+        """depth mode: camparam::camlr of this grid (kroeger/oflow.h:28; 0 left: displacement <= 0, 1 right: >= 0)"""
+        check(lib().fotg_grid_set_camera(self._ofc._h, self.lvl, int(camlr)))
+
     def Optimize(self):
         check(lib().fotg_grid_optimize(self._ofc._h, self.lvl, self._n, _stream()))
 
     def AggregateFlowDense(self, flowout=None):
         if flowout is None:
-            flowout = torch.empty((self._n, self.i_params.height, self.i_params.width, 2), dtype=torch.float32, device=self._ofc.device)
+            flowout = torch.empty((self._n, self.i_params.height, self.i_params.width, self._ofc.nch), dtype=torch.float32, device=self._ofc.device)
         check(lib().fotg_grid_aggregate(self._ofc._h, self.lvl, self._n, _ptr(_dev_f32(flowout, "flowout")), _stream()))
         return flowout
 

@@ -46,6 +46,7 @@ class opt_params:
     sor_mode: int = 0                # 0 lexicographic (kroeger, parity), 1 red-black (src/ ordering)
     cost_func: int = 0               # kroeger/oflow.h:45: 0 L2, 1 L1, 2 pseudo-Huber (threshold norm_outlier)
     use_fbcon: bool = False          # kroeger/oflow.h:44 usefbcon: forward-backward merge in the densification
+    depth_mode: bool = False         # kroeger SELECTMODE=2 (run_DE_*): stereo depth, one displacement channel
     # derived (src/oflow.cpp:45-48)
     outlier_thresh: float = 0.0
     steps: int = 0
@@ -72,6 +73,7 @@ class opt_params:
         p.tv_innerit, p.tv_solverit, p.tv_sor = 1, self.var_ref_iter, self.var_ref_sor_weight
         p.sor_mode = self.sor_mode
         p.costfct, p.normoutlier, p.usefbcon = self.cost_func, self.norm_outlier, int(self.use_fbcon)
+        p.depth = int(self.depth_mode)
         return p
 
 

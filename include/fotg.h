@@ -52,6 +52,11 @@ typedef struct fotg_params {
   float normoutlier;   /* 5.0: Huber threshold (kroeger/oflow.h:63; src: norm_outlier) */
   int usefbcon;        /* 0 (all operating points); 1: also compute the backward flow at every scale and merge both in the
                           densification (kroeger/oflow.h:44, oflow.cpp:160-170, patchgrid.cpp:278-375) */
+  int depth;           /* 0: optical flow (the reference's SELECTMODE=1 build, run_OF_*); 1: stereo depth (SELECTMODE=2,
+                          run_DE_*): ONE horizontal displacement per pixel -- every flow array (initflow, outflow, the
+                          per-stage flow arguments, fotg_upsample_crop) has 1 channel instead of 2; forward grid /
+                          refinement clamp the displacement to <= 0, the backward ones (usefbcon) to >= 0
+                          (kroeger/oflow.cpp:76-80,153-157, patch.cpp:188-193, refine_variational.cpp:243-330) */
 } fotg_params;
 
 typedef struct fotg_ctx fotg_ctx;
@@ -118,6 +123,9 @@ int fotg_grid_init(fotg_ctx *ctx, int level, int n, const float *I0, const float
                    long pair_stride, void *stream);                                   /* InitializeGrid */
 int fotg_grid_set_target(fotg_ctx *ctx, int level, const float *I1, long pair_stride);  /* SetTargetImage */
 int fotg_grid_init_from_coarser(fotg_ctx *ctx, int level, int n, const float *flow_prev, void *stream); /* InitializeFromCoarserOF */
+/* depth mode only: camera side of the level's grid and of fotg_varref on that level, camparam::camlr (kroeger/oflow.h:28):
+ * 0 = left camera, displacement <= 0 (default; what the forward grid uses), 1 = right camera, displacement >= 0 */
+int fotg_grid_set_camera(fotg_ctx *ctx, int level, int camlr);
 int fotg_grid_optimize(fotg_ctx *ctx, int level, int n, void *stream);                /* Optimize */
 int fotg_grid_aggregate(fotg_ctx *ctx, int level, int n, float *flowout, void *stream); /* AggregateFlowDense */
 /* test taps: copy grid state of pair `pair` to host.  Any pointer may be NULL.
@@ -138,7 +146,8 @@ int fotg_varref(fotg_ctx *ctx, int level, int n, const float *I0, const float *I
 /* test tap: copy one refinement workspace plane (stride-padded, FDF image_t layout) of pair `pair` to host.
  * The solver planes (du, dv, a11 .. sv) of levels refined entirely on chip are only written back when
  * fotg_enable_taps(ctx, 1) was called before fotg_varref.
- * name: "wx","wy","mask","du","dv","sh","sv","a11","a12","a22" (block inverse),"b1","b2","avg","Iz","Ix","Iy","Ixx","Ixy","Iyy","Ixz","Iyz" */
+ * name: "wx","wy","mask","du","dv","sh","sv","a11","a12","a22" (block inverse),"b1","b2","avg","Iz","Ix","Iy","Ixx","Ixy","Iyy","Ixz","Iyz"
+ * depth mode: "wx","mask","du","uu","s","a11","b1","sh","sv" and the image planes (a11/b1: the scalar system of compute_data_DE) */
 int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, float *host_out);
 
 /* test tap: how often an opt-in kernel variant was launched by this process ("sor_stream"); -1 for unknown names */

@@ -49,6 +49,7 @@ typedef struct {
   int sor_mode = FOTG_SOR_LEXICOGRAPHIC;
   int cost_func = 0;      // kroeger/oflow.h:45: 0 L2, 1 L1, 2 pseudo-Huber (threshold norm_outlier)
   bool use_fbcon = false; // kroeger/oflow.h:44 usefbcon: forward-backward merge in the densification
+  bool depth_mode = false; // kroeger SELECTMODE=2 build (run_DE_*): stereo depth, flow arrays have ONE channel
 } opt_params;
 
 inline fotg_params to_fotg(const opt_params &op)
@@ -62,7 +63,7 @@ inline fotg_params to_fotg(const opt_params &op)
   p.patove = op.patch_stride; p.patnorm = op.use_mean_normalization; p.noc = op.channels;
   p.usetvref = op.use_var_ref; p.tv_alpha = op.var_ref_alpha; p.tv_gamma = op.var_ref_gamma; p.tv_delta = op.var_ref_delta;
   p.tv_innerit = 1; p.tv_solverit = op.var_ref_iter; p.tv_sor = op.var_ref_sor_weight; p.sor_mode = op.sor_mode;
-  p.costfct = op.cost_func; p.normoutlier = op.norm_outlier; p.usefbcon = op.use_fbcon;
+  p.costfct = op.cost_func; p.normoutlier = op.norm_outlier; p.usefbcon = op.use_fbcon; p.depth = op.depth_mode;
   return p;
 }
 

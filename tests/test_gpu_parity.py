@@ -36,6 +36,7 @@ def oracle_params(O, op):
     p.tv_alpha, p.tv_gamma, p.tv_delta = op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta
     p.tv_innerit, p.tv_solverit, p.tv_sor = 1, op.var_ref_iter, op.var_ref_sor_weight
     p.costfct, p.normoutlier, p.usefbcon = op.cost_func, op.norm_outlier, int(op.use_fbcon)
+    p.depth = int(op.depth_mode)
     return p
 
 
