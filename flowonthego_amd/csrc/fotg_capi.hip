@@ -799,13 +799,19 @@ static int varref_depth_impl(fotg_ctx *c, int l, int n, const float *I0, const f
   LAUNCHCHK();
   const int threads = ((g.h + 63) / 64) * 64;
   const int du_bytes = g.st * g.h * (int)sizeof(float);
-  const bool lds = du_bytes <= 128 * 1024;
-  if (lds && du_bytes > 64 * 1024) {
+  // du + the four coefficient planes in LDS when they fit in the CU's 160 KiB, else du alone, else global memory
+  const int lds = 5 * du_bytes <= 160 * 1024 ? 2 : du_bytes <= 128 * 1024 ? 1 : 0;
+  const int lds_bytes = lds == 2 ? 5 * du_bytes : lds == 1 ? du_bytes : 0;
+  if (lds_bytes > 64 * 1024) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 32 && !g_de_lds_set[dev]) {
-      HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<3, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       g_de_lds_set[dev] = true;
     }
   }
@@ -816,13 +822,18 @@ static int varref_depth_impl(fotg_ctx *c, int l, int n, const float *I0, const f
     LAUNCHCHK();
     // the sweeps are sequential passes over du, so `k` single-sweep launches equal one k-sweep launch bit for bit; the
     // operating points use 3.  (With 0 sweeps the clamped update still runs: uu = min/max(wx + du, 0).)
-    if (c->p.tv_solverit == 3) {
-      if (lds) vr_de_sor_kernel<3, true><<<n, threads, du_bytes, s>>>(a, c->p.tv_sor, camlr);
-      else vr_de_sor_kernel<3, false><<<n, threads, 0, s>>>(a, c->p.tv_sor, camlr);
+    if (c->p.tv_solverit == 3 && 3 * threads <= 1024 && lds) {     // one wave group per sweep
+      if (lds == 2) vr_de_sor_kernel<3, 2, true><<<n, 3 * threads, lds_bytes, s>>>(a, c->p.tv_sor, camlr);
+      else vr_de_sor_kernel<3, 1, true><<<n, 3 * threads, lds_bytes, s>>>(a, c->p.tv_sor, camlr);
+    } else if (c->p.tv_solverit == 3) {
+      if (lds == 2) vr_de_sor_kernel<3, 2><<<n, threads, lds_bytes, s>>>(a, c->p.tv_sor, camlr);
+      else if (lds == 1) vr_de_sor_kernel<3, 1><<<n, threads, lds_bytes, s>>>(a, c->p.tv_sor, camlr);
+      else vr_de_sor_kernel<3, 0><<<n, threads, 0, s>>>(a, c->p.tv_sor, camlr);
     } else {
       for (int k = 0; k < c->p.tv_solverit; ++k) {
-        if (lds) vr_de_sor_kernel<1, true><<<n, threads, du_bytes, s>>>(a, c->p.tv_sor, camlr);
-        else vr_de_sor_kernel<1, false><<<n, threads, 0, s>>>(a, c->p.tv_sor, camlr);
+        if (lds == 2) vr_de_sor_kernel<1, 2><<<n, threads, lds_bytes, s>>>(a, c->p.tv_sor, camlr);
+        else if (lds == 1) vr_de_sor_kernel<1, 1><<<n, threads, lds_bytes, s>>>(a, c->p.tv_sor, camlr);
+        else vr_de_sor_kernel<1, 0><<<n, threads, 0, s>>>(a, c->p.tv_sor, camlr);
       }
     }
     LAUNCHCHK();

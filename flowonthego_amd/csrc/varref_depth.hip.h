@@ -124,61 +124,93 @@ __global__ __launch_bounds__(256) void vr_de_data_kernel(VrArgs a, float half_de
 // The sweeps of sor_coupled_slow_but_readable_DE as an anti-diagonal wavefront, one workgroup per pair, thread r = image
 // row r.  Pixel (i, j) of sweep n runs at step i + j + 2n: after its NEW top/left neighbours (same sweep, one step earlier)
 // and with the OLD bottom/right ones (previous sweep, also one step earlier) -- the dependencies of the serial row-major
-// loops, hence the same floats.  One barrier per step.  du lives in LDS when the level fits (LDS_DU), the coefficient
-// planes are read one step ahead of their use.  Afterwards: uu = min/max(wx + du, 0) (refine_variational.cpp:299-314).
+// loops, hence the same floats.  One barrier per step.  LDS: 2 = du and the four coefficient planes live in LDS (levels
+// up to 8192 cells: the finest level of 1080p op-pt 2 is 120x68 = 8160), 1 = only du (coefficients are read from global
+// memory one step ahead of their use), 0 = everything in global memory (levels beyond 128 KiB of du).
+// Afterwards: uu = min/max(wx + du, 0) (refine_variational.cpp:299-314).
 extern __shared__ float fotg_de_lds[];
-template <int SW, bool LDS_DU>
+// SPLIT: the SW sweeps of a step run on SW groups of waves (thread = (sweep, row); blockDim = SW * roundup64(h)) instead
+// of one after the other in each thread -- a solver wave is bound by its own instruction stream, so this divides the
+// step time by almost SW.  Needs SW * roundup64(h) <= 1024.
+template <int SW, int LDS, bool SPLIT = false>
 __global__ __launch_bounds__(1024) void vr_de_sor_kernel(VrArgs a, float omega, int camlr)
 {
-  const int pair = blockIdx.x, w = a.w, h = a.h, st = a.st, j = threadIdx.x;
+  constexpr bool LDS_DU = LDS >= 1;
+  constexpr int NS = SPLIT ? 1 : SW;               // sweeps handled by one thread
+  const int rows_pad = SPLIT ? (int)blockDim.x / SW : (int)blockDim.x;
+  const int n0 = SPLIT ? (int)threadIdx.x / rows_pad : 0;
+  const int pair = blockIdx.x, w = a.w, h = a.h, st = a.st, j = SPLIT ? (int)threadIdx.x % rows_pad : (int)threadIdx.x;
   const float *__restrict__ a11 = de_plane(a, pair, DE_A11), *__restrict__ b1 = de_plane(a, pair, DE_B1);
   const float *__restrict__ sh = de_plane(a, pair, DE_SH), *__restrict__ sv = de_plane(a, pair, DE_SV);
   float *dug = de_plane(a, pair, DE_DU);
   float *du = LDS_DU ? fotg_de_lds : dug;
   if (LDS_DU) {
-    for (int k = threadIdx.x; k < st * h; k += blockDim.x) du[k] = dug[k];
+    const int np = st * h;
+    for (int k = threadIdx.x; k < np; k += blockDim.x) du[k] = dug[k];
+    if (LDS == 2) {
+      float *l = fotg_de_lds + np;
+      for (int k = threadIdx.x; k < np; k += blockDim.x) { l[k] = a11[k]; l[np + k] = b1[k]; l[2 * np + k] = sh[k]; l[3 * np + k] = sv[k]; }
+      a11 = l; b1 = l + np; sh = l + 2 * np; sv = l + 3 * np;
+    }
     __syncthreads();
   }
+  // Branch-free step: every lane always loads (indices clamped into the image), the terms of missing neighbours are
+  // selected to 0 (x - 0 == x, x + 0 == x: the same floats as the reference's skipped statements) and only the store is
+  // predicated -- so the loads of the SW sweeps of a step are all in flight together instead of one dependent
+  // load -> divide -> store chain per sweep.  Loads first, stores last: within a step the sweeps touch disjoint
+  // diagonals (d, d-2, d-4) and read only d+-1, so this is the sequential order.
   struct Coef { float a, b, h, v, vt; };
   const bool row = j < h;
+  const int jc = row ? j : h - 1;
+  const bool has_t = jc > 0, has_b = jc < h - 1;
   auto load = [&](int i) {
-    Coef c = {1.f, 0.f, 0.f, 0.f, 0.f};
-    if (row && i >= 0 && i < w) {
-      const int o = j * st + i;
-      c.a = a11[o]; c.b = b1[o]; c.h = sh[o]; c.v = sv[o]; c.vt = j > 0 ? sv[o - st] : 0.f;
-    }
+    const int o = jc * st + clampi(i, w);
+    Coef c;
+    c.a = a11[o]; c.b = b1[o]; c.h = sh[o]; c.v = sv[o]; c.vt = sv[has_t ? o - st : o];
     return c;
   };
-  Coef cur[SW];
-  float hl[SW];                                   // sh of the previous pixel of the row (psi towards the left neighbour)
+  Coef cur[NS];
+  float hl[NS];                                   // sh of the previous pixel of the row (psi towards the left neighbour)
 #pragma unroll
-  for (int n = 0; n < SW; ++n) { cur[n] = load(0 - j - 2 * n); hl[n] = 0.f; }
+  for (int n = 0; n < NS; ++n) { cur[n] = load(0 - j - 2 * (n0 + n)); hl[n] = 0.f; }
   const float om1 = 1.0f - omega;
   const int T = w + h - 1 + 2 * (SW - 1);
   for (int t = 0; t < T; ++t) {
-    Coef nxt[SW];
+    Coef nxt[NS];
+    float own[NS], up[NS], lf[NS], dn[NS], rt[NS], res[NS];
+    int oo[NS];
+    bool valid[NS], has_l[NS], has_r[NS];
 #pragma unroll
-    for (int n = 0; n < SW; ++n) nxt[n] = load(t + 1 - j - 2 * n);
+    for (int n = 0; n < NS; ++n) {
+      const int i = t - j - 2 * (n0 + n), ic = clampi(i, w), o = jc * st + ic;
+      valid[n] = row && i >= 0 && i < w;
+      has_l[n] = ic > 0; has_r[n] = ic < w - 1;
+      oo[n] = o;
+      own[n] = du[o];
+      up[n] = du[has_t ? o - st : o];
+      lf[n] = du[has_l[n] ? o - 1 : o];
+      dn[n] = du[has_b ? o + st : o];
+      rt[n] = du[has_r[n] ? o + 1 : o];
+      nxt[n] = load(i + 1);
+    }
 #pragma unroll
-    for (int n = 0; n < SW; ++n) {
-      const int i = t - j - 2 * n;
-      if (row && i >= 0 && i < w) {
-        const int o = j * st + i;
-        const Coef c = cur[n];
-        float sigma_u = 0.0f, sum_dpsis = 0.0f;
-        if (j > 0)     { sigma_u -= c.vt * du[o - st];  sum_dpsis += c.vt; }
-        if (i > 0)     { sigma_u -= hl[n] * du[o - 1];  sum_dpsis += hl[n]; }
-        if (j < h - 1) { sigma_u -= c.v * du[o + st];   sum_dpsis += c.v; }
-        if (i < w - 1) { sigma_u -= c.h * du[o + 1];    sum_dpsis += c.h; }
-        const float A11 = c.a + sum_dpsis;
-        const float B1 = c.b - sigma_u;
-        du[o] = om1 * du[o] + omega * (B1 / A11);
-        hl[n] = c.h;
-      }
+    for (int n = 0; n < NS; ++n) {
+      const Coef c = cur[n];
+      float sigma_u = 0.0f, sum_dpsis = 0.0f;
+      sigma_u = sigma_u - (has_t ? c.vt * up[n] : 0.0f);     sum_dpsis = sum_dpsis + (has_t ? c.vt : 0.0f);
+      sigma_u = sigma_u - (has_l[n] ? hl[n] * lf[n] : 0.0f); sum_dpsis = sum_dpsis + (has_l[n] ? hl[n] : 0.0f);
+      sigma_u = sigma_u - (has_b ? c.v * dn[n] : 0.0f);      sum_dpsis = sum_dpsis + (has_b ? c.v : 0.0f);
+      sigma_u = sigma_u - (has_r[n] ? c.h * rt[n] : 0.0f);   sum_dpsis = sum_dpsis + (has_r[n] ? c.h : 0.0f);
+      const float A11 = c.a + sum_dpsis;
+      const float B1 = c.b - sigma_u;
+      res[n] = om1 * own[n] + omega * (B1 / A11);
+    }
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+      if (valid[n]) { du[oo[n]] = res[n]; hl[n] = cur[n].h; }
+      cur[n] = nxt[n];
     }
     __syncthreads();
-#pragma unroll
-    for (int n = 0; n < SW; ++n) cur[n] = nxt[n];
   }
   const float *wx = a.single(pair, P_WX);
   float *uu = de_plane(a, pair, DE_UU);

@@ -114,9 +114,12 @@ def test_depth_varref_golden_reference_vectors(noc):
             assert np.array_equal(flow[0, ..., 0].cpu().numpy(), z["%s/out_de%d" % (name, camlr)]), (name, camlr)
 
 
-@pytest.mark.parametrize("w,h,solverit", [(37, 19, 3), (120, 68, 3), (64, 40, 2), (250, 140, 3), (300, 170, 1)])
+@pytest.mark.parametrize("w,h,solverit", [(37, 19, 3), (120, 68, 3), (64, 40, 2), (200, 110, 3), (200, 110, 2), (300, 170, 1), (300, 170, 3),
+                                          (20, 400, 3), (60, 400, 3)])
 def test_depth_varref_sizes(w, h, solverit):
-    """level sizes with stride padding, the LDS-resident and the global-memory du variants (300x170 > 128 KiB), other sweep counts"""
+    """level sizes with stride padding; the three solver residencies (everything in LDS up to 8192 cells, du alone in LDS
+    up to 128 KiB, global memory beyond: 300x170), one wave group per sweep (up to 341 rows) or all sweeps in each thread
+    (the 400-row cases), other sweep counts"""
     F, OFClass, VarRefClass, O = _mods()
     lvl = 2
     f0, f1, _ = stereo_pair(h, w, seed=w)
