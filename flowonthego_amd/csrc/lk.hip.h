@@ -9,8 +9,8 @@
 //
 // Mapping: pixel q of the PSxPS patch lives in lane q%64, slot q/64 (8x8: exactly one pixel per lane;
 // 12x12: 3 slots, the last one 16 lanes wide).  Template, both gradients and the residual stay in
-// VGPRs for the whole loop; the three reductions per iteration (two projections, query mean, L1
-// residual) are wave butterflies (wave_sum) whose order is the oracle's dis_sum().  All lanes carry
+// VGPRs for the whole loop; the reductions of an iteration (query mean; two projections and the L1
+// residual) are packed wave butterflies (wave_sum_multi) whose order is the oracle's dis_sum().  All lanes carry
 // the same scalar state, so the 2x2 Cholesky solve and the termination tests are computed redundantly
 // and the loop branch is wave-uniform.  The part of I1 the patch can reach -- it may move at most ps/2 from its start
 // before it is reset (patch.cpp:199) -- is staged once into a wave-private LDS window of (2ps+4)^2 pixels, so the
@@ -137,17 +137,6 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
         r[k][s * NOC + c] = 0.f; wabs[k][s * NOC + c] = 0.f;
       }
     }
-    if (a.patnorm > 0) {                                           // patch.cpp:330-331
-      const float m = wave_sum(lane_sum(T[k])) / (float)NV;
-#pragma unroll
-      for (int e = 0; e < NE; ++e) T[k][e] -= m;
-    }
-    h00u[k] = wave_sum(lane_dot(Tx[k], Tx[k]));
-    if constexpr (DEPTH) { h01u[k] = 0.f; h11u[k] = 0.f; }
-    else {
-      h01u[k] = wave_sum(lane_dot(Tx[k], Ty[k]));
-      h11u[k] = wave_sum(lane_dot(Ty[k], Ty[k]));
-    }
     float pin0 = 0.f, pin1 = 0.f;
     if (a.flow_prev) {
       const int fx = (int)floorf(rx / 2), fy = (int)floorf(ry / 2);
@@ -169,6 +158,36 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
 #pragma unroll
         for (int c = 0; c < NOC; ++c) win[t * NOC + c] = I1[src + c];
       }
+    }
+  }
+
+  // template mean (patch.cpp:330-331) and Hessian sums (:74-77, depth :84) of all NP patches, reduced together
+  if (a.patnorm > 0) {
+    float ms[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) ms[k] = lane_sum(T[k]);
+    wave_sum_multi<NP>(ms);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const float m = ms[k] / (float)NV;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) T[k][e] -= m;
+    }
+  }
+  {
+    constexpr int NH = DEPTH ? 1 : 3;
+    float hs[NH * NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      hs[NH * k] = lane_dot(Tx[k], Tx[k]);
+      if constexpr (!DEPTH) { hs[NH * k + 1] = lane_dot(Tx[k], Ty[k]); hs[NH * k + 2] = lane_dot(Ty[k], Ty[k]); }
+    }
+    wave_sum_multi<NH * NP>(hs);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      h00u[k] = hs[NH * k];
+      h01u[k] = DEPTH ? 0.f : hs[NH * k + (DEPTH ? 0 : 1)];
+      h11u[k] = DEPTH ? 0.f : hs[NH * k + (DEPTH ? 0 : 2)];
     }
   }
 
@@ -200,18 +219,99 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
   if (trace && VALID && (lane % G) < 4)
     for (int t = 0; t <= a.max_iter; ++t) trace[(size_t)IP * trow + t * 4 + (lane % G)] = 0.f;
 
-  bool first = true;
-  while (first || __builtin_amdgcn_ballot_w64(!CONV) != 0) {
-    const bool ACT = first ? START_OK : !CONV;           // patches that run this iteration
-    if (!first) {
-      // projection on the steepest-descent images (:178-179), per patch
-      float b0u[NP], b1u[NP];
+  // ---- OptimizeComputeErrImg (:264-284) for the patches in ACT: bilinear query patch (:335-402), mean, residual, and the
+  //      three sums every patch needs next -- the two projections on the steepest-descent images (:178-179, used by the NEXT
+  //      update) and the L1 residual (:278) -- reduced together for all NP patches (wave_sum_multi)
+  float B0 = 0.f, B1 = 0.f;
+  auto eval = [&](const bool ACT) {
+    const int pos2 = (int)floorf(PTX), pos3 = (int)floorf(PTY);
+    const int pos0 = (int)ceilf(PTX + .00001f) + PAD - WX0, pos1 = (int)ceilf(PTY + .00001f) + PAD - WY0;   // window coordinates
+    const float r0 = PTX - (float)pos2, r1 = PTY - (float)pos3;
+    const float WE0 = r0 * r1, WE1 = (1 - r0) * r1, WE2 = r0 * (1 - r1), WE3 = (1 - r0) * (1 - r1);
+    const int IA = (pos1 * WIN + pos0) * NOC;
+    const int ACTI = ACT ? 1 : 0;
+    float q[NP][NE], ms[NP];
+    bool act[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      act[k] = geti(ACTI, k) != 0;                         // wave-uniform
+#pragma unroll
+      for (int e = 0; e < NE; ++e) q[k][e] = 0.f;
+      if (act[k]) {
+        const float *win = win_all[wave][k];
+        const int iab = geti(IA, k);
+        const float we0 = getf(WE0, k), we1 = getf(WE1, k), we2 = getf(WE2, k), we3 = getf(WE3, k);
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+          const int ia = iab + poff[s];
+          const int ic = ia - WIN * NOC;
+#pragma unroll
+          for (int c = 0; c < NOC; ++c) {
+            if (have[s]) {
+              const float va = win[ia + c], vb = win[ia - NOC + c], vc = win[ic + c], vd = win[ic - NOC + c];
+              q[k][s * NOC + c] = we0 * va + we1 * vb + we2 * vc + we3 * vd;
+            }
+          }
+        }
+      }
+      ms[k] = lane_sum(q[k]);
+    }
+    if (a.patnorm > 0) {
+      wave_sum_multi<NP>(ms);
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        b0u[k] = wave_sum(lane_dot(Tx[k], r[k]));
-        b1u[k] = DEPTH ? 0.f : wave_sum(lane_dot(Ty[k], r[k]));
+        const float m = ms[k] / (float)NV;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) q[k][e] -= m;
       }
-      const float B0 = packf(b0u), B1 = packf(b1u);
+    }
+    constexpr int NR = DEPTH ? 2 : 3;
+    float red[NR * NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      if (act[k]) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          float d = q[k][e] - T[k][e];                           // :230-236 L2: the difference image itself
+          if (a.costfct == 1) d = copysignf(sqrtf(fabsf(d)), d);                                      // :238-246 L1
+          else if (a.costfct == 2) d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / a.huber_bsq) - 1.0f) * a.huber_2bsq), d);   // :247-261
+          r[k][e] = d; wabs[k][e] = fabsf(d);
+        }
+      }
+      red[NR * k] = lane_dot(Tx[k], r[k]);
+      if constexpr (!DEPTH) red[NR * k + 1] = lane_dot(Ty[k], r[k]);
+      red[NR * k + NR - 1] = lane_sum(wabs[k]);
+    }
+    wave_sum_multi<NR * NP>(red);
+    float b0u[NP], b1u[NP], maresu[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      b0u[k] = red[NR * k];
+      b1u[k] = DEPTH ? 0.f : red[NR * k + (DEPTH ? 0 : 1)];
+      maresu[k] = act[k] ? red[NR * k + NR - 1] / (float)NV : 0.f;   // :278
+    }
+    B0 = packf(b0u); B1 = packf(b1u);
+    const float MN = packf(maresu);
+    if (ACT) {
+      const float dpn = DP0 * DP0 + DP1 * DP1;           // :272
+      if (CNT == 1) DPN_INIT = dpn;
+      MARES_OLD = MARES;
+      MARES = MN;
+      // :279-282 (the two rate tests only matter once cnt >= min_iter)
+      bool go = (CNT < a.max_iter) & (MARES > a.res_thresh);
+      if (go && CNT >= a.min_iter) go = (dpn / DPN_INIT >= a.dp_thresh_sq) & (MARES / MARES_OLD <= a.dr_thresh);
+      if (!go) CONV = true;
+      if (trace && (lane % G) == 0 && CNT <= a.max_iter) {
+        float *tr = trace + (size_t)IP * trow + CNT * 4;
+        tr[0] = P0; tr[1] = P1; tr[2] = MARES; tr[3] = (float)CNT;
+      }
+    }
+  };
+
+  eval(START_OK);                                        // OptimizeStart's first error image (:154)
+  while (__builtin_amdgcn_ballot_w64(!CONV) != 0) {
+    const bool ACT = !CONV;                              // patches that run this iteration
+    {
       // 2x2 LLT solve (:184), packed; depth mode: the 1x1 system, L = sqrt(H)
       const float y0 = B0 / L00;
       float x0, x1;
@@ -239,67 +339,7 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
         if (reset) CONV = true;
       }
     }
-    // ---- OptimizeComputeErrImg (:264-284): bilinear query patch (:335-402), mean, residual ----
-    {
-      const int pos2 = (int)floorf(PTX), pos3 = (int)floorf(PTY);
-      const int pos0 = (int)ceilf(PTX + .00001f) + PAD - WX0, pos1 = (int)ceilf(PTY + .00001f) + PAD - WY0;   // window coordinates
-      const float r0 = PTX - (float)pos2, r1 = PTY - (float)pos3;
-      const float WE0 = r0 * r1, WE1 = (1 - r0) * r1, WE2 = r0 * (1 - r1), WE3 = (1 - r0) * (1 - r1);
-      const int IA = (pos1 * WIN + pos0) * NOC;
-      const int ACTI = ACT ? 1 : 0;
-      float maresu[NP];
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        maresu[k] = 0.f;
-        if (geti(ACTI, k)) {                             // wave-uniform
-          const float *win = win_all[wave][k];
-          const int iab = geti(IA, k);
-          const float we0 = getf(WE0, k), we1 = getf(WE1, k), we2 = getf(WE2, k), we3 = getf(WE3, k);
-          float q[NE];
-#pragma unroll
-          for (int s = 0; s < NSLOT; ++s) {
-            const int ia = iab + poff[s];
-            const int ic = ia - WIN * NOC;
-#pragma unroll
-            for (int c = 0; c < NOC; ++c) {
-              if (have[s]) {
-                const float va = win[ia + c], vb = win[ia - NOC + c], vc = win[ic + c], vd = win[ic - NOC + c];
-                q[s * NOC + c] = we0 * va + we1 * vb + we2 * vc + we3 * vd;
-              } else q[s * NOC + c] = 0.f;
-            }
-          }
-          if (a.patnorm > 0) {
-            const float m = wave_sum(lane_sum(q)) / (float)NV;
-#pragma unroll
-            for (int e = 0; e < NE; ++e) q[e] -= m;
-          }
-#pragma unroll
-          for (int e = 0; e < NE; ++e) {
-            float d = q[e] - T[k][e];                            // :230-236 L2: the difference image itself
-            if (a.costfct == 1) d = copysignf(sqrtf(fabsf(d)), d);                                      // :238-246 L1
-            else if (a.costfct == 2) d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / a.huber_bsq) - 1.0f) * a.huber_2bsq), d);   // :247-261
-            r[k][e] = d; wabs[k][e] = fabsf(d);
-          }
-          maresu[k] = wave_sum(lane_sum(wabs[k])) / (float)NV;   // :278
-        }
-      }
-      const float MN = packf(maresu);
-      if (ACT) {
-        const float dpn = DP0 * DP0 + DP1 * DP1;           // :272
-        if (CNT == 1) DPN_INIT = dpn;
-        MARES_OLD = MARES;
-        MARES = MN;
-        // :279-282 (the two rate tests only matter once cnt >= min_iter)
-        bool go = (CNT < a.max_iter) & (MARES > a.res_thresh);
-        if (go && CNT >= a.min_iter) go = (dpn / DPN_INIT >= a.dp_thresh_sq) & (MARES / MARES_OLD <= a.dr_thresh);
-        if (!go) CONV = true;
-        if (trace && (lane % G) == 0 && CNT <= a.max_iter) {
-          float *tr = trace + (size_t)IP * trow + CNT * 4;
-          tr[0] = P0; tr[1] = P1; tr[2] = MARES; tr[3] = (float)CNT;
-        }
-      }
-    }
-    first = false;
+    eval(ACT);
   }
 
   // ---- results ----

@@ -158,7 +158,7 @@ float dis_sum(const float *v, int n, int noc)
     int l = (e / noc) & 63;
     if (!used[l]) { lane[l] = v[e]; used[l] = 1; } else lane[l] = lane[l] + v[e];
   }
-  for (int k = 1; k < 64; k <<= 1) {
+  for (int k = 32; k >= 1; k >>= 1) {
     float t[64];
     for (int i = 0; i < 64; ++i) t[i] = lane[i] + lane[i ^ k];
     memcpy(lane, t, sizeof(t));

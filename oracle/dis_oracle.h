@@ -72,7 +72,7 @@ int dis_level_h(const dis_pyramid *p, int l);
 /* The reduction every per-patch sum uses (template mean, Hessian, projections, query mean,
  * L1 residual).  Element e of n belongs to pixel e/noc; pixel q to lane q%64.  Each lane adds its
  * elements in increasing e; the 64 lane sums are then combined by the balanced tree
- * v[i] += v[i^1], ^2, ^4, ^8, ^16, ^32.  (kroeger: Eigen .sum(), patch.cpp:74-76,178-179,278,331.) */
+ * v[i] += v[i^32], ^16, ^8, ^4, ^2, ^1.  (kroeger: Eigen .sum(), patch.cpp:74-76,178-179,278,331.) */
 float dis_sum(const float *v, int n, int noc);
 
 /* ---- patch grid (kroeger/patchgrid.cpp) ---- */

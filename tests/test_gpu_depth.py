@@ -176,3 +176,22 @@ def test_depth_unsupported_combinations():
     op.sor_mode = 1                      # red-black ordering exists only for the coupled optical-flow system
     with pytest.raises(F.FotgError):
         OFClass(op, F.img_params(width=640, height=360, padding=8))
+
+
+def test_depth_u8_and_sequence_entry_points():
+    """the other front-ends of the same path in depth mode: 8-bit frames and the video entry point (one pyramid per frame)"""
+    F, OFClass, _, O = _mods()
+    f0, f1, _ = stereo_pair(270, 500, seed=33)
+    f2 = np.roll(f1, -3, axis=1)
+    h, w = f0.shape
+    op = depth_op(F, 2, w, 1)
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+    I0 = torch.stack([dev(f0), dev(f1)])
+    I1 = torch.stack([dev(f1), dev(f2)])
+    ref = ofc.calc_batch(I0, I1).cpu().numpy()
+    p = oracle_params(O, op)
+    assert np.array_equal(ref[0], O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0))
+    assert np.array_equal(ofc.calc_batch_u8(I0.to(torch.uint8), I1.to(torch.uint8)).cpu().numpy(), ref)
+    seq = torch.stack([dev(f0), dev(f1), dev(f2)])
+    assert np.array_equal(ofc.calc_sequence(seq).cpu().numpy(), ref)
+    assert np.array_equal(ofc.calc_sequence(seq.to(torch.uint8)).cpu().numpy(), ref)
