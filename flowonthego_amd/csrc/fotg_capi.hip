@@ -463,7 +463,10 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   // Patches per wave (packed scalar domain).  More patches per wave = fewer wave instructions per patch but a longer
   // wave, so only when the launch is throughput bound (enough patches to fill the GPU several times over).
   dim3 block(256);
-  int np = ((long)n * g.nop >= 4096) ? 2 : 1;          // measured (MI355X, 64 x 1080p): NP 2 beats 1 and 4 at 8.6k and 32k patches, NP 1 wins at 2.5k
+  // measured (MI355X, 64 x 1080p, packed reductions): 32.6k patches: NP 4 0.083 ms, NP 2 0.087; 8.6k: NP 2 0.034, NP 4 0.040;
+  // 2.5k: NP 1 0.018, NP 2 0.020
+  const long npatch = (long)n * g.nop;
+  int np = npatch >= 24576 ? 4 : npatch >= 4096 ? 2 : 1;
   if (const char *e = getenv("FOTG_LK_NP")) np = atoi(e);
 #define LK(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
 #define LKD(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_, true><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
