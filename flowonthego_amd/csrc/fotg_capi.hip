@@ -755,13 +755,14 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     LAUNCHCHK();
     return FOTG_OK;
   }
-  HIPCHK(hipMemsetAsync(a.D, 0, (size_t)n * a.d_pair_stride * sizeof(float2), s));      // image_erase(du), image_erase(dv) (:185-186)
   const char *esetup = getenv("FOTG_VR_SETUP");
   if (!esetup || atoi(esetup)) {
-    // warp + first + second derivatives in one tiled launch (FOTG_VR_SETUP=0: the three plane-at-a-time launches; tests)
-    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
+    // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
+    // (FOTG_VR_SETUP=0: memset + the three plane-at-a-time launches; tests)
+    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1);
     LAUNCHCHK();
   } else {
+    HIPCHK(hipMemsetAsync(a.D, 0, (size_t)n * a.d_pair_stride * sizeof(float2), s));      // image_erase(du), image_erase(dv) (:185-186)
     vr_prep_kernel<NOC><<<grid, block, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
     LAUNCHCHK();
     vr_deriv1_kernel<NOC><<<grid, block, 0, s>>>(a);

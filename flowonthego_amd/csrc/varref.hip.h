@@ -189,13 +189,18 @@ __global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
 template <int NOC, int NCH = 2>
 __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__restrict__ I0, const float *__restrict__ I1,
                                                        long img_stride, int tw, int pad,
-                                                       const float *__restrict__ flow, long flow_stride)
+                                                       const float *__restrict__ flow, long flow_stride, int zero_d = 0)
 {
   constexpr int TW_ = 32, TH_ = 8, XW = TW_ + 8, XH = TH_ + 8, YW = TW_ + 4, YH = TH_ + 4;
   __shared__ float Xa[NOC][XH * XW], Xz[NOC][XH * XW], Yx[NOC][YH * YW], Yy[NOC][YH * YW];
   const WgId wg = xcd_local_wg();
   const int pair = wg.y, w = a.w, h = a.h;
   const int tiles_x = (w + TW_ - 1) / TW_;
+  if (zero_d) {
+    // image_erase(du), image_erase(dv) (refine_variational.cpp:185-186): the pair's tiles share the zeroing of its skewed D
+    float2 *D = a.Dp(pair);
+    for (long k = (long)wg.x * 256 + threadIdx.x; k < a.d_pair_stride; k += (long)gridDim.x * 256) D[k] = make_float2(0.f, 0.f);
+  }
   const int tx0 = (wg.x % tiles_x) * TW_, ty0 = (wg.x / tiles_x) * TH_;
   // stage A: warp + mask + average / difference at the clamped coordinate of every tile+4 position
   for (int e = threadIdx.x; e < XW * XH; e += 256) {

@@ -22,6 +22,7 @@ for k in range(n):
     f0, f1 = synth_pair(h, w, seed=1000 + k, noc=noc)
     op = F.operating_point(op_point, w, noc)
     op.cost_func = int(rng.integers(0, 3)); op.use_fbcon = bool(rng.integers(0, 4) == 0)
+    op.depth_mode = bool(rng.integers(0, 3) == 0)             # stereo depth mode (one displacement channel)
     try:
         ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
     except F.FotgError as e:
@@ -32,7 +33,7 @@ for k in range(n):
     ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
     ok = np.array_equal(out, ref)
     bad += not ok
-    print(k, (w, h, op_point, noc, op.cost_func, op.use_fbcon), "rows@finest", ref.shape[0], "OK" if ok else "MISMATCH max %g" % np.abs(out - ref).max(), flush=True)
+    print(k, (w, h, op_point, noc, op.cost_func, op.use_fbcon, op.depth_mode), "rows@finest", ref.shape[0], "OK" if ok else "MISMATCH max %g" % np.abs(out - ref).max(), flush=True)
     ofc.close()
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
