@@ -799,10 +799,26 @@ static int varref_depth_impl(fotg_ctx *c, int l, int n, const float *I0, const f
   const int inner = c->p.tv_innerit * (l + 1);
   vr_setup_kernel<NOC, 1><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
   LAUNCHCHK();
-  vr_de_init_kernel<<<grid, block, 0, s>>>(a);
-  LAUNCHCHK();
   const int threads = ((g.h + 63) / 64) * 64;
   const int du_bytes = g.st * g.h * (int)sizeof(float);
+  // levels up to 8192 cells with the operating points' three sweeps: everything after the set-up in one launch per level
+  // (FOTG_VR_PATH != 0 forces the launch-per-stage path below; tests)
+  if (5 * du_bytes <= 160 * 1024 && c->p.tv_solverit == 3 && 3 * threads <= 1024 && vr_path_override() == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool set[32];
+    if (dev >= 0 && dev < 32 && !set[dev]) {
+      HIPCHK(hipFuncSetAttribute((const void *)vr_de_inner_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)vr_de_inner_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      set[dev] = true;
+    }
+    vr_de_inner_kernel<NOC><<<n, 1024, 5 * du_bytes, s>>>(a, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, camlr,
+                                                          flow, fs, threads, c->taps ? 1 : 0);
+    LAUNCHCHK();
+    return FOTG_OK;
+  }
+  vr_de_init_kernel<<<grid, block, 0, s>>>(a);
+  LAUNCHCHK();
   // du + the four coefficient planes in LDS when they fit in the CU's 160 KiB, else du alone, else global memory
   const int lds = 5 * du_bytes <= 160 * 1024 ? 2 : du_bytes <= 128 * 1024 ? 1 : 0;
   const int lds_bytes = lds == 2 ? 5 * du_bytes : lds == 1 ? du_bytes : 0;

@@ -46,22 +46,12 @@ __global__ __launch_bounds__(256) void vr_de_smooth_kernel(VrArgs a, float quart
   de_plane(a, pair, DE_S)[o] = smooth_w(at(ol), at(o), at(orr), at(ot), at(ob), j, a.h, quarter_alpha);
 }
 
-// compute_smoothness second half (:141-163), compute_data_DE (:446-540), sub_laplacian(b1, wx) (:172-199)
+// compute_data_DE (opticalflow_aux.c:446-540) + sub_laplacian(b1, wx) (:172-199) for pixel (i, j): the scalar system (a11, b1)
+// given the increment u = du and the four smoothness pair sums
 template <int NOC>
-__global__ __launch_bounds__(256) void vr_de_data_kernel(VrArgs a, float half_delta_over3, float half_gamma_over3)
+__device__ __forceinline__ void de_data_pixel(const PixIn<NOC> &p, float u, float hr, float hl, float vb, float vt, int i, int j, int w, int h,
+                                              float half_delta_over3, float half_gamma_over3, float &A11_out, float &B1_out)
 {
-  const WgId wg = xcd_local_wg();
-  const int idx = wg.x * blockDim.x + threadIdx.x;
-  if (idx >= a.w * a.h) return;
-  const int pair = wg.y, w = a.w, h = a.h, i = idx % w, j = idx / w, st = a.st, o = j * st + i;
-  const PixIn<NOC> p = data_load<NOC>(a, pair, i, j);
-  const float *s = de_plane(a, pair, DE_S);
-  const float s_o = s[o];
-  const float hr = (i < w - 1) ? s_o + s[o + 1] : 0.0f;
-  const float hl = (i > 0) ? s[o - 1] + s_o : 0.0f;
-  const float vb = (j < h - 1) ? s_o + s[o + st] : 0.0f;
-  const float vt = (j > 0) ? s[o - st] + s_o : 0.0f;
-  const float u = de_plane(a, pair, DE_DU)[o];
   const float dnorm = 0.1f * 0.1f, epsc = 0.001f * 0.001f, epsg = 0.001f * 0.001f;
   const float m = p.m;
   float A11 = 0, B1 = 0;
@@ -115,6 +105,26 @@ __global__ __launch_bounds__(256) void vr_de_data_kernel(VrArgs a, float half_de
   if (i < w - 1) B1 += hr * (p.wxr - p.wxc);
   if (j > 0)     B1 -= vt * (p.wxc - p.wxt);
   if (j < h - 1) B1 += vb * (p.wxb - p.wxc);
+  A11_out = A11; B1_out = B1;
+}
+
+// compute_smoothness second half (:141-163) + de_data_pixel, one thread per pixel
+template <int NOC>
+__global__ __launch_bounds__(256) void vr_de_data_kernel(VrArgs a, float half_delta_over3, float half_gamma_over3)
+{
+  const WgId wg = xcd_local_wg();
+  const int idx = wg.x * blockDim.x + threadIdx.x;
+  if (idx >= a.w * a.h) return;
+  const int pair = wg.y, w = a.w, h = a.h, i = idx % w, j = idx / w, st = a.st, o = j * st + i;
+  const PixIn<NOC> p = data_load<NOC>(a, pair, i, j);
+  const float *s = de_plane(a, pair, DE_S);
+  const float s_o = s[o];
+  const float hr = (i < w - 1) ? s_o + s[o + 1] : 0.0f;
+  const float hl = (i > 0) ? s[o - 1] + s_o : 0.0f;
+  const float vb = (j < h - 1) ? s_o + s[o + st] : 0.0f;
+  const float vt = (j > 0) ? s[o - st] + s_o : 0.0f;
+  float A11, B1;
+  de_data_pixel<NOC>(p, de_plane(a, pair, DE_DU)[o], hr, hl, vb, vt, i, j, w, h, half_delta_over3, half_gamma_over3, A11, B1);
   de_plane(a, pair, DE_A11)[o] = A11;
   de_plane(a, pair, DE_B1)[o] = B1;
   de_plane(a, pair, DE_SH)[o] = hr;
@@ -220,6 +230,95 @@ __global__ __launch_bounds__(1024) void vr_de_sor_kernel(VrArgs a, float omega, 
     if (LDS_DU) dug[o] = d;
     const float s = wx[o] + d;
     uu[o] = camlr == 0 ? (s < 0.0f ? s : 0.0f) : (s > 0.0f ? s : 0.0f);
+  }
+}
+
+// The whole level after the set-up stage in ONE launch, one workgroup (1024 threads) per pair, for levels whose five planes
+// du, uu, s, a11, b1 fit in LDS (<= 8192 cells): per inner iteration the smoothness weights, the data term (per-pixel
+// phases, all threads), the three sweeps (the wave groups of vr_de_sor_kernel's SPLIT form; the other waves only keep the
+// barriers) and the clamped update -- nothing but the per-pixel image terms is read from global memory in between, and
+// nothing is written until the final uu.  The solver forms psi from the s plane on the fly (sh = s + s_right etc., the
+// same additions compute_smoothness makes), so sh / sv need no planes.  taps: also store du, uu, s, a11, b1, sh, sv of
+// the last inner iteration to the workspace planes for fotg_varref_plane.
+template <int NOC>
+__global__ __launch_bounds__(1024) void vr_de_inner_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
+                                                           float half_gamma_over3, float omega, int camlr, float *__restrict__ flow,
+                                                           long flow_stride, int rows_pad, int taps)
+{
+  constexpr int SW = 3;
+  const int pair = blockIdx.x, w = a.w, h = a.h, st = a.st, np = st * h, tid = threadIdx.x;
+  float *du = fotg_de_lds, *uu = du + np, *S = uu + np, *A = S + np, *B = A + np;
+  const float *__restrict__ wx = a.single(pair, P_WX);
+  for (int k = tid; k < np; k += 1024) { du[k] = 0.f; uu[k] = (k % st) < w ? wx[k] : 0.f; }     // :277-280
+  const bool solver = tid < SW * rows_pad;
+  const int n0 = tid / rows_pad, j = tid % rows_pad;
+  const bool row = solver && j < h;
+  const int jc = j < h ? j : h - 1;
+  const bool has_t = jc > 0, has_b = jc < h - 1;
+  const float om1 = 1.0f - omega;
+  const int T = w + h - 1 + 2 * (SW - 1);
+  __syncthreads();
+  for (int it = 0; it < inner; ++it) {
+    // compute_smoothness first half (:126-139) on (uu, 0)
+    for (int k = tid; k < w * h; k += 1024) {
+      const int i = k % w, jj = k / w, o = jj * st + i;
+      auto at = [&](int q) { return make_float2(uu[q], 0.f); };
+      const int ol = i > 0 ? o - 1 : o, orr = i < w - 1 ? o + 1 : o, ot = jj > 0 ? o - st : o, ob = jj < h - 1 ? o + st : o;
+      S[o] = smooth_w(at(ol), at(o), at(orr), at(ot), at(ob), jj, h, quarter_alpha);
+    }
+    __syncthreads();
+    // second half (:141-163) + compute_data_DE + sub_laplacian
+    for (int k = tid; k < w * h; k += 1024) {
+      const int i = k % w, jj = k / w, o = jj * st + i;
+      const PixIn<NOC> p = data_load<NOC>(a, pair, i, jj);
+      const float s_o = S[o];
+      const float hr = (i < w - 1) ? s_o + S[o + 1] : 0.0f;
+      const float hl = (i > 0) ? S[o - 1] + s_o : 0.0f;
+      const float vb = (jj < h - 1) ? s_o + S[o + st] : 0.0f;
+      const float vt = (jj > 0) ? S[o - st] + s_o : 0.0f;
+      float A11, B1;
+      de_data_pixel<NOC>(p, du[o], hr, hl, vb, vt, i, jj, w, h, half_delta_over3, half_gamma_over3, A11, B1);
+      A[o] = A11; B[o] = B1;
+    }
+    __syncthreads();
+    // sor_coupled_slow_but_readable_DE: sweep n0 of row j, one diagonal per step (see vr_de_sor_kernel)
+    for (int t = 0; t < T; ++t) {
+      if (solver) {
+        const int i = t - j - 2 * n0, ic = clampi(i, w), o = jc * st + ic;
+        const bool valid = row && i >= 0 && i < w, has_l = ic > 0, has_r = ic < w - 1;
+        const float own = du[o], up = du[has_t ? o - st : o], lf = du[has_l ? o - 1 : o], dn = du[has_b ? o + st : o], rt = du[has_r ? o + 1 : o];
+        const float s_o = S[o], s_t = S[has_t ? o - st : o], s_l = S[has_l ? o - 1 : o], s_b = S[has_b ? o + st : o], s_r = S[has_r ? o + 1 : o];
+        const float ca = A[o], cb = B[o];
+        const float pvt = s_t + s_o, phl = s_l + s_o, pv = s_o + s_b, ph = s_o + s_r;      // vert[o-st], horiz[o-1], vert[o], horiz[o]
+        float sigma_u = 0.0f, sum_dpsis = 0.0f;
+        sigma_u = sigma_u - (has_t ? pvt * up : 0.0f); sum_dpsis = sum_dpsis + (has_t ? pvt : 0.0f);
+        sigma_u = sigma_u - (has_l ? phl * lf : 0.0f); sum_dpsis = sum_dpsis + (has_l ? phl : 0.0f);
+        sigma_u = sigma_u - (has_b ? pv * dn : 0.0f);  sum_dpsis = sum_dpsis + (has_b ? pv : 0.0f);
+        sigma_u = sigma_u - (has_r ? ph * rt : 0.0f);  sum_dpsis = sum_dpsis + (has_r ? ph : 0.0f);
+        const float A11 = ca + sum_dpsis;
+        const float B1 = cb - sigma_u;
+        const float res = om1 * own + omega * (B1 / A11);
+        if (valid) du[o] = res;
+      }
+      __syncthreads();
+    }
+    // uu = min/max(wx + du, 0) (refine_variational.cpp:299-314)
+    for (int k = tid; k < w * h; k += 1024) {
+      const int o = (k / w) * st + k % w;
+      const float sum = wx[o] + du[o];
+      uu[o] = camlr == 0 ? (sum < 0.0f ? sum : 0.0f) : (sum > 0.0f ? sum : 0.0f);
+    }
+    __syncthreads();
+  }
+  for (int k = tid; k < w * h; k += 1024) {
+    const int i = k % w, jj = k / w, o = jj * st + i;
+    flow[(size_t)pair * flow_stride + k] = uu[o];                                   // :316-317
+    if (taps) {
+      de_plane(a, pair, DE_DU)[o] = du[o]; de_plane(a, pair, DE_UU)[o] = uu[o]; de_plane(a, pair, DE_S)[o] = S[o];
+      de_plane(a, pair, DE_A11)[o] = A[o]; de_plane(a, pair, DE_B1)[o] = B[o];
+      de_plane(a, pair, DE_SH)[o] = (i < w - 1) ? S[o] + S[o + 1] : 0.0f;
+      de_plane(a, pair, DE_SV)[o] = (jj < h - 1) ? S[o] + S[o + st] : 0.0f;
+    }
   }
 }
 

@@ -104,6 +104,7 @@ def test_depth_varref_golden_reference_vectors(noc):
             buf = np.zeros((h, st), np.float32)
             F._lib.check(F.lib().fotg_varref_plane(ofc._h, 0, nm.encode(), lvl, buf.ctypes.data))
             return buf[:, :w]
+        F.lib().fotg_enable_taps(ofc._h, 1)     # the solver planes of levels refined on chip are only written back for taps
         for camlr in (0, 1):
             w0 = (-np.abs(wx) if camlr == 0 else np.abs(wx)).astype(np.float32)
             flow = dev(w0[..., None])[None].contiguous()
@@ -114,13 +115,15 @@ def test_depth_varref_golden_reference_vectors(noc):
             assert np.array_equal(flow[0, ..., 0].cpu().numpy(), z["%s/out_de%d" % (name, camlr)]), (name, camlr)
 
 
+@pytest.mark.parametrize("path", ["0", "2"])
 @pytest.mark.parametrize("w,h,solverit", [(37, 19, 3), (120, 68, 3), (64, 40, 2), (200, 110, 3), (200, 110, 2), (300, 170, 1), (300, 170, 3),
                                           (20, 400, 3), (60, 400, 3)])
-def test_depth_varref_sizes(w, h, solverit):
+def test_depth_varref_sizes(w, h, solverit, path, monkeypatch):
     """level sizes with stride padding; the three solver residencies (everything in LDS up to 8192 cells, du alone in LDS
     up to 128 KiB, global memory beyond: 300x170), one wave group per sweep (up to 341 rows) or all sweeps in each thread
     (the 400-row cases), other sweep counts"""
     F, OFClass, VarRefClass, O = _mods()
+    monkeypatch.setenv("FOTG_VR_PATH", path)        # 0: one launch per level where it applies (<= 8192 cells, 3 sweeps); 2: launch per stage
     lvl = 2
     f0, f1, _ = stereo_pair(h, w, seed=w)
     rng = np.random.default_rng(w * 100 + h)
