@@ -29,3 +29,33 @@ def read_flo(path):
     if w <= 0 or h <= 0 or data.size != w * h * 2:
         raise ValueError("%s: header says %dx%d, payload has %d floats" % (path, w, h, data.size))
     return data.reshape(h, w, 2).astype(np.float32)
+
+
+def write_pfm(path, disp):
+    """Stereo depth mode output, SavePFMFile (kroeger/run_dense.cpp:60-81): header "Pf\\n<w> <h>\\n-1.000000\\n" (negative scale =
+    little endian), then the rows BOTTOM-UP, each value NEGATED (the left camera's displacement is <= 0, the file holds the
+    positive disparity).  disp: (h, w) or (h, w, 1) float32."""
+    if hasattr(disp, "detach"):
+        disp = disp.detach().cpu().numpy()
+    disp = np.ascontiguousarray(disp, dtype=np.float32)
+    if disp.ndim == 3 and disp.shape[2] == 1:
+        disp = disp[..., 0]
+    if disp.ndim != 2:
+        raise ValueError("disparity must be (h, w) or (h, w, 1), got %s" % (disp.shape,))
+    h, w = disp.shape
+    with open(path, "wb") as f:
+        f.write(("Pf\n%d %d\n%f\n" % (w, h, -1.0)).encode("ascii"))
+        f.write((-disp[::-1]).astype("<f4").tobytes())
+
+
+def read_pfm(path):
+    """inverse of write_pfm: returns the displacement field (h, w) as the engine produced it"""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"Pf":
+            raise ValueError("%s: not a single-channel PFM file" % path)
+        w, h = (int(v) for v in f.readline().split())
+        scale = float(f.readline())
+        data = np.frombuffer(f.read(), "<f4" if scale < 0 else ">f4")
+    if data.size != w * h:
+        raise ValueError("%s: header says %dx%d, payload has %d floats" % (path, w, h, data.size))
+    return (-data.reshape(h, w)[::-1]).astype(np.float32)

@@ -82,6 +82,26 @@ def test_flo_writer_matches_reference_file_layout(tmp_path, alley_golden_flow):
         read_flo(path)
 
 
+def test_pfm_writer_matches_reference_file_layout(tmp_path):
+    """write_pfm == SavePFMFile (kroeger/run_dense.cpp:60-81), restated here byte by byte: "Pf\\n%d %d\\n%f\\n" with scale -1,
+    rows bottom-up, values negated"""
+    import struct
+    from flowonthego_amd.flo import read_pfm, write_pfm
+    rng = np.random.default_rng(2)
+    d = -np.abs(rng.standard_normal((7, 5))).astype(np.float32)
+    path = str(tmp_path / "d.pfm")
+    write_pfm(path, d[..., None])
+    raw = open(path, "rb").read()
+    exp = b"Pf\n5 7\n-1.000000\n"
+    for y in range(6, -1, -1):
+        for x in range(5):
+            exp += struct.pack("<f", -d[y, x])
+    assert raw == exp
+    assert np.array_equal(read_pfm(path), d)
+    with pytest.raises(ValueError):
+        write_pfm(path, np.zeros((3, 3, 2), np.float32))
+
+
 def _build_example(tmpdir):
     import subprocess
     exe = os.path.join(str(tmpdir), "run_dense_min")
