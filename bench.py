@@ -154,6 +154,36 @@ def cpu_baseline(I0, I1, budget_s=12.0):
         one(n1)
         n1 += 1
     single = n1 / (time.perf_counter() - t0)
+    # per-stage split of ONE pair on one thread, the oracle's stage entry points in the order of kroeger/oflow.cpp:184-337 (the
+    # reference prints the same split as "TIME (Sc: ..)", oflow.cpp:303); ms per pair, comparable with stage_ms / batch
+    st = {}
+
+    def lap(name, t):
+        st[name] = st.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+
+    a0, b0 = pair(0)
+    pa, pb = O.pad_frame(a0, p.sc_f), O.pad_frame(b0, p.sc_f)
+    t = time.perf_counter()
+    for fr in (pa, pb):                                   # the C call alone (the Pyramid wrapper below also copies every level)
+        O.lib().dis_pyramid_free(O.lib().dis_pyramid_build(O.P(fr), fr.shape[1], fr.shape[0], 1, p.sc_f, p.ps))
+    lap("pyramid(I0,I1)", t)
+    P0, P1 = O.Pyramid(pa, p.sc_f, p.ps), O.Pyramid(pb, p.sc_f, p.ps)
+    prev = None
+    for sl in range(p.sc_f, p.sc_l - 1, -1):
+        lw, lh = P0.level_wh(sl)
+        t = time.perf_counter()
+        g = O.Grid(lw, lh, sl, p)
+        g.init(P0.im[sl], P0.dx[sl], P0.dy[sl])
+        if prev is not None:
+            g.init_from_coarser(prev)
+        g.optimize(P1.im[sl])
+        lap("lk[%d]" % sl, t)
+        t = time.perf_counter()
+        fl = g.aggregate()
+        lap("densify[%d]" % sl, t)
+        t = time.perf_counter()
+        prev = O.varref(P0.im[sl], P1.im[sl], lw, lh, sl, p, fl)
+        lap("varref[%d]" % sl, t)
     # all cores: a calibration round of one pair per thread, then enough pairs for ~0.6 * budget_s at the measured rate
     for k in range(min(cores, nb)):
         pair(k)                                                            # device -> host copies outside the timed part
@@ -168,7 +198,7 @@ def cpu_baseline(I0, I1, budget_s=12.0):
         list(ex.map(one, range(nall)))
         el = time.perf_counter() - t1
     return {"value": nall / el, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-            "single_thread": single,
+            "single_thread": single, "single_thread_stage_ms_per_pair": {k: round(v, 3) for k, v in st.items()},
             "sample": "%d of the batch's 1080p pairs (cycled), op-pt 2 + refinement, pyramid included, oracle/libdis_oracle.so "
                       "(gcc -O2, scalar), one pair per thread on %d threads in %.1f s; single thread: %d pairs at %.1f pairs/s"
                       % (nall, cores, el, n1, single)}
