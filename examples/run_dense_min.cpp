@@ -3,11 +3,14 @@
 // the reference holds them after cv::imread + convertTo(CV_32F) (src/run_dense.cpp:137-145).
 //
 //   hipcc -O2 -Iinclude examples/run_dense_min.cpp -Lflowonthego_amd -lfotg -Wl,-rpath,$PWD/flowonthego_amd -o examples/run_dense_min
-//   examples/run_dense_min frame0.raw frame1.raw W H C out.flo [op-point 1..4]
+//   examples/run_dense_min frame0.raw frame1.raw W H C out.flo [op-point 1..4] [depth]
+// With the 8th argument "depth" it is the reference's run_DE_* binary instead (kroeger SELECTMODE=2): a rectified stereo pair in,
+// one displacement channel out, written as a PFM file (SavePFMFile, kroeger/run_dense.cpp:60-81).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string.h>
 #include "fotg/oflow.h"
 
 static std::vector<float> read_raw(const char *path, size_t n)
@@ -31,10 +34,23 @@ static void save_flo(const char *path, const float *uv, int w, int h)
   fclose(f);
 }
 
+// SavePFMFile (kroeger/run_dense.cpp:60-81): "Pf", width height, scale -1 (little endian), rows bottom-up, values negated
+static void save_pfm(const char *path, const float *d, int w, int h)
+{
+  FILE *f = fopen(path, "wb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(1); }
+  fprintf(f, "Pf\n%d %d\n%f\n", w, h, -1.0f);
+  for (int y = h - 1; y >= 0; --y)
+    for (int x = 0; x < w; ++x) { const float v = -d[(size_t)y * w + x]; fwrite(&v, sizeof(float), 1, f); }
+  fclose(f);
+}
+
 int main(int argc, char **argv)
 {
-  if (argc < 7) { fprintf(stderr, "usage: %s frame0.raw frame1.raw W H C out.flo [op-point]\n", argv[0]); return 2; }
+  if (argc < 7) { fprintf(stderr, "usage: %s frame0.raw frame1.raw W H C out.flo|out.pfm [op-point] [depth]\n", argv[0]); return 2; }
   const int W = atoi(argv[3]), H = atoi(argv[4]), C = atoi(argv[5]), oppt = argc > 7 ? atoi(argv[7]) : 2;
+  const bool depth = argc > 8 && !strcmp(argv[8], "depth");
+  const int nch = depth ? 1 : 2;
   const size_t n = (size_t)W * H * C;
   const std::vector<float> f0 = read_raw(argv[1], n), f1 = read_raw(argv[2], n);
 
@@ -47,6 +63,7 @@ int main(int argc, char **argv)
   op.dp_thresh = p.dp_thresh; op.dr_thresh = p.dr_thresh; op.res_thresh = p.res_thresh;
   op.use_var_ref = p.usetvref != 0; op.var_ref_iter = p.tv_solverit; op.var_ref_alpha = p.tv_alpha; op.var_ref_gamma = p.tv_gamma;
   op.var_ref_delta = p.tv_delta; op.var_ref_sor_weight = p.tv_sor; op.verbosity = 0; op.channels = C;
+  op.depth_mode = depth;
   OFC::img_params iparams;
   iparams.width = W; iparams.height = H; iparams.padding = op.patch_size;       // unpadded: the library pads inside its pyramid kernel
 
@@ -58,18 +75,19 @@ int main(int argc, char **argv)
   OFC::OFClass ofc(op, iparams);                                                    // src/run_dense.cpp:277
   int ow, oh;
   OFC::fotgCheck(fotg_out_size(ofc.handle(), &ow, &oh), "fotg_out_size");
-  std::vector<float> coarse((size_t)2 * ow * oh);
+  std::vector<float> coarse((size_t)nch * ow * oh);
   ofc.calc(d0, d1, iparams, nullptr, coarse.data());                                // src/run_dense.cpp:286
 
   // post-processing of src/run_dense.cpp:293-303 on the device: x 2^finest, bilinear upsample, crop the padding
   hipMalloc(&dflow, coarse.size() * 4);
-  hipMalloc(&dfull, (size_t)2 * W * H * 4);
+  hipMalloc(&dfull, (size_t)nch * W * H * 4);
   hipMemcpy(dflow, coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice);
   OFC::fotgCheck(fotg_upsample_crop(ofc.handle(), 1, dflow, dfull, nullptr), "fotg_upsample_crop");
-  std::vector<float> full((size_t)2 * W * H);
+  std::vector<float> full((size_t)nch * W * H);
   hipMemcpy(full.data(), dfull, full.size() * 4, hipMemcpyDeviceToHost);
-  save_flo(argv[6], full.data(), W, H);
-  printf("%s: %dx%d flow written (finest scale %dx%d, op-point %d)\n", argv[6], W, H, ow, oh, oppt);
+  if (depth) save_pfm(argv[6], full.data(), W, H);
+  else save_flo(argv[6], full.data(), W, H);
+  printf("%s: %dx%d %s written (finest scale %dx%d, op-point %d)\n", argv[6], W, H, depth ? "disparity" : "flow", ow, oh, oppt);
   hipFree(d0); hipFree(d1); hipFree(dflow); hipFree(dfull);
   return 0;
 }

@@ -198,3 +198,22 @@ def test_depth_u8_and_sequence_entry_points():
     seq = torch.stack([dev(f0), dev(f1), dev(f2)])
     assert np.array_equal(ofc.calc_sequence(seq).cpu().numpy(), ref)
     assert np.array_equal(ofc.calc_sequence(seq.to(torch.uint8)).cpu().numpy(), ref)
+
+
+def test_cpp_shim_run_dense_example_depth(tmp_path):
+    """examples/run_dense_min.cpp with the `depth` switch = the reference's run_DE_* binary: rectified pair in, PFM out
+    (SavePFMFile layout), compared bit for bit with the oracle's full-resolution displacement"""
+    import subprocess
+    from test_host import _build_example
+    F, OFClass, _, O = _mods()
+    from flowonthego_amd.flo import read_pfm
+    exe = _build_example(tmp_path)
+    f0, f1, _ = stereo_pair(272, 480, seed=77)
+    p0, p1, out = (str(tmp_path / n) for n in ("f0.raw", "f1.raw", "out.pfm"))
+    f0.astype(np.float32).tofile(p0)
+    f1.astype(np.float32).tofile(p1)
+    r = subprocess.run([exe, p0, p1, "480", "272", "1", out, "2", "depth"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    p = O.op_point(2, 480, 1)
+    p.depth = 1
+    assert np.array_equal(read_pfm(out), O.full_flow(f0, f1, params=p)[..., 0])
