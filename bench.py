@@ -287,6 +287,23 @@ def main():
             torch.cuda.synchronize()
             res["u8_frames"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
                                 "note": "same workload with uint8 input frames (exact conversion on load); informational"}
+            # BASELINE configs[1]: ONE 1080p pair, op-pt 2's patch parameters (ps 8, stride 4, 3 scales), no variational refinement:
+            # the latency of a single call (informational; the headline value is configs[2])
+            op1 = F.operating_point(OP_POINT, W, 1)
+            op1.use_var_ref = False
+            ofc1 = OFClass(op1, F.img_params(width=W, height=H, padding=op1.patch_size), max_batch=1, device=local)
+            o1 = ofc1.new_outflow(1)
+            for _ in range(5):
+                ofc1.calc_batch(I0[:1], I1[:1], None, o1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(100):
+                ofc1.calc_batch(I0[:1], I1[:1], None, o1)
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t1) * 10.0
+            res["single_pair_no_refine"] = {"ms_per_pair": ms1, "value": 1e3 / ms1, "unit": "frame-pairs/s",
+                                            "note": "BASELINE configs[1]: one 1080p pair per call, 3 scales, no refinement; informational"}
+            ofc1.close()
         if a.extras:
             # video mode (fotg_calc_sequence): batch+1 consecutive frames -> batch flows, every pyramid built once
             seq = torch.cat([I0, I1[-1:]]).contiguous()
