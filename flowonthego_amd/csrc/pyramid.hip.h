@@ -87,11 +87,40 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
     constexpr int RG = R >= 4 ? 4 : R;                               // rows per group
     constexpr int NGRP = R / RG;
     constexpr int GROUPS_IN_FLIGHT = (NOC == 1 || sizeof(T) == 1) ? NGRP : 2;
+    // Three-channel f32 frames: a lane's 4 pixels are 48 contiguous bytes, so lane-private 16-byte loads have a 48-byte lane
+    // stride and every 128-byte line is requested by three different instructions.  Instead the wave loads its 3072-byte row
+    // segment with three fully coalesced instructions (lane L: bytes 1024 k + 16 L) and transposes through a wave-private LDS
+    // slab (written linearly, read back at 48 L + 16 k: 16 lanes cover the 64 banks exactly, no conflicts).  LDS executes a
+    // wave's accesses in order, so no barrier is needed.
+    constexpr bool XPOSE = FAST && NOC == 3 && sizeof(T) == 4 && R >= 4;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    __shared__ vf4 xpose[XPOSE ? 4 : 1][XPOSE ? RG : 1][XPOSE ? 192 : 1];
     float l1[R / 2][2 * NOC];
 #pragma unroll
     for (int g = 0; g < NGRP; ++g) {
       float v[RG][C];
-      if (active) {
+      if constexpr (XPOSE) {
+        const int seg4 = ((Wp - strip * 256 < 256 ? Wp - strip * 256 : 256) * 3) / 4;     // float4s of this strip's row segment
+        vf4 t[RG][3];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+          const int sy = clampi(oy * R + g * RG + r - top, h_org);
+          const vf4 *p4 = reinterpret_cast<const vf4 *>(reinterpret_cast<const float *>(src) + ((size_t)sy * w_org + strip * 256) * 3);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) t[r][k] = (k * 64 + lane < seg4) ? __builtin_nontemporal_load(p4 + k * 64 + lane) : vf4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) xpose[wave][r][k * 64 + lane] = t[r][k];
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const vf4 q = xpose[wave][r][3 * lane + k];
+            v[r][4 * k] = q.x; v[r][4 * k + 1] = q.y; v[r][4 * k + 2] = q.z; v[r][4 * k + 3] = q.w;
+          }
+      } else if (active) {
 #pragma unroll
         for (int r = 0; r < RG; ++r) load_row(g * RG + r, v[r]);
       } else {

@@ -54,11 +54,14 @@ def frames(case, alley):
     if case == "synth_rgb":
         a, b = synth_pair(200, 328, seed=9, noc=3)
         return a, b, 3
+    if case == "synth_rgb_fast":       # no horizontal padding at op-pt 2 (352 = 22 * 16): the coalesced + LDS-transposed row loads,
+        a, b = synth_pair(200, 352, seed=10, noc=3)        # with a partial last 256-pixel strip
+        return a, b, 3
     raise KeyError(case)
 
 
 @pytest.mark.parametrize("case,op_point", [("alley", 2), ("alley_rgb", 2), ("synth_1080p", 2), ("synth_odd", 2),
-                                           ("synth_odd", 3), ("synth_rgb", 1)])
+                                           ("synth_odd", 3), ("synth_rgb", 1), ("synth_rgb_fast", 2)])
 def test_pyramid_parity(case, op_point, alley):
     F, OFClass, _, O = _mods()
     f0, f1, noc = frames(case, alley)
@@ -155,7 +158,8 @@ def test_varref_golden_reference_vectors(noc):
 
 
 @pytest.mark.parametrize("case,op_point,sor_mode", [("alley", 2, 0), ("alley", 2, 1), ("alley_rgb", 2, 0),
-                                                    ("synth_odd", 3, 0), ("synth_odd", 1, 0), ("synth_rgb", 2, 0)])
+                                                    ("synth_odd", 3, 0), ("synth_odd", 1, 0), ("synth_rgb", 2, 0),
+                                                    ("synth_rgb_fast", 2, 0)])
 def test_end_to_end_parity(case, op_point, sor_mode, alley):
     """OFClass::calc on original (unpadded) frames == oracle pipeline, finest-scale flow and full-resolution flow"""
     F, OFClass, _, O = _mods()
