@@ -328,6 +328,22 @@ def test_uint8_frames(alley):
         p = oracle_params(O, op)
         assert np.array_equal(got, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
         assert np.array_equal(got, ofc.calc(dev(f0), dev(f1)).cpu().numpy()), case
+    # gray, rows 16-byte aligned: four rows per 16-byte load (partial last strip: 352 = 256 + 96); the same frames at an
+    # address that is only 4-byte aligned take the dword loads -- same bits
+    f0, f1 = synth_pair(208, 352, seed=12)
+    op = F.operating_point(2, 352, 1)
+    ofc = OFClass(op, F.img_params(width=352, height=208, padding=op.patch_size))
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    u0 = torch.from_numpy(f0.astype(np.uint8)).cuda()[None].contiguous()
+    u1 = torch.from_numpy(f1.astype(np.uint8)).cuda()[None].contiguous()
+    assert np.array_equal(ofc.calc_batch_u8(u0, u1)[0].cpu().numpy(), ref)
+    buf0 = torch.zeros(u0.numel() + 64, dtype=torch.uint8, device="cuda")
+    buf1 = torch.zeros(u1.numel() + 64, dtype=torch.uint8, device="cuda")
+    m0, m1 = buf0[4:4 + u0.numel()].view_as(u0), buf1[4:4 + u1.numel()].view_as(u1)
+    m0.copy_(u0); m1.copy_(u1)
+    assert m0.data_ptr() % 16 == 4
+    assert np.array_equal(ofc.calc_batch_u8(m0, m1)[0].cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("cost_func", [1, 2])
