@@ -598,6 +598,7 @@ static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hip
   return true;
 }
 
+static long g_wide_launches = 0;        // fotg_debug_counter("sor_wide")
 static long g_stream_launches = 0;      // fotg_debug_counter("sor_stream"): tests assert the opt-in kernel really ran
 // streaming solver (vr_sor_stream_kernel): diagonals travel through LDS rings.  Instantiated for 64..69 rows (1080p level 4).
 // FOTG_VR_STREAM=1 selects it (tests).
@@ -716,6 +717,21 @@ static int vr_path_override()
 static void dispatch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
   if (vr_path_override() != 1 && dispatch_sor_pipe(a, n, sweeps, omega, s)) return;
+  // levels too tall for the LDS solvers: a whole workgroup per pair on the global arrays (FOTG_VR_WIDE=0: the single-wave kernel)
+  {
+    const char *e = getenv("FOTG_VR_WIDE");
+    if ((!e || atoi(e)) && vr_path_override() != 1 && sweeps >= 1 && sweeps <= 4 && a.h > 96) {
+      for (int k = 2; k <= 4; k += 2) {
+        if (a.K % k) continue;
+        const int lp = (((a.h + k - 1) / k + 63) / 64) * 64;
+        if (sweeps * lp > 1024) continue;
+        if (k == 2) vr_sor_wide_kernel<2><<<n, sweeps * lp, 0, s>>>(a, sweeps, omega);
+        else vr_sor_wide_kernel<4><<<n, sweeps * lp, 0, s>>>(a, sweeps, omega);
+        ++g_wide_launches;
+        return;
+      }
+    }
+  }
   // prefetch depth: as deep as the register budget of K rows per lane allows, and 2P+2 <= S (ring never
   // runs ahead into rows the current sweep has not rewritten yet)
   const int cap = (a.S - 2) / 2;
@@ -1148,6 +1164,7 @@ int fotg_calc_sequence_u8(fotg_ctx *c, int n_frames, const unsigned char *frames
 long fotg_debug_counter(const char *name)
 {
   if (name && !strcmp(name, "sor_stream")) return g_stream_launches;
+  if (name && !strcmp(name, "sor_wide")) return g_wide_launches;
   return -1;
 }
 

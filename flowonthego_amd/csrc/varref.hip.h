@@ -548,6 +548,74 @@ __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float 
   }
 }
 
+// Wide variant for levels whose (du,dv) do not fit in LDS (more than ~130 rows at video widths: the fine levels of the
+// quality presets, e.g. 480x272 and 960x544).  The single wave of vr_sor_kernel has to walk K = 6..16 rows per lane, one
+// sweep after the other; here one workgroup of up to 1024 threads works on a pair: thread = (sweep n, lane), a lane owns
+// K = 2 or 4 rows, so up to 512 cells of a diagonal are relaxed per step, and the sweeps run concurrently, sweep n+1 DS = 3
+// diagonals behind sweep n.  Everything stays in the skewed global arrays (L2 / the CU's L1: each diagonal is a contiguous row,
+// so all accesses are coalesced); one workgroup barrier per step.  As in vr_sor_kernel the NEW left values stay in the
+// lane's registers and the new top value of a lane's first row comes from the lane above by DPP -- across a wave boundary
+// through a small double-buffered LDS array -- while C and the old values are loaded ONE STEP AHEAD of their use (the old
+// values a sweep needs were written at least two steps earlier, i.e. before the last barrier).  Same update order as the
+// reference's row-major loop, hence the same bits.
+template <int K>
+__global__ __launch_bounds__(1024) void vr_sor_wide_kernel(VrArgs a, int sweeps, float omega)
+{
+  constexpr int DS = 3;
+  __shared__ float2 edge[2][4][16];                  // [step parity][sweep][wave of the sweep]: prev[K-1] of the wave's lane 63
+  const int pair = blockIdx.x, tid = threadIdx.x, LP = blockDim.x / sweeps;
+  const int n = tid / LP, L = tid % LP, lane = tid & 63, wv = L >> 6;
+  const int nl = (a.h + K - 1) / K;                  // K divides the K the arrays were padded for, so rows nl*K-1 < RP exist (zero cells)
+  const bool act = L < nl;
+  const int r0 = L * K;
+  const float4 *__restrict__ C = a.Cp(pair);
+  float2 *D = a.Dp(pair);
+  const int S = a.S, RP = a.RP, RPD = a.RPD;
+  struct Stage { float4 c[K][2]; float2 own[K]; float2 nxt[K + 1]; };
+  auto issue = [&](Stage &st, int row) {
+    if (act && row >= 0 && row < S) {
+      const float4 *cp = C + ((size_t)row * RP + r0) * 2;
+#pragma unroll
+      for (int m = 0; m < K; ++m) { st.c[m][0] = cp[2 * m]; st.c[m][1] = cp[2 * m + 1]; }
+      const float2 *d0 = D + (size_t)row * RPD + r0, *d1 = D + (size_t)(row + 1) * RPD + r0;
+#pragma unroll
+      for (int m = 0; m < K; ++m) st.own[m] = d0[m];
+#pragma unroll
+      for (int m = 0; m <= K; ++m) st.nxt[m] = d1[m];
+    }
+  };
+  float2 prev[K];
+  float hl[K];
+#pragma unroll
+  for (int m = 0; m < K; ++m) { prev[m] = make_float2(0.f, 0.f); hl[m] = 0.f; }
+  if (tid < 2 * 4 * 16) (&edge[0][0][0])[tid] = make_float2(0.f, 0.f);
+  __syncthreads();
+  Stage cur, nx;
+  issue(cur, 0 - DS * n);
+  const int T = S + DS * (sweeps - 1);
+  for (int t = 0; t < T; ++t) {
+    const int s = t - DS * n;                        // this sweep's diagonal (wave-uniform)
+    issue(nx, s + 1);
+    // the DPP shift is taken with all lanes enabled and selected afterwards (DPP does not fetch from inactive lanes)
+    float2 top0;
+    top0.x = dpp_wave_shr1(prev[K - 1].x);
+    top0.y = dpp_wave_shr1(prev[K - 1].y);
+    if (lane == 0) top0 = wv > 0 ? edge[(t + 1) & 1][n][wv - 1] : make_float2(0.f, 0.f);
+    if (act && s >= 0 && s < S) {
+      float2 res[K];
+#pragma unroll
+      for (int m = 0; m < K; ++m)
+        res[m] = sor_update(cur.own[m], cur.c[m][0], cur.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], cur.nxt[m], cur.nxt[m + 1], omega);
+      float2 *dst = D + (size_t)s * RPD + r0;
+#pragma unroll
+      for (int m = 0; m < K; ++m) { dst[m] = res[m]; prev[m] = res[m]; hl[m] = cur.c[m][1].y; }
+    }
+    if (lane == 63) edge[t & 1][n][wv] = prev[K - 1];
+    cur = nx;
+    __syncthreads();
+  }
+}
+
 // Sweep-pipelined variant (the production path whenever D fits in LDS): the `sweeps` Gauss-Seidel sweeps of one
 // sor_coupled call run CONCURRENTLY, one wave per sweep, staggered along the anti-diagonals.  Sweep n+1 may process
 // diagonal s as soon as sweep n has finished diagonal s+1 (its "old" right/bottom neighbours are sweep n's values of

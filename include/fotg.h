@@ -150,7 +150,7 @@ int fotg_varref(fotg_ctx *ctx, int level, int n, const float *I0, const float *I
  * depth mode: "wx","mask","du","uu","s","a11","b1","sh","sv" and the image planes (a11/b1: the scalar system of compute_data_DE) */
 int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, float *host_out);
 
-/* test tap: how often an opt-in kernel variant was launched by this process ("sor_stream"); -1 for unknown names */
+/* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_wide"); -1 for unknown names */
 long fotg_debug_counter(const char *name);
 const char *fotg_strerror(int status);
 int fotg_last_hip_error(void);

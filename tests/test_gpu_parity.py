@@ -223,6 +223,31 @@ def test_streaming_solver_kernel(mode, monkeypatch):
     assert F.lib().fotg_debug_counter(b"sor_stream") == before + expect
 
 
+@pytest.mark.parametrize("wide", ["1", "0"])
+def test_wide_solver_kernel(wide, monkeypatch):
+    """levels too tall for the LDS solvers (the fine levels of the quality presets) are relaxed by vr_sor_wide_kernel: a whole
+    workgroup per pair, two or four rows per lane, sweeps side by side on the global arrays.  FOTG_VR_WIDE=0: the single-wave
+    kernel -- same bits.  Sizes: op-pt 3 at 1080p (level 2 = 480x272, two rows per lane), a 132-row level (three rows per
+    lane in the array padding: falls back), op-pt 4 on a tall frame (544-row level), and a batch of two"""
+    F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_WIDE", wide)
+    before = F.lib().fotg_debug_counter(b"sor_wide")
+    ran = 0
+    for (w, h), op_point, width_for_op in (((1920, 1080), 3, 1920), ((640, 528), 3, 640), ((480, 2176), 4, 3840)):
+        f0, f1 = synth_pair(h, w, seed=4)
+        op = F.operating_point(op_point, width_for_op, 1)
+        if op_point == 4:
+            op.grad_descent_iter = 8                           # keep the oracle quick; the solver is what is under test
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+        out = ofc.calc_batch(dev(np.stack([f0, f1])), dev(np.stack([f1, f0]))).cpu().numpy()
+        p = oracle_params(O, op)
+        a, b = O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f)
+        assert np.array_equal(out[0], O.flow(a, b, p, 0)) and np.array_equal(out[1], O.flow(b, a, p, 0)), (w, h)
+        ofc.close()
+    ran = F.lib().fotg_debug_counter(b"sor_wide") - before
+    assert (ran > 0) if wide == "1" else (ran == 0)
+
+
 def test_plane_at_a_time_setup_stages(alley, monkeypatch):
     """FOTG_VR_SETUP=0: warp, first and second derivatives as three launches through global memory instead of the tiled
     single launch (levels that are not refined on chip): same planes, same flow"""
