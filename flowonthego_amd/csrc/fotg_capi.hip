@@ -337,7 +337,7 @@ static int pyramid_impl(fotg_ctx *c, int n, const T *I0, const T *I1, hipStream_
     if (I0 && I1) { fa.n_per_src = n; }
     else if (I0) { fa.n_per_src = n; }                       // only `which` 0 blocks exist
     else { fa.n_per_src = 0; }                               // every block is `which` 1
-    pyr_finish_kernel<NOC><<<nimg, 1024, 0, s>>>(fa);
+    pyr_finish_kernel<NOC><<<dim3(nimg, fa.first_used == 0 ? 2 : 1), 1024, 0, s>>>(fa);
     LAUNCHCHK();
     return FOTG_OK;
   }

@@ -278,6 +278,11 @@ __global__ __launch_bounds__(1024) void pyr_finish_kernel(PyrFinishArgs a)
 {
   const int which = blockIdx.x >= a.n_per_src, img = blockIdx.x - (which ? a.n_per_src : 0);
   const int ps = a.ps;
+  // two workgroups per image: blockIdx.y = 1 does border + gradients of the base level (its interior is complete when this
+  // kernel starts), blockIdx.y = 0 the chain halve -> halve -> borders + gradients of the coarser levels
+  const int part = blockIdx.y, kb = part == 1 ? a.first_used : (a.first_used == 0 && gridDim.y > 1 ? 1 : a.first_used);
+  const int ke = part == 1 ? (a.first_used == 0 ? 1 : 0) : a.nlev;
+  if (part == 0)
   for (int k = 1; k < a.nlev; ++k) {
     const float *s = a.im[which][k - 1] + (size_t)img * a.stride[k - 1];
     float *d = a.im[which][k] + (size_t)img * a.stride[k];
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(1024) void pyr_finish_kernel(PyrFinishArgs a)
     }
     __syncthreads();
   }
-  for (int k = a.first_used; k < a.nlev; ++k) {
+  for (int k = kb; k < ke; ++k) {
     const int w = a.w[k], h = a.h[k], tw = w + 2 * ps, th = h + 2 * ps;
     float *I = a.im[which][k] + (size_t)img * a.stride[k];
     float *gx = which == 0 ? a.dx[k] + (size_t)img * a.stride[k] : nullptr;
