@@ -160,6 +160,9 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
       }
     }
   }
+  // the window is filled by all lanes of the wave and read by all of them: keep the compiler (which reasons per thread) from
+  // moving reads above the fill; the hardware executes a wave's LDS accesses in order
+  asm volatile("" ::: "memory");
 
   // template mean (patch.cpp:330-331) and Hessian sums (:74-77, depth :84) of all NP patches, reduced together
   if (a.patnorm > 0) {

@@ -128,10 +128,16 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
 #pragma unroll
           for (int k = 0; k < 3; ++k) t[r][k] = (k * 64 + lane < seg4) ? __builtin_nontemporal_load(p4 + k * 64 + lane) : vf4{0.f, 0.f, 0.f, 0.f};
         }
+        // The slab is how the LANES of this wave exchange data, and the compiler reasons per thread: it may prove that a
+        // thread's own writes never hit the cell it reads (64 k + lane != 3 lane + 1 for every lane) and then reuse the
+        // value it read for the previous row group, or move the next group's writes above this group's reads.  The
+        // compiler barriers pin write phase | read phase | next write phase; the hardware keeps a wave's LDS accesses in order.
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = 0; r < RG; ++r)
 #pragma unroll
           for (int k = 0; k < 3; ++k) xpose[wave][r][k * 64 + lane] = t[r][k];
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = 0; r < RG; ++r)
 #pragma unroll
@@ -139,15 +145,19 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
             const vf4 q = xpose[wave][r][3 * lane + k];
             v[r][4 * k] = q.x; v[r][4 * k + 1] = q.y; v[r][4 * k + 2] = q.z; v[r][4 * k + 3] = q.w;
           }
+        asm volatile("" ::: "memory");
       } else if (XPOSE8 && x8) {
         if constexpr (XPOSE8) {
+          asm volatile("" ::: "memory");               // same lane-to-lane hand-over as above
           xpose8[wave][lane] = t8[g];
+          asm volatile("" ::: "memory");
           const unsigned *slab = reinterpret_cast<const unsigned *>(&xpose8[wave][0]);
 #pragma unroll
           for (int r = 0; r < RG; ++r) {
             const unsigned t = slab[r * 64 + lane];
             v[r][0] = (float)(t & 0xffu); v[r][1] = (float)((t >> 8) & 0xffu); v[r][2] = (float)((t >> 16) & 0xffu); v[r][3] = (float)(t >> 24);
           }
+          asm volatile("" ::: "memory");
         }
       } else if (active) {
 #pragma unroll

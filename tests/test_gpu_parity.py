@@ -54,6 +54,12 @@ def frames(case, alley):
     if case == "synth_rgb":
         a, b = synth_pair(200, 328, seed=9, noc=3)
         return a, b, 3
+    if case == "synth_rgb_lv3":        # RGB fast path with the base level at 3 (two row groups per wave) and vertical padding
+        a, b = synth_pair(515, 1024, seed=1094, noc=3)
+        return a, b, 3
+    if case == "synth_rgb_1080p":      # RGB fast path with the base level at 4 (four row groups), partial last strip
+        a, b = synth_pair(1080, 1920, seed=1095, noc=3)
+        return a, b, 3
     if case == "synth_rgb_fast":       # no horizontal padding at op-pt 2 (352 = 22 * 16): the coalesced + LDS-transposed row loads,
         a, b = synth_pair(200, 352, seed=10, noc=3)        # with a partial last 256-pixel strip
         return a, b, 3
@@ -61,7 +67,8 @@ def frames(case, alley):
 
 
 @pytest.mark.parametrize("case,op_point", [("alley", 2), ("alley_rgb", 2), ("synth_1080p", 2), ("synth_odd", 2),
-                                           ("synth_odd", 3), ("synth_rgb", 1), ("synth_rgb_fast", 2)])
+                                           ("synth_odd", 3), ("synth_rgb", 1), ("synth_rgb_fast", 2), ("synth_rgb_lv3", 1),
+                                           ("synth_rgb_1080p", 2)])
 def test_pyramid_parity(case, op_point, alley):
     F, OFClass, _, O = _mods()
     f0, f1, noc = frames(case, alley)
@@ -159,7 +166,7 @@ def test_varref_golden_reference_vectors(noc):
 
 @pytest.mark.parametrize("case,op_point,sor_mode", [("alley", 2, 0), ("alley", 2, 1), ("alley_rgb", 2, 0),
                                                     ("synth_odd", 3, 0), ("synth_odd", 1, 0), ("synth_rgb", 2, 0),
-                                                    ("synth_rgb_fast", 2, 0)])
+                                                    ("synth_rgb_fast", 2, 0), ("synth_rgb_lv3", 1, 0)])
 def test_end_to_end_parity(case, op_point, sor_mode, alley):
     """OFClass::calc on original (unpadded) frames == oracle pipeline, finest-scale flow and full-resolution flow"""
     F, OFClass, _, O = _mods()
@@ -369,6 +376,15 @@ def test_uint8_frames(alley):
     m0.copy_(u0); m1.copy_(u1)
     assert m0.data_ptr() % 16 == 4
     assert np.array_equal(ofc.calc_batch_u8(m0, m1)[0].cpu().numpy(), ref)
+    # 1080p (base level 4: four row groups per wave through the LDS slab), gray and RGB: same bits as the float frames
+    for noc in (1, 3):
+        f0, f1 = synth_pair(1080, 1920, seed=13, noc=noc)
+        op = F.operating_point(2, 1920, noc)
+        ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=op.patch_size))
+        u0 = torch.from_numpy(f0.astype(np.uint8)).cuda()[None].contiguous()
+        u1 = torch.from_numpy(f1.astype(np.uint8)).cuda()[None].contiguous()
+        assert torch.equal(ofc.calc_batch_u8(u0, u1), ofc.calc_batch(dev(f0)[None], dev(f1)[None])), noc
+        ofc.close()
 
 
 @pytest.mark.parametrize("cost_func", [1, 2])
