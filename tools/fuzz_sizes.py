@@ -28,12 +28,23 @@ for k in range(n):
     except F.FotgError as e:
         print(k, (w, h, op_point, noc), "refused:", e); continue
     dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    out = ofc.calc(dv(f0), dv(f1)).cpu().numpy()
     p = oracle_params(O, op)
     ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
-    ok = np.array_equal(out, ref)
+    entry = int(rng.integers(0, 3))                          # 0: calc (f32), 1: 8-bit frames, 2: batch of two (pair, swapped pair)
+    if entry == 1:
+        out = ofc.calc_batch_u8(dv(f0.astype(np.uint8))[None], dv(f1.astype(np.uint8))[None])[0].cpu().numpy()
+        ok = np.array_equal(out, ref)
+    elif entry == 2:
+        ofc.close()
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+        o2 = ofc.calc_batch(dv(np.stack([f0, f1])), dv(np.stack([f1, f0]))).cpu().numpy()
+        out = o2[0]
+        ok = np.array_equal(out, ref) and np.array_equal(o2[1], O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0))
+    else:
+        out = ofc.calc(dv(f0), dv(f1)).cpu().numpy()
+        ok = np.array_equal(out, ref)
     bad += not ok
-    print(k, (w, h, op_point, noc, op.cost_func, op.use_fbcon, op.depth_mode), "rows@finest", ref.shape[0], "OK" if ok else "MISMATCH max %g" % np.abs(out - ref).max(), flush=True)
+    print(k, (w, h, op_point, noc, op.cost_func, op.use_fbcon, op.depth_mode, "entry %d" % entry), "rows@finest", ref.shape[0], "OK" if ok else "MISMATCH max %g" % np.abs(out - ref).max(), flush=True)
     ofc.close()
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
