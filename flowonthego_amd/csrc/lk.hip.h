@@ -139,7 +139,11 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
     }
     float pin0 = 0.f, pin1 = 0.f;
     if (a.flow_prev) {
-      const int fx = (int)floorf(rx / 2), fy = (int)floorf(ry / 2);
+      int fx = (int)floorf(rx / 2), fy = (int)floorf(ry / 2);
+      // oracle definition D5: a level of odd size has patches whose half coordinate is one past the coarser array (only
+      // reachable with `initflow`); the reference reads out of bounds there, here the index is clamped
+      fx = fx > a.g.w / 2 - 1 ? a.g.w / 2 - 1 : fx;
+      fy = fy > a.g.h / 2 - 1 ? a.g.h / 2 - 1 : fy;
       const float *fp = a.flow_prev + (size_t)pair * a.flow_prev_stride + (DEPTH ? 1 : 2) * (size_t)(fy * (a.g.w / 2) + fx);
       pin0 = fp[0] * 2;
       if constexpr (!DEPTH) pin1 = fp[1] * 2;

@@ -76,7 +76,9 @@ void fotg_destroy(fotg_ctx *ctx);
 
 /* Replaces OFClass::calc(I0, I1, iparams, initflow, outflow) (src/oflow.cpp:211-368) for n pairs at once.
  * I0, I1: n contiguous frames, each h_org x w_org x noc float32 interleaved (src/run_dense.cpp:137-162).
- * initflow: NULL (as every reference caller passes, src/run_dense.cpp:286) or n x (h/2^(sc_f+1)) x (w/2^(sc_f+1)) x 2.
+ * initflow: NULL (as every reference caller passes, src/run_dense.cpp:286) or n x (h/2^(sc_f+1)) x (w/2^(sc_f+1)) x 2
+ *   (patches in the last row / column of an odd-sized coarsest level take the last row / column of it: the reference's
+ *   InitializeFromCoarserOF indexes one past the array there).
  * outflow: n x (Hp/2^sc_l) x (Wp/2^sc_l) x 2 float32 interleaved (u,v), row-major (src/run_dense.cpp:280-289).
  * stream: hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
 int fotg_calc_batch(fotg_ctx *ctx, int n, const float *I0, const float *I1, const float *initflow,

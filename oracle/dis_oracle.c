@@ -13,6 +13,8 @@
  *        (reference: pweight is left as it was allocated -- uninitialised, patch.cpp:135-141).
  *   (D3) a non-finite LK update is treated like an outlier (reset to p_in, stop).  The reference
  *        would convert NaN to int (undefined behaviour, patch.cpp:345-348).
+ *   (D5) InitializeFromCoarserOF clamps the half-resolution index into the coarser array (the reference reads
+ *        one row / column out of bounds when the level size is odd, which only `initflow` can make happen).
  *   (D4) 2x2 half-resolution = ((a+c)+(b+d))*0.25 (rows first); for 8-bit valued input every
  *        order is exact up to level 7, so this only matters for non-integer input.
  */
@@ -257,6 +259,11 @@ void dis_grid_init_from_coarser(dis_grid *g, const float *flow_prev)
   for (int ip = 0; ip < g->nop; ++ip) {
     int x = (int)floor(g->pt_ref[2 * ip] / 2);
     int y = (int)floor(g->pt_ref[2 * ip + 1] / 2);
+    /* (D5) a level of odd size has patches at x = w-1 or y = h-1, whose half coordinate is one past the (w/2) x (h/2)
+       array: the reference reads out of bounds there (only reachable with `initflow`, which no reference caller passes --
+       between scales the sizes are exact halves).  Clamp to the last row / column. */
+    if (x > g->w / 2 - 1) x = g->w / 2 - 1;
+    if (y > g->h / 2 - 1) y = g->h / 2 - 1;
     int i = y * (g->w / 2) + x;
     if (g->depth) { g->p_init[2 * ip] = flow_prev[i] * 2; continue; }   /* :207-208 */
     g->p_init[2 * ip] = flow_prev[2 * i] * 2;

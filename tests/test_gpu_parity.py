@@ -474,6 +474,37 @@ def test_sequence_mode(alley):
             ofc.calc_sequence(dev(np.concatenate([seq, seq[:1]])))        # 4 pairs > max_batch
 
 
+def test_sequence_mode_with_switches():
+    """the video entry point combined with the other switches: forward-backward merge (the backward grids take their
+    templates and gradients from the NEXT frame's pyramid), L1 cost, and an initflow warm start -- each flow equals the
+    ordinary batch call on the same pairs"""
+    F, OFClass, _, O = _mods()
+    h, w = 272, 480
+    seq = np.stack([synth_pair(h, w, seed=50 + k)[0] for k in range(2)] + [synth_pair(h, w, seed=50)[1]])
+    for fb, cost in ((True, 0), (False, 1), (True, 2)):
+        op = F.operating_point(2, w, 1)
+        op.use_fbcon, op.cost_func = fb, cost
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+        p = oracle_params(O, op)
+        ref = np.stack([O.flow(O.pad_frame(seq[k], p.sc_f), O.pad_frame(seq[k + 1], p.sc_f), p, 0) for k in range(2)])
+        got = ofc.calc_sequence(dev(seq)).cpu().numpy()
+        assert np.array_equal(got, ref), (fb, cost)
+        assert np.array_equal(ofc.calc_batch(dev(seq[:2]), dev(seq[1:])).cpu().numpy(), ref), (fb, cost)
+        ofc.close()
+    # warm start: the same initflow through both entry points
+    op = F.operating_point(2, w, 1)
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+    wp, hp, _, _ = O.padded_size(w, h, op.coarsest_scale)
+    init = (np.random.default_rng(3).standard_normal((2, hp >> (op.coarsest_scale + 1), wp >> (op.coarsest_scale + 1), 2)) * 0.5).astype(np.float32)
+    a = ofc.calc_sequence(dev(seq), initflow=dev(init)).cpu().numpy()
+    b = ofc.calc_batch(dev(seq[:2]), dev(seq[1:]), initflow=dev(init)).cpu().numpy()
+    assert np.array_equal(a, b)
+    p = oracle_params(O, op)
+    P0 = O.Pyramid(O.pad_frame(seq[0], p.sc_f), p.sc_f, p.ps)
+    P1 = O.Pyramid(O.pad_frame(seq[1], p.sc_f), p.sc_f, p.ps)
+    assert np.array_equal(a[0], O.flow_pyr(P0, P1, p, initflow=init[0]))
+
+
 def test_initflow_warm_start(alley):
     """initflow (kroeger/oflow.h:91, oflow.cpp:217-220; src/oflow.cpp:268-271): coarsest-scale patches start from 2 x the
     given flow, sampled nearest-neighbour like a coarser scale"""
