@@ -34,7 +34,8 @@ for k in range(n):
     dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     p = oracle_params(O, op)
     ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
-    entry = int(rng.integers(0, 3))                          # 0: calc (f32), 1: 8-bit frames, 2: batch of two (pair, swapped pair)
+    entry = int(rng.integers(0, 5))                          # 0: calc (f32), 1: 8-bit frames, 2: batch of two (pair, swapped pair),
+                                                             # 3: video entry point (f0, f1, f0), 4: initflow warm start
     if entry == 1:
         out = ofc.calc_batch_u8(dv(f0.astype(np.uint8))[None], dv(f1.astype(np.uint8))[None])[0].cpu().numpy()
         ok = np.array_equal(out, ref)
@@ -44,6 +45,22 @@ for k in range(n):
         o2 = ofc.calc_batch(dv(np.stack([f0, f1])), dv(np.stack([f1, f0]))).cpu().numpy()
         out = o2[0]
         ok = np.array_equal(out, ref) and np.array_equal(o2[1], O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0))
+    elif entry == 3:
+        ofc.close()
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+        o2 = ofc.calc_sequence(dv(np.stack([f0, f1, f0]))).cpu().numpy()
+        out = o2[0]
+        ok = np.array_equal(out, ref) and np.array_equal(o2[1], O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0))
+    elif entry == 4:
+        wp, hp, _, _ = O.padded_size(w, h, p.sc_f)
+        nch = 1 if op.depth_mode else 2
+        init = (rng.standard_normal((hp >> (p.sc_f + 1), wp >> (p.sc_f + 1), nch)) * 0.7).astype(np.float32)
+        if op.depth_mode:
+            init = -np.abs(init)
+        P0, P1 = O.Pyramid(O.pad_frame(f0, p.sc_f), p.sc_f, p.ps), O.Pyramid(O.pad_frame(f1, p.sc_f), p.sc_f, p.ps)
+        ref = O.flow_pyr(P0, P1, p, initflow=init)
+        out = ofc.calc_batch(dv(f0)[None], dv(f1)[None], initflow=dv(init)[None])[0].cpu().numpy()
+        ok = np.array_equal(out, ref)
     else:
         out = ofc.calc(dv(f0), dv(f1)).cpu().numpy()
         ok = np.array_equal(out, ref)
