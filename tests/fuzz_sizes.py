@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""One-off robustness sweep (not part of the test suite): random frame sizes / operating points / channels / switches,
-GPU result against the oracle, bit for bit.  usage: python tools/fuzz_sizes.py [n_cases] [seed]"""
+"""Robustness sweep (test infrastructure, run by hand on a GPU box; pytest does not collect it): random frame sizes /
+operating points / channels / switches / entry points, GPU result against the oracle, bit for bit.
+usage: python tests/fuzz_sizes.py [n_cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

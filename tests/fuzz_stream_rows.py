@@ -1,5 +1,7 @@
+"""Sweep of frame heights around the streaming solver's row range (test infrastructure, run by hand on a GPU box).
+usage: python tests/fuzz_stream_rows.py"""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 from conftest import synth_pair
 import flowonthego_amd as F
