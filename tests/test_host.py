@@ -63,6 +63,23 @@ def test_product_package_does_not_import_oracle():
                 assert "import oracle" not in txt and "from oracle" not in txt and "dis_oracle" not in txt.replace("oracle/dis_oracle.c", ""), f
 
 
+def test_only_tests_smoke_and_bench_touch_the_oracle():
+    """tools/, examples/ and include/ never load the oracle; bench.py does so only inside cpu_baseline / its parity leg and
+    __graft_entry__.py only inside build() (compiling the checker) and smoke()"""
+    for d in ("tools", "examples", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, d)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".sh")):
+                    txt = open(os.path.join(dp, f)).read()
+                    assert "import oracle" not in txt and "from oracle" not in txt and "libdis_oracle" not in txt, os.path.join(dp, f)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src.split("def cpu_baseline")[0]
+    assert "from oracle" not in head and "import oracle" not in head           # no module-level import
+    for line in src.splitlines():
+        if "from oracle" in line or "import oracle" in line:
+            assert line.startswith("    "), line                               # only inside functions (cpu_baseline, the parity leg)
+
+
 def test_flo_writer_matches_reference_file_layout(tmp_path, alley_golden_flow):
     """write_flo == SaveFlowFile (kroeger/run_dense.cpp:16-57): tag, int32 w, int32 h, h*w*2 float32; the golden flow of the
     reference's own kroeger/flows/alley_0001.flo (tests/golden/alley_0001_flo.npz) survives a round trip bit for bit"""
