@@ -171,7 +171,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
 {
   if (!p || !out || w_org <= 0 || h_org <= 0 || max_batch <= 0) return FOTG_ERR_ARG;
   if (p->noc != 1 && p->noc != 3) return FOTG_ERR_ARG;
-  if (p->ps != 8 && p->ps != 12) return FOTG_ERR_UNSUPPORTED;     // op-points use 8 and 12 (run_dense.cpp:242-261)
+  if (p->ps != 4 && p->ps != 8 && p->ps != 12 && p->ps != 16) return FOTG_ERR_UNSUPPORTED;   // op-points use 8 and 12 (run_dense.cpp:242-261); 4 and 16 for custom parameter sets
   if (p->sc_l < 0 || p->sc_f < p->sc_l || p->sc_f >= FOTG_MAXLEV) return FOTG_ERR_ARG;
   if (p->max_iter < 0 || p->tv_solverit < 0 || p->tv_innerit < 0) return FOTG_ERR_ARG;
   if (p->costfct < 0 || p->costfct > 2 || (p->costfct == 2 && !(p->normoutlier > 0))) return FOTG_ERR_ARG;
@@ -470,7 +470,16 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   if (const char *e = getenv("FOTG_LK_NP")) np = atoi(e);
 #define LK(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
 #define LKD(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_, true><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
-  if (c->p.depth) {
+  if (c->ps == 4 || c->ps == 16) {                                  // custom patch sizes: one patch per wave
+    if (c->p.depth) {
+      if (c->ps == 4) { if (c->noc == 1) LKD(4, 1, 1); else LKD(4, 3, 1); }
+      else { if (c->noc == 1) LKD(16, 1, 1); else LKD(16, 3, 1); }
+    } else {
+      if (c->ps == 4) { if (c->noc == 1) LK(4, 1, 1); else LK(4, 3, 1); }
+      else { if (c->noc == 1) LK(16, 1, 1); else LK(16, 3, 1); }
+    }
+  }
+  else if (c->p.depth) {
     if (c->ps == 8 && c->noc == 1) { if (np >= 2) LKD(8, 1, 2); else LKD(8, 1, 1); }
     else if (c->ps == 8) { if (np >= 2) LKD(8, 3, 2); else LKD(8, 3, 1); }
     else if (c->noc == 1) { if (np >= 2) LKD(12, 1, 2); else LKD(12, 1, 1); }
@@ -499,7 +508,11 @@ static int aggregate_impl(fotg_ctx *c, int l, int n, const float *p_iter, const 
   const int nch = c->nch;
   if (cg_p_iter) {
     dim3 grid(((g.w + 15) / 16) * ((g.h + 15) / 16), n), block(256);
-    if (c->ps == 8 && c->noc == 1) densify_fb_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g, nch);
+#define DFB(PS_, NOC_) densify_fb_kernel<PS_, NOC_><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g, nch)
+    if (c->ps == 4) { if (c->noc == 1) DFB(4, 1); else DFB(4, 3); }
+    else if (c->ps == 16) { if (c->noc == 1) DFB(16, 1); else DFB(16, 3); }
+#undef DFB
+    else if (c->ps == 8 && c->noc == 1) densify_fb_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g, nch);
     else if (c->ps == 8) densify_fb_kernel<8, 3><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g, nch);
     else if (c->noc == 1) densify_fb_kernel<12, 1><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g, nch);
     else densify_fb_kernel<12, 3><<<grid, block, 0, s>>>(p_iter, pweight, cg_p_iter, cg_pweight, flowout, fs, g, nch);
@@ -507,7 +520,11 @@ static int aggregate_impl(fotg_ctx *c, int l, int n, const float *p_iter, const 
     return FOTG_OK;
   }
   dim3 grid((g.w * g.h + 255) / 256, n), block(256);
-  if (c->ps == 8 && c->noc == 1) densify_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
+#define DF(PS_, NOC_) densify_kernel<PS_, NOC_><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch)
+  if (c->ps == 4) { if (c->noc == 1) DF(4, 1); else DF(4, 3); }
+  else if (c->ps == 16) { if (c->noc == 1) DF(16, 1); else DF(16, 3); }
+#undef DF
+  else if (c->ps == 8 && c->noc == 1) densify_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
   else if (c->ps == 8) densify_kernel<8, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
   else if (c->noc == 1) densify_kernel<12, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
   else densify_kernel<12, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);

@@ -33,7 +33,7 @@ extern "C" {
 typedef struct fotg_params {
   int sc_f;            /* coarsest scale            (src: coarsest_scale) */
   int sc_l;            /* finest scale              (src: finest_scale) */
-  int ps;              /* patch size 8 or 12        (src: patch_size) */
+  int ps;              /* patch size 4, 8, 12 or 16 (src: patch_size; the operating points use 8 and 12) */
   int max_iter;        /* LK iterations             (src: grad_descent_iter) */
   int min_iter;
   float dp_thresh;     /* 0.05 (squared internally, kroeger/oflow.cpp:88; src/oflow.cpp:53) */

@@ -27,6 +27,10 @@ for k in range(n):
     if op_point == 4:
         op.grad_descent_iter = 6                               # 128 in the preset; the solver / pyramid paths are what this sweeps
     op.cost_func = int(rng.integers(0, 3)); op.use_fbcon = bool(rng.integers(0, 4) == 0)
+    if rng.integers(0, 4) == 0:                                # a custom parameter set: other patch size / overlap / iteration count
+        op.patch_size = int(rng.choice([4, 8, 12, 16]))
+        op.patch_stride = float(rng.choice([0.3, 0.5, 0.75]))
+        op.grad_descent_iter = int(rng.integers(2, 10))
     op.depth_mode = bool(rng.integers(0, 3) == 0)             # stereo depth mode (one displacement channel)
     try:
         ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
@@ -66,7 +70,7 @@ for k in range(n):
         out = ofc.calc(dv(f0), dv(f1)).cpu().numpy()
         ok = np.array_equal(out, ref)
     bad += not ok
-    print(k, (w, h, op_point, noc, op.cost_func, op.use_fbcon, op.depth_mode, "entry %d" % entry), "rows@finest", ref.shape[0], "OK" if ok else "MISMATCH max %g" % np.abs(out - ref).max(), flush=True)
+    print(k, (w, h, op_point, noc, op.cost_func, op.use_fbcon, op.depth_mode, "ps %d" % op.patch_size, "entry %d" % entry), "rows@finest", ref.shape[0], "OK" if ok else "MISMATCH max %g" % np.abs(out - ref).max(), flush=True)
     ofc.close()
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -474,6 +474,25 @@ def test_sequence_mode(alley):
             ofc.calc_sequence(dev(np.concatenate([seq, seq[:1]])))        # 4 pairs > max_batch
 
 
+@pytest.mark.parametrize("ps,stride", [(4, 0.5), (16, 0.5), (16, 0.75)])
+def test_custom_patch_sizes(ps, stride):
+    """parameter sets beyond the four operating points (the reference's run_* binaries take the whole optparam list on
+    the command line, kroeger/run_dense.cpp:200-223): patch sizes 4 and 16 -- gray and RGB, with refinement, the
+    forward-backward merge and the depth variant"""
+    F, OFClass, _, O = _mods()
+    for noc, fb, depth in ((1, False, False), (3, False, False), (1, True, False), (1, False, True), (3, True, True)):
+        f0, f1 = synth_pair(200, 328, seed=60 + ps, noc=noc)
+        op = F.operating_point(2, 328, noc)
+        op.patch_size, op.patch_stride, op.use_fbcon, op.depth_mode = ps, stride, fb, depth
+        op.grad_descent_iter = 8
+        ofc = OFClass(op, F.img_params(width=328, height=200, padding=ps))
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        p = oracle_params(O, op)
+        ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+        assert out.shape == ref.shape and np.array_equal(out, ref), (ps, noc, fb, depth, float(np.abs(out - ref).max()))
+        ofc.close()
+
+
 def test_sequence_mode_with_switches():
     """the video entry point combined with the other switches: forward-backward merge (the backward grids take their
     templates and gradients from the NEXT frame's pyramid), L1 cost, and an initflow warm start -- each flow equals the
