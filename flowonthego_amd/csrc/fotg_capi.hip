@@ -212,7 +212,9 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   }
   if (p->usetvref) {
     const LevelGeom &g = c->geom[p->sc_l];
-    if (g.h > 1024 && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
+    // lexicographic solver: up to 1024 rows any kernel, up to 4096 rows the wide kernel one sweep per launch; the depth solver
+    // has one thread per row of a workgroup
+    if (g.h > (p->depth ? 1024 : 4096) && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     if (g.w < 3 || c->geom[p->sc_f].h < 5 || c->geom[p->sc_f].w < 3) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc + (p->depth ? (int)DE_NPLANE : 0));
     ALLOC(c->vr, B * c->vr_pair_stride * sizeof(float));
@@ -737,6 +739,13 @@ static void dispatch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStr
   // levels too tall for the LDS solvers: a whole workgroup per pair on the global arrays (FOTG_VR_WIDE=0: the single-wave kernel)
   {
     const char *e = getenv("FOTG_VR_WIDE");
+    if (a.h > 1024 && sweeps >= 1) {
+      // beyond the single-wave kernel's 16 rows per lane: four rows per lane, one sweep per launch (sweeps are sequential passes)
+      const int lp = (((a.h + 3) / 4 + 63) / 64) * 64;
+      for (int k = 0; k < sweeps; ++k) vr_sor_wide_kernel<4><<<n, lp, 0, s>>>(a, 1, omega);
+      g_wide_launches += sweeps;
+      return;
+    }
     if ((!e || atoi(e)) && vr_path_override() != 1 && sweeps >= 1 && sweeps <= 4 && a.h > 96) {
       for (int k = 2; k <= 4; k += 2) {
         if (a.K % k) continue;

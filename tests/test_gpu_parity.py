@@ -255,6 +255,23 @@ def test_wide_solver_kernel(wide, monkeypatch):
     assert (ran > 0) if wide == "1" else (ran == 0)
 
 
+def test_levels_taller_than_1024_rows():
+    """a refined level of more than 1024 rows (beyond 16 rows per lane of the single-wave solver): the wide kernel, four rows
+    per lane, one sweep per launch.  op-pt 3 on a narrow tall frame refines the full-resolution level (1304 rows)"""
+    F, OFClass, _, O = _mods()
+    w, h = 304, 1300
+    f0, f1 = synth_pair(h, w, seed=8)
+    op = F.operating_point(3, w, 1)
+    assert op.finest_scale == 0
+    before = F.lib().fotg_debug_counter(b"sor_wide")
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    assert out.shape[0] > 1024 and np.array_equal(out, ref)
+    assert F.lib().fotg_debug_counter(b"sor_wide") > before
+
+
 def test_plane_at_a_time_setup_stages(alley, monkeypatch):
     """FOTG_VR_SETUP=0: warp, first and second derivatives as three launches through global memory instead of the tiled
     single launch (levels that are not refined on chip): same planes, same flow"""
