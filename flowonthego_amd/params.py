@@ -47,6 +47,7 @@ class opt_params:
     cost_func: int = 0               # kroeger/oflow.h:45: 0 L2, 1 L1, 2 pseudo-Huber (threshold norm_outlier)
     use_fbcon: bool = False          # kroeger/oflow.h:44 usefbcon: forward-backward merge in the densification
     depth_mode: bool = False         # kroeger SELECTMODE=2 (run_DE_*): stereo depth, one displacement channel
+    min_iter: int = -1               # kroeger optparam.min_iter (oflow.h:38); < 0: = grad_descent_iter, as src/ and the operating points have it
     # derived (src/oflow.cpp:45-48)
     outlier_thresh: float = 0.0
     steps: int = 0
@@ -66,6 +67,8 @@ class opt_params:
         p = FotgParams()
         p.sc_f, p.sc_l, p.ps = self.coarsest_scale, self.finest_scale, self.patch_size
         p.max_iter = p.min_iter = self.grad_descent_iter       # src/kernels/optimize.cu:225-229: min == max
+        if 0 <= self.min_iter <= self.grad_descent_iter:
+            p.min_iter = self.min_iter                          # kroeger: stop early on the dp / residual rate tests (patch.cpp:279-282)
         p.dp_thresh, p.dr_thresh, p.res_thresh = self.dp_thresh, self.dr_thresh, self.res_thresh
         p.patove, p.patnorm, p.noc = self.patch_stride, int(self.use_mean_normalization), self.channels
         p.usetvref = int(self.use_var_ref)

@@ -50,6 +50,7 @@ typedef struct {
   int cost_func = 0;      // kroeger/oflow.h:45: 0 L2, 1 L1, 2 pseudo-Huber (threshold norm_outlier)
   bool use_fbcon = false; // kroeger/oflow.h:44 usefbcon: forward-backward merge in the densification
   bool depth_mode = false; // kroeger SELECTMODE=2 build (run_DE_*): stereo depth, flow arrays have ONE channel
+  int min_iter = -1; // kroeger optparam.min_iter (oflow.h:38); < 0: = grad_descent_iter (src/ and the operating points)
 } opt_params;
 
 inline fotg_params to_fotg(const opt_params &op)
@@ -57,6 +58,7 @@ inline fotg_params to_fotg(const opt_params &op)
   fotg_params p;
   p.sc_f = op.coarsest_scale; p.sc_l = op.finest_scale; p.ps = op.patch_size;
   p.max_iter = p.min_iter = op.grad_descent_iter;          // src/kernels/optimize.cu:225-229
+  if (op.min_iter >= 0 && op.min_iter <= op.grad_descent_iter) p.min_iter = op.min_iter;   // kroeger early termination (patch.cpp:279-282)
   p.dp_thresh = op.dp_thresh > 0 ? op.dp_thresh : 0.05f;
   p.dr_thresh = op.dr_thresh > 0 ? op.dr_thresh : 0.95f;
   p.res_thresh = op.res_thresh;

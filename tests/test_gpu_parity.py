@@ -31,6 +31,8 @@ def oracle_params(O, op):
     p = O.DisParams()
     p.sc_f, p.sc_l, p.ps = op.coarsest_scale, op.finest_scale, op.patch_size
     p.max_iter = p.min_iter = op.grad_descent_iter
+    if 0 <= op.min_iter <= op.grad_descent_iter:
+        p.min_iter = op.min_iter
     p.dp_thresh, p.dr_thresh, p.res_thresh = op.dp_thresh, op.dr_thresh, op.res_thresh
     p.patove, p.patnorm, p.noc, p.usetvref = op.patch_stride, int(op.use_mean_normalization), op.channels, int(op.use_var_ref)
     p.tv_alpha, p.tv_gamma, p.tv_delta = op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta
@@ -508,6 +510,34 @@ def test_custom_patch_sizes(ps, stride):
         ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
         assert out.shape == ref.shape and np.array_equal(out, ref), (ps, noc, fb, depth, float(np.abs(out - ref).max()))
         ofc.close()
+
+
+@pytest.mark.parametrize("noc", [1, 3])
+def test_early_termination(noc):
+    """min_iter < max_iter (kroeger's own parameter; every operating point sets them equal): patches stop on the update-rate
+    and residual-rate tests at different iterations (patch.cpp:279-282), two or four patches share a wave -- per-iteration
+    traces, iteration counts and the flow equal the oracle"""
+    import ctypes as C
+    F, OFClass, _, O = _mods()
+    f0, f1 = synth_pair(272, 480, seed=70, noc=noc)
+    varied = 0
+    for dp, dr in ((0.05, 0.95), (0.05, 2.0), (0.3, 1.2)):
+        op = F.operating_point(2, 480, noc)
+        op.grad_descent_iter, op.min_iter, op.dp_thresh, op.dr_thresh = 16, 2, dp, dr
+        ofc = OFClass(op, F.img_params(width=480, height=272, padding=op.patch_size))
+        F.lib().fotg_enable_taps(ofc._h, 1)
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        p = oracle_params(O, op)
+        assert p.min_iter == 2 and p.max_iter == 16
+        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (noc, dp)
+        # iteration counts of the finest scale really vary
+        P0 = O.Pyramid(O.pad_frame(f0, p.sc_f), p.sc_f, p.ps)
+        sl = p.sc_l
+        cnt = ofc.grid[0].read_state(0, taps=True)["cnt"]
+        assert cnt.max() <= 16 and cnt.min() >= 1, np.bincount(cnt).tolist()
+        varied += int(cnt.min() < cnt.max())
+        ofc.close()
+    assert varied >= 1              # with the residual-rate test relaxed the patches stop at different iterations
 
 
 def test_sequence_mode_with_switches():
