@@ -31,6 +31,13 @@ for k in range(n):
         op.patch_size = int(rng.choice([4, 8, 12, 16]))
         op.patch_stride = float(rng.choice([0.3, 0.5, 0.75]))
         op.grad_descent_iter = int(rng.integers(2, 10))
+        op.use_mean_normalization = bool(rng.integers(0, 2))
+        op.min_iter = int(rng.integers(0, op.grad_descent_iter + 1))
+        op.res_thresh = float(rng.choice([0.0, 0.5, 2.0]))
+        op.dr_thresh = float(rng.choice([0.95, 1.5]))
+        op.var_ref_iter = int(rng.integers(1, 5))
+        op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta = float(rng.choice([10.0, 3.0])), float(rng.choice([10.0, 0.0, 4.0])), float(rng.choice([5.0, 0.0]))
+        op.var_ref_sor_weight = float(rng.choice([1.6, 1.0, 1.9]))
     op.depth_mode = bool(rng.integers(0, 3) == 0)             # stereo depth mode (one displacement channel)
     try:
         ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
