@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3]: one 3840x2160 pair at operating point 4 (quality preset): python tools/time_4k_op4.py"""
+import sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import torch
+from conftest import synth_pair
+import flowonthego_amd as F
+from flowonthego_amd.oflow import OFClass
+f0, f1 = synth_pair(2160, 3840, seed=5)
+op = F.operating_point(4, 3840, 1)
+ofc = OFClass(op, F.img_params(width=3840, height=2160, padding=op.patch_size))
+a, b = torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda()
+for _ in range(2):
+    ofc.calc(a, b)
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(5):
+    ofc.calc(a, b)
+torch.cuda.synchronize()
+print("4K op-pt 4 (scales %d..%d): %.2f ms per pair" % (op.coarsest_scale, op.finest_scale, (time.perf_counter() - t) / 5 * 1e3))
