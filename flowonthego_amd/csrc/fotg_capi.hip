@@ -26,6 +26,24 @@ static thread_local int g_last_hip = 0;
   } while (0)
 #define LAUNCHCHK() HIPCHK(hipGetLastError())
 
+// every entry point runs on the context's device and leaves the caller's current device as it found it
+struct DevGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DevGuard(int dev)
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return;
+    if (cur == dev) { ok = true; return; }
+    if (hipSetDevice(dev) != hipSuccess) return;
+    prev = cur; ok = true;
+  }
+  ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define ON_DEVICE(dev)                                                              \
+  DevGuard dev_guard_(dev);                                                         \
+  if (!dev_guard_.ok) { g_last_hip = (int)hipGetLastError(); return FOTG_ERR_HIP; }
+
 struct GridState {
   const float *I0 = nullptr, *I0x = nullptr, *I0y = nullptr, *I1 = nullptr;
   long stride = 0;
@@ -34,8 +52,21 @@ struct GridState {
   int camlr = 0;                     // depth mode: camera side of this grid (kroeger/oflow.cpp:153,157)
 };
 
+// Switches read ONCE from the environment at fotg_create (tests force the kernel variants through them; nothing under
+// fotg_calc_batch touches the environment).  Every variant computes the same bits.
+struct FotgTune {
+  int lk_np;        // FOTG_LK_NP: patches per LK wave (0 = by launch size)
+  int vr_path;      // FOTG_VR_PATH: 0 automatic, 1 single-wave global-memory solver only, 2 no fused per-level kernel
+  int vr_stream;    // FOTG_VR_STREAM: 0 = resident-D kernel instead of the streaming solver
+  int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
+  int vr_wide;      // FOTG_VR_WIDE: 0 = single-wave kernel instead of the wide one
+  int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
+};
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+
 struct fotg_ctx {
   fotg_params p;
+  FotgTune tune;
   int w_org, h_org, Wp, Hp, padw, padh, device, max_batch, noc, ps;
   int nch;                           // flow channels: 2, or 1 in stereo depth mode (op.nop, kroeger/oflow.cpp:76-80)
   int base_lv;                       // first level the pyramid materialises: min(sc_l, 4)
@@ -176,7 +207,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   if (p->max_iter < 0 || p->tv_solverit < 0 || p->tv_innerit < 0) return FOTG_ERR_ARG;
   if (p->costfct < 0 || p->costfct > 2 || (p->costfct == 2 && !(p->normoutlier > 0))) return FOTG_ERR_ARG;
   if (p->depth && p->usetvref && p->sor_mode != FOTG_SOR_LEXICOGRAPHIC) return FOTG_ERR_UNSUPPORTED;
-  HIPCHK(hipSetDevice(device));
+  ON_DEVICE(device);
   fotg_ctx *c = new (std::nothrow) fotg_ctx();
   if (!c) return FOTG_ERR_ARG;
   memset((void *)c, 0, sizeof(*c));
@@ -243,12 +274,16 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   }
 #undef ALLOC
   {
-    const char *e = getenv("FOTG_SUBBATCH");
-    c->nsub = e ? atoi(e) : 1;     // measured on MI355X, 64 x 1080p: no gain (every stage is latency-, not throughput-bound at this batch), so off by default
+    c->tune.lk_np = env_int("FOTG_LK_NP", 0);
+    c->tune.vr_path = env_int("FOTG_VR_PATH", 0);
+    c->tune.vr_stream = env_int("FOTG_VR_STREAM", 1);
+    c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
+    c->tune.vr_wide = env_int("FOTG_VR_WIDE", 1);
+    c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
+    c->nsub = env_int("FOTG_SUBBATCH", 1);     // measured on MI355X, 64 x 1080p: no gain (the host launch path is the wall), so off by default
     if (c->nsub < 1) c->nsub = 1;
     if (c->nsub > 8) c->nsub = 8;
-    const char *g = getenv("FOTG_GRAPH");
-    c->use_graph = g ? atoi(g) : 1;
+    c->use_graph = env_int("FOTG_GRAPH", 1);
     if (hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
     if (c->nsub > 1) {
       if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
@@ -265,7 +300,7 @@ int fotg_enable_taps(fotg_ctx *c, int on)
 {
   if (!c) return FOTG_ERR_ARG;
   if (on && !c->taps) {
-    HIPCHK(hipSetDevice(c->device));
+    ON_DEVICE(c->device);
     for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) {
       const size_t n = (size_t)c->max_batch * c->geom[l].nop, nv = (size_t)c->ps * c->ps * c->noc;
       HIPCHK(hipMalloc((void **)&c->tap_t[l], n * nv * 4)); HIPCHK(hipMalloc((void **)&c->tap_tx[l], n * nv * 4));
@@ -368,7 +403,7 @@ int fotg_pyramid(fotg_ctx *c, int n, const float *I, int which, void *stream)
 {
   if (!c || !I || (which != 0 && which != 1)) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c->device);
   const float *I0 = which == 0 ? I : nullptr, *I1 = which == 1 ? I : nullptr;
   return c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, (hipStream_t)stream) : pyramid_impl<3>(c, n, I0, I1, (hipStream_t)stream);
 }
@@ -377,7 +412,7 @@ int fotg_pyramid_pair(fotg_ctx *c, int n, const float *I0, const float *I1, int 
 {
   if (!c || !I0 || !I1 || !(stages & 3)) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c->device);
   return c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, (hipStream_t)stream, stages) : pyramid_impl<3>(c, n, I0, I1, (hipStream_t)stream, stages);
 }
 
@@ -442,7 +477,7 @@ int fotg_grid_set_trace(fotg_ctx *c, int l, float *trace_host)
 int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
 {
   int st = check_level(c, l, n); if (st) return st;
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c->device);
   GridState &gs = c->gs[l];
   if (!gs.I0 || !gs.I1) return FOTG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -469,7 +504,7 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   // 2.5k: NP 1 0.018, NP 2 0.020
   const long npatch = (long)n * g.nop;
   int np = npatch >= 24576 ? 4 : npatch >= 4096 ? 2 : 1;
-  if (const char *e = getenv("FOTG_LK_NP")) np = atoi(e);
+  if (c->tune.lk_np > 0) np = c->tune.lk_np;
 #define LK(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
 #define LKD(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_, true><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
   if (c->ps == 4 || c->ps == 16) {                                  // custom patch sizes: one patch per wave
@@ -538,7 +573,7 @@ int fotg_grid_aggregate(fotg_ctx *c, int l, int n, float *flowout, void *stream)
 {
   int st = check_level(c, l, n); if (st) return st;
   if (!flowout) return FOTG_ERR_ARG;
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c->device);
   return aggregate_impl(c, l, n, c->p_iter[l], c->pweight[l], nullptr, nullptr, flowout, (hipStream_t)stream);
 }
 
@@ -573,26 +608,15 @@ static void launch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStrea
   vr_sor_kernel<K, P, U><<<n, 64, 0, s>>>(a, sweeps, omega);
 }
 
-// Solver-wave flavours of the LDS solvers (FOTG_VR_BANDS forces one; tests run them all against the oracle):
-//   0  sor_pipe_wave   one wave per sweep, K rows per lane, progress-counter handshake between sweeps
-//   1  sor_band_wave   bands of <= 32 rows, two lanes per row (u / v split), progress counters
-//   2  sor_rows_wave   bands of <= 64 rows, one lane per row, progress counters
-//   3  sor_sync_wave   bands of <= 64 rows, one lane per row, lock step by a workgroup barrier every 4 steps  [default]
-// Measured on MI355X (64 x 1080p, varref[6]/[5]/[4] ms): mode 0/2 0.121/0.145/0.323, mode 3 0.093/0.150/0.328 -- the
-// barrier-stepped waves start sweep n+1 only 8-12 diagonals behind sweep n (24 with the handshake), which wins on the
-// short diagonals of the coarse levels.
-static void set_bands(VrArgs &b, int sweeps, int max_waves)
+// Row bands of the barrier-stepped solver waves (sor_sync_wave): bands of <= 64 rows, one lane per row, one wave per (sweep, band).
+static void set_bands(VrArgs &b, int sweeps)
 {
   b.nbands = 0; b.band_rows = 0; b.band_mode = 0;
-  const char *e = getenv("FOTG_VR_BANDS");
-  const int mode = e ? atoi(e) : 3;
-  if (mode < 1 || mode > 3) return;
-  const int rows = mode == 1 ? 32 : 64;
-  const int nb = (b.h + rows - 1) / rows;
-  if (nb > 5 || sweeps * nb > (mode >= 2 && max_waves > 8 ? 8 : max_waves) || sweeps > 4) return;
+  const int nb = (b.h + 63) / 64;
+  if (sweeps * nb > 8 || sweeps > 4) return;
   b.nbands = nb;
   b.band_rows = (b.h + nb - 1) / nb;
-  b.band_mode = mode;
+  b.band_mode = 3;
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: cache what was set per device
@@ -606,73 +630,64 @@ static bool ensure_dyn_lds(const void *fn, int lds, int (&set)[32])
   return true;
 }
 
-template <int K, int P, int BANDED>
-static bool launch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s, const VrArgs &b, int threads)
+static bool launch_sor_pipe(int n, float omega, hipStream_t s, const VrArgs &b)
 {
-  constexpr int U = (P >= 8) ? 32 : 8 * P;
-  const int lds = 128 + (a.S + 2) * a.RPD * (int)sizeof(float2);
+  constexpr int P = 8, U = 32;
+  const int lds = 128 + (b.S + 2) * b.RPD * (int)sizeof(float2);
   static int lds_set[32] = {0};
-  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_sor_pipe_kernel<K, P, U, BANDED>), lds, lds_set)) return false;
-  vr_sor_pipe_kernel<K, P, U, BANDED><<<n, threads, lds, s>>>(b, omega);
+  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_sor_pipe_kernel<P, U>), lds, lds_set)) return false;
+  vr_sor_pipe_kernel<P, U><<<n, 1024, lds, s>>>(b, omega);          // all 16 waves copy D in and out
   return true;
 }
 
 static long g_wide_launches = 0;        // fotg_debug_counter("sor_wide")
-static long g_stream_launches = 0;      // fotg_debug_counter("sor_stream"): tests assert the opt-in kernel really ran
-// streaming solver (vr_sor_stream_kernel): diagonals travel through LDS rings.  Instantiated for 64..69 rows (1080p level 4).
-// FOTG_VR_STREAM=1 selects it (tests).
-template <int K, int RD, int RCW>
+static long g_stream_launches = 0;      // fotg_debug_counter("sor_stream"): tests assert the kernel really ran
+// streaming solver (vr_sor_stream_kernel): diagonals travel through LDS rings, two rows per lane.
+template <int RD, int RCW>
 static bool launch_sor_stream_k(const VrArgs &b, int n, float omega, hipStream_t s)
 {
   constexpr int M = FOTG_SYNC_M, U = 32;
   using GEO = StreamGeom<RD, RCW>;
-  const int NB = K == 2 ? 1 : (b.nbands > 0 ? b.nbands : 1);
   if (b.RP < 64 || b.RP + 1 > RCW || b.RPD > RD || (b.RPD & 1) || b.S < 2 * U) return false;
-  if (K == 2 ? (b.nsweeps > 3 || b.h + 2 > b.RPD) : (b.nsweeps * NB + 3 > 12)) return false;
-  const int DS = NB > 1 ? ((2 * M + 2 + M - 1) / M) * M : ((M + 2 + M - 1) / M) * M;
-  const int omax = b.nsweeps > 0 ? (b.nsweeps - 1) * DS + (NB - 1) * M : 0;
+  if (b.nsweeps > 3 || b.h + 2 > b.RPD) return false;
+  const int DS = ((M + 2 + M - 1) / M) * M;
+  const int omax = b.nsweeps > 0 ? (b.nsweeps - 1) * DS : 0;
   const int RDN = M * (GEO::LI + omax / M + 1 + 1), RCN = RDN - M;
   const int lds = RCN * GEO::CSLOT + RDN * GEO::DB + GEO::DB;
   if (lds > 160 * 1024) return false;
   static int lds_set[32] = {0};
-  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_sor_stream_kernel<RD, RCW, M, U, K>), lds, lds_set)) return false;
-  vr_sor_stream_kernel<RD, RCW, M, U, K><<<n, 1024, lds, s>>>(b, omega);
+  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_sor_stream_kernel<RD, RCW, M, U>), lds, lds_set)) return false;
+  vr_sor_stream_kernel<RD, RCW, M, U><<<n, 1024, lds, s>>>(b, omega);
   ++g_stream_launches;
   return true;
 }
 
-// Levels of 65..96 rows (1080p level 4: 68): FOTG_VR_STREAM unset / 2 = two rows per lane + packed arithmetic [default],
-// 1 = one row per lane in row bands, 0 = the resident-D kernel.  Two geometries: <= 69 rows and <= 97 rows per diagonal.
-static bool launch_sor_stream(const VrArgs &b, int n, float omega, hipStream_t s)
+// Levels of 65..96 rows (1080p level 4: 68).  Two geometries: <= 69 rows and <= 97 rows per diagonal.
+// tune.vr_stream = 0 (FOTG_VR_STREAM=0 at context creation; tests): the resident-D kernel instead.
+static bool launch_sor_stream(const fotg_ctx *c, const VrArgs &b, int n, float omega, hipStream_t s)
 {
-  const char *e = getenv("FOTG_VR_STREAM");
-  const int mode = e ? atoi(e) : 2;
-  if (mode == 2) return launch_sor_stream_k<2, 72, 70>(b, n, omega, s) || launch_sor_stream_k<2, 100, 98>(b, n, omega, s);
-  if (mode == 1) return launch_sor_stream_k<1, 72, 70>(b, n, omega, s);
-  return false;
+  if (!c->tune.vr_stream) return false;
+  return launch_sor_stream_k<72, 70>(b, n, omega, s) || launch_sor_stream_k<100, 98>(b, n, omega, s);
 }
 
-// sweep-pipelined LDS solver when it applies: <= 4 sweeps (one wave each), (du,dv) of the level fit in LDS
-static bool dispatch_sor_pipe(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
+// sweep-pipelined LDS solver when it applies: <= 4 sweeps (one wave each per band)
+static bool dispatch_sor_pipe(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
+#ifdef FOTG_DEBUG
   if (const char *e = getenv("FOTG_DEBUG_SWEEPS")) sweeps = atoi(e);                    // timing experiments only (wrong results)
+#endif
   const int lds = 128 + (a.S + 2) * a.RPD * (int)sizeof(float2);
   if (sweeps < 1 || sweeps > 4 || a.S < 24) return false;
   VrArgs b = a;
-  b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
-  set_bands(b, sweeps, 16);
-  if (b.band_mode == 3 && launch_sor_stream(b, n, omega, s)) return true;     // 65..96 rows, any width: diagonals stream through LDS rings
-  if (lds > 150 * 1024) return false;                            // the kernels below keep the whole (du,dv) in LDS
-  if (b.band_mode == 1) return launch_sor_pipe<1, 8, 1>(a, n, sweeps, omega, s, b, sweeps * b.nbands * 64);
-  if (b.band_mode == 2) return launch_sor_pipe<1, 8, 2>(a, n, sweeps, omega, s, b, (sweeps * b.nbands < 4 ? 4 : sweeps * b.nbands) * 64);
-  if (b.band_mode == 3) return launch_sor_pipe<1, 8, 3>(a, n, sweeps, omega, s, b, 1024);     // all 16 waves copy D in and out
-  switch (a.K) {
-    case 1: return launch_sor_pipe<1, 8, 0>(a, n, sweeps, omega, s, b, 256);
-    case 2: return launch_sor_pipe<2, 8, 0>(a, n, sweeps, omega, s, b, 256);
-    case 3: return launch_sor_pipe<3, 4, 0>(a, n, sweeps, omega, s, b, 256);
-    case 4: return launch_sor_pipe<4, 4, 0>(a, n, sweeps, omega, s, b, 256);
-    default: return false;
-  }
+  b.nsweeps = sweeps;
+#ifdef FOTG_DEBUG
+  if (getenv("FOTG_DEBUG_NOSOR")) b.nsweeps = 0;                // timing experiments only
+#endif
+  set_bands(b, sweeps);
+  if (b.band_mode != 3) return false;
+  if (launch_sor_stream(c, b, n, omega, s)) return true;        // 65..96 rows, any width: diagonals stream through LDS rings
+  if (lds > 150 * 1024) return false;                           // the kernel below keeps the whole (du,dv) in LDS
+  return launch_sor_pipe(n, omega, s, b);
 }
 
 static int fused_lds_bytes(const VrArgs &b, bool with_c)
@@ -680,82 +695,66 @@ static int fused_lds_bytes(const VrArgs &b, bool with_c)
   return 128 + (b.S + 2) * b.RPD * (int)sizeof(float2) + ((b.w * b.h + 3) / 4) * 16 + (with_c ? (b.SC * b.RP + 1) * 32 : 0);
 }
 
-template <int NOC, int K, int P, int BANDED, bool CL = false, bool RES = false>
+template <int NOC, bool CL = false, bool RES = false>
 static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s,
                                const float *I0, const float *I1, long img_stride, int tw, int pad)
 {
-  constexpr int U = (P >= 8) ? 32 : 8 * P;
+  constexpr int P = 8, U = 32;
   const int lds = fused_lds_bytes(b, CL);
   static int lds_set[32] = {0};
-  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL, RES>), lds, lds_set)) return false;
-  vr_inner_fused_kernel<NOC, K, P, U, BANDED, CL, RES><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
+  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, P, U, CL, RES>), lds, lds_set)) return false;
+  vr_inner_fused_kernel<NOC, P, U, CL, RES><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
   return true;
 }
 
-// whole fixed-point loop in one launch when (du,dv) + the smoothness plane fit in LDS and sweeps <= 4
+// whole fixed-point loop in one launch when (du,dv) + the smoothness plane fit in LDS, sweeps <= 4 and the level has <= 64 rows
 template <int NOC>
-static bool dispatch_inner_fused(const VrArgs &a, int n, int sweeps, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s,
-                                 const float *I0, const float *I1, long img_stride, int tw, int pad, int taps)
+static bool dispatch_inner_fused(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, int inner, float qa, float hd, float hg, float omega, float *flow,
+                                 long fs, hipStream_t s, const float *I0, const float *I1, long img_stride, int tw, int pad, int taps)
 {
   const int lds = fused_lds_bytes(a, false);
   // one workgroup does the per-pixel phases of its pair: only worth it for small levels (measured: 60x34 yes, 120x68 no)
   if (sweeps < 1 || sweeps > 4 || inner < 1 || lds > 156 * 1024 || a.S < 24 || a.w * a.h > 3000) return false;
   VrArgs b = a;
   b.taps = taps;
-  b.nsweeps = getenv("FOTG_DEBUG_NOSOR") ? 0 : sweeps;          // timing experiments only
-  set_bands(b, sweeps, 8);
-  if (b.band_mode == 2) { b.nbands = 0; b.band_mode = 0; }      // the fused kernel has no mode 2: plain waves
-  if (b.band_mode == 3 && b.nbands > 1) return false;           // the fused kernel's barrier-stepped waves assume a single band (<= 64 rows)
-  if (b.band_mode == 3) {
-    // system cells in LDS as well when they fit (FOTG_VR_CLDS=0: keep them in global memory; tests)
-    const char *e = getenv("FOTG_VR_CLDS");
-    if ((!e || atoi(e)) && fused_lds_bytes(a, true) <= 160 * 1024) {
-      // gray levels of <= 4 pixels per thread also keep their per-pixel inputs in registers over the loop
-      if constexpr (NOC == 1) {
-        if (a.w * a.h <= 4 * 512 && launch_inner_fused<1, 1, 8, 3, true, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
-      }
-      if (launch_inner_fused<NOC, 1, 8, 3, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
+  b.nsweeps = sweeps;
+#ifdef FOTG_DEBUG
+  if (getenv("FOTG_DEBUG_NOSOR")) b.nsweeps = 0;                // timing experiments only
+#endif
+  set_bands(b, sweeps);
+  if (b.band_mode != 3 || b.nbands > 1) return false;           // the fused kernel's barrier-stepped waves assume a single band (<= 64 rows)
+  // system cells in LDS as well when they fit (tune.vr_clds = 0: keep them in global memory; tests)
+  if (c->tune.vr_clds && fused_lds_bytes(a, true) <= 160 * 1024) {
+    // gray levels of <= 4 pixels per thread also keep their per-pixel inputs in registers over the loop
+    if constexpr (NOC == 1) {
+      if (a.w * a.h <= 4 * 512 && launch_inner_fused<1, true, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
     }
-    return launch_inner_fused<NOC, 1, 8, 3>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
+    if (launch_inner_fused<NOC, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
   }
-  if (b.band_mode == 1) return launch_inner_fused<NOC, 1, 8, 1>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
-  switch (a.K) {
-    case 1: return launch_inner_fused<NOC, 1, 8, 0>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
-    case 2: return launch_inner_fused<NOC, 2, 4, 0>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
-    default: return false;
-  }
+  return launch_inner_fused<NOC>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
 }
 
-// FOTG_VR_PATH (tests): 0/unset = automatic, 1 = single-wave global-memory solver only, 2 = no fused inner loop
-static int vr_path_override()
+static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
-  const char *e = getenv("FOTG_VR_PATH");
-  return e ? atoi(e) : 0;
-}
-
-static void dispatch_sor(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
-{
-  if (vr_path_override() != 1 && dispatch_sor_pipe(a, n, sweeps, omega, s)) return;
-  // levels too tall for the LDS solvers: a whole workgroup per pair on the global arrays (FOTG_VR_WIDE=0: the single-wave kernel)
-  {
-    const char *e = getenv("FOTG_VR_WIDE");
-    if (a.h > 1024 && sweeps >= 1) {
-      // beyond the single-wave kernel's 16 rows per lane: four rows per lane, one sweep per launch (sweeps are sequential passes)
-      const int lp = (((a.h + 3) / 4 + 63) / 64) * 64;
-      for (int k = 0; k < sweeps; ++k) vr_sor_wide_kernel<4><<<n, lp, 0, s>>>(a, 1, omega);
-      g_wide_launches += sweeps;
+  const int path = c->tune.vr_path;    // 0 = automatic, 1 = single-wave global-memory solver only, 2 = no fused inner loop (tests)
+  if (path != 1 && dispatch_sor_pipe(c, a, n, sweeps, omega, s)) return;
+  // levels too tall for the LDS solvers: a whole workgroup per pair on the global arrays (tune.vr_wide = 0: the single-wave kernel)
+  if (a.h > 1024 && sweeps >= 1) {
+    // beyond the single-wave kernel's 16 rows per lane: four rows per lane, one sweep per launch (sweeps are sequential passes)
+    const int lp = (((a.h + 3) / 4 + 63) / 64) * 64;
+    for (int k = 0; k < sweeps; ++k) vr_sor_wide_kernel<4><<<n, lp, 0, s>>>(a, 1, omega);
+    g_wide_launches += sweeps;
+    return;
+  }
+  if (c->tune.vr_wide && path != 1 && sweeps >= 1 && sweeps <= 4 && a.h > 96) {
+    for (int k = 2; k <= 4; k += 2) {
+      if (a.K % k) continue;
+      const int lp = (((a.h + k - 1) / k + 63) / 64) * 64;
+      if (sweeps * lp > 1024) continue;
+      if (k == 2) vr_sor_wide_kernel<2><<<n, sweeps * lp, 0, s>>>(a, sweeps, omega);
+      else vr_sor_wide_kernel<4><<<n, sweeps * lp, 0, s>>>(a, sweeps, omega);
+      ++g_wide_launches;
       return;
-    }
-    if ((!e || atoi(e)) && vr_path_override() != 1 && sweeps >= 1 && sweeps <= 4 && a.h > 96) {
-      for (int k = 2; k <= 4; k += 2) {
-        if (a.K % k) continue;
-        const int lp = (((a.h + k - 1) / k + 63) / 64) * 64;
-        if (sweeps * lp > 1024) continue;
-        if (k == 2) vr_sor_wide_kernel<2><<<n, sweeps * lp, 0, s>>>(a, sweeps, omega);
-        else vr_sor_wide_kernel<4><<<n, sweeps * lp, 0, s>>>(a, sweeps, omega);
-        ++g_wide_launches;
-        return;
-      }
     }
   }
   // prefetch depth: as deep as the register budget of K rows per lane allows, and 2P+2 <= S (ring never
@@ -791,16 +790,15 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   const float half_delta_over3 = c->p.tv_delta * 0.5f / 3.0f;
   const int inner = c->p.tv_innerit * (l + 1);
   // small levels: the whole level (set-up stages, fixed-point loop, final w + d) in one launch, one workgroup per pair
-  if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && vr_path_override() == 0 &&
-      dispatch_inner_fused<NOC>(a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s,
+  if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && c->tune.vr_path == 0 &&
+      dispatch_inner_fused<NOC>(c, a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s,
                                 I0, I1, img_stride, g.tw, c->ps, c->taps ? 1 : 0)) {
     LAUNCHCHK();
     return FOTG_OK;
   }
-  const char *esetup = getenv("FOTG_VR_SETUP");
-  if (!esetup || atoi(esetup)) {
+  if (c->tune.vr_setup) {
     // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
-    // (FOTG_VR_SETUP=0: memset + the three plane-at-a-time launches; tests)
+    // (tune.vr_setup = 0: memset + the three plane-at-a-time launches; tests)
     vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1);
     LAUNCHCHK();
   } else {
@@ -817,7 +815,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     LAUNCHCHK();
     if (c->p.tv_solverit > 0) {
       if (c->p.sor_mode == FOTG_SOR_REDBLACK) vr_sor_redblack_kernel<<<n, 1024, 0, s>>>(a, c->p.tv_solverit, c->p.tv_sor);
-      else dispatch_sor(a, n, c->p.tv_solverit, c->p.tv_sor, s);
+      else dispatch_sor(c, a, n, c->p.tv_solverit, c->p.tv_sor, s);
       LAUNCHCHK();
     }
   }
@@ -845,7 +843,7 @@ static int varref_depth_impl(fotg_ctx *c, int l, int n, const float *I0, const f
   const int du_bytes = g.st * g.h * (int)sizeof(float);
   // levels up to 8192 cells with the operating points' three sweeps: everything after the set-up in one launch per level
   // (FOTG_VR_PATH != 0 forces the launch-per-stage path below; tests)
-  if (5 * du_bytes <= 160 * 1024 && c->p.tv_solverit == 3 && 3 * threads <= 1024 && vr_path_override() == 0) {
+  if (5 * du_bytes <= 160 * 1024 && c->p.tv_solverit == 3 && 3 * threads <= 1024 && c->tune.vr_path == 0) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool set[32];
@@ -910,7 +908,7 @@ static int varref_dispatch(fotg_ctx *c, int l, int n, const float *I0, const flo
   int st = check_level(c, l, n); if (st) return st;
   if (!I0 || !I1 || !flow || !c->vr) return FOTG_ERR_ARG;
   if (c->geom[l].h < 5 || c->geom[l].w < 3) return FOTG_ERR_UNSUPPORTED;
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c->device);
   if (c->p.depth)
     return c->noc == 1 ? varref_depth_impl<1>(c, l, n, I0, I1, pair_stride, flow, stream, camlr)
                        : varref_depth_impl<3>(c, l, n, I0, I1, pair_stride, flow, stream, camlr);
@@ -1123,7 +1121,7 @@ int fotg_calc_batch(fotg_ctx *c, int n, const float *I0, const float *I1, const 
 {
   if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c->device);
   hipStream_t s = (hipStream_t)stream;
   bool tracing = false;
   for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) tracing |= c->gs[l].trace_host != nullptr;
@@ -1167,7 +1165,7 @@ int fotg_calc_batch_u8(fotg_ctx *c, int n, const unsigned char *I0, const unsign
 {
   if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c->device);
   return calc_range<unsigned char>(c, n, I0, I1, initflow, outflow, (hipStream_t)stream);
 }
 
@@ -1176,14 +1174,14 @@ int fotg_calc_sequence(fotg_ctx *c, int n_frames, const float *frames, const flo
 {
   if (!c || !frames || !outflow) return FOTG_ERR_ARG;
   if (n_frames < 2 || n_frames - 1 > c->max_batch) return FOTG_ERR_BATCH;
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c->device);
   return calc_range<float>(c, n_frames - 1, frames, nullptr, initflow, outflow, (hipStream_t)stream);
 }
 int fotg_calc_sequence_u8(fotg_ctx *c, int n_frames, const unsigned char *frames, const float *initflow, float *outflow, void *stream)
 {
   if (!c || !frames || !outflow) return FOTG_ERR_ARG;
   if (n_frames < 2 || n_frames - 1 > c->max_batch) return FOTG_ERR_BATCH;
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c->device);
   return calc_range<unsigned char>(c, n_frames - 1, frames, nullptr, initflow, outflow, (hipStream_t)stream);
 }
 
@@ -1208,7 +1206,7 @@ int fotg_upsample_crop(fotg_ctx *c, int n, const float *flow, float *out, void *
 {
   if (!c || !flow || !out) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c->device);
   const LevelGeom &g = c->geom[c->p.sc_l];
   dim3 grid((c->w_org * c->h_org + 255) / 256, n), block(256);
   upsample_crop_kernel<<<grid, block, 0, (hipStream_t)stream>>>(flow, (long)g.w * g.h * c->nch, g.w, g.h, c->p.sc_l, c->padw / 2, c->padh / 2,

@@ -96,16 +96,18 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
       if (have[k / NOC]) acc = acc + x[k] * y[k];
     return acc;
   };
+  // (the empty asm keeps every step a v_cndmask: left alone, the compiler turns the select chain of NP = 4 into a load from a
+  // private array indexed by gid -- scratch stores and loads in every iteration, 13x the kernel's algorithmic HBM traffic)
   auto packf = [&](const float (&v)[NP]) {
     float x = v[0];
 #pragma unroll
-    for (int k = 1; k < NP; ++k) x = gid == k ? v[k] : x;
+    for (int k = 1; k < NP; ++k) { x = gid == k ? v[k] : x; asm volatile("" : "+v"(x)); }
     return x;
   };
   auto packi = [&](const int (&v)[NP]) {
     int x = v[0];
 #pragma unroll
-    for (int k = 1; k < NP; ++k) x = gid == k ? v[k] : x;
+    for (int k = 1; k < NP; ++k) { x = gid == k ? v[k] : x; asm volatile("" : "+v"(x)); }
     return x;
   };
   auto getf = [&](float x, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), k * G)); };

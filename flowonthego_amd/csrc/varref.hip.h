@@ -563,7 +563,9 @@ __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float 
 template <int K>
 __global__ __launch_bounds__(1024) void vr_sor_wide_kernel(VrArgs a, int sweeps, float omega)
 {
-  constexpr int LA = 2, DS = 2 * LA + 2;
+  // look-ahead: K = 2 keeps two stages of loads in flight (ring of three); K = 4 one (ring of two: three stages of four rows
+  // would not fit the 128 registers a 1024-thread workgroup leaves a lane)
+  constexpr int LA = K >= 4 ? 1 : 2, DS = 2 * LA + 2;
   __shared__ float2 edge[2][4][16];                  // [step parity][sweep][wave of the sweep]: prev[K-1] of the wave's lane 63
   const int pair = blockIdx.x, tid = threadIdx.x, LP = blockDim.x / sweeps;
   const int n = tid / LP, L = tid % LP, lane = tid & 63, wv = L >> 6;
@@ -601,7 +603,7 @@ __global__ __launch_bounds__(1024) void vr_sor_wide_kernel(VrArgs a, int sweeps,
   __syncthreads();
   Stage s0, s1, s2;                                  // ring of LA + 1 stages, rotated by unrolling (no copies of loads in flight)
   issue(s0, 0 - DS * n);
-  issue(s1, 1 - DS * n);
+  if constexpr (LA == 2) issue(s1, 1 - DS * n);
   const int T = S + DS * (sweeps - 1);
   auto step = [&](Stage &cur, Stage &nx, int t) {
     const int s = t - DS * n;                        // this sweep's diagonal (wave-uniform)
@@ -628,410 +630,36 @@ __global__ __launch_bounds__(1024) void vr_sor_wide_kernel(VrArgs a, int sweeps,
   };
   // 6 steps per loop trip (the compiler drains all loads at the loop header); the steps past T that round the count up find
   // s >= S and only keep the barriers.  Step t consumes stage t % 3 and refills stage (t + 2) % 3.
-  for (int t = 0; t < T; t += 6) {
-    step(s0, s2, t);     step(s1, s0, t + 1); step(s2, s1, t + 2);
-    step(s0, s2, t + 3); step(s1, s0, t + 4); step(s2, s1, t + 5);
+  if constexpr (LA == 2) {
+    for (int t = 0; t < T; t += 6) {
+      step(s0, s2, t);     step(s1, s0, t + 1); step(s2, s1, t + 2);
+      step(s0, s2, t + 3); step(s1, s0, t + 4); step(s2, s1, t + 5);
+    }
+  } else {
+    // step t consumes stage t % 2 and refills the other one (consumed by the previous step)
+    for (int t = 0; t < T; t += 4) {
+      step(s0, s1, t);     step(s1, s0, t + 1);
+      step(s0, s1, t + 2); step(s1, s0, t + 3);
+    }
   }
 }
 
-// Sweep-pipelined variant (the production path whenever D fits in LDS): the `sweeps` Gauss-Seidel sweeps of one
-// sor_coupled call run CONCURRENTLY, one wave per sweep, staggered along the anti-diagonals.  Sweep n+1 may process
-// diagonal s as soon as sweep n has finished diagonal s+1 (its "old" right/bottom neighbours are sweep n's values of
-// diagonal s+1, its own old value is sweep n's value of diagonal s) -- again exactly the data dependencies of the
-// sequential reference, so the result is bit-identical, but the dependent chain shrinks from sweeps*(w+h-1) steps to
-// (w+h-1) + a few.  (du,dv) live in LDS in the skewed layout; waves hand over through it, gated by per-wave progress
-// counters (the LDS unit executes one wave's accesses in order; compiler barriers keep program order, the counters
-// are relaxed atomics).  The system C is streamed from global memory (nontemporal: L2-served, never stale in L1)
-// through the register ring.
+// (du,dv) of a level in LDS, skewed like the global arrays (the LDS solvers below).
 //
-// LDS map (dynamic): u64[0..16) = 32 int progress counters, u64[16 ..) = float2 cells of D ((S+2) rows of RPD cells:
-// row S stays zero, row S+1 is scratch for the tail steps), then whatever the calling kernel appends.
+// LDS map (dynamic): u64[0..16) = header (unused), u64[16 ..) = float2 cells of D ((S+2) rows of RPD cells: row S stays zero,
+// row S+1 is scratch for the tail steps), then whatever the calling kernel appends.
 extern __shared__ unsigned long long fotg_lds64[];
-#define FOTG_LDS_HDR 16     // u64 units: 32 int progress counters (slot 31 = the always-ready dummy leader)
+#define FOTG_LDS_HDR 16     // u64 units
 #ifndef FOTG_FUSED_NT
 #define FOTG_FUSED_NT false
+#endif
 #ifndef FOTG_SYNC_M
 #define FOTG_SYNC_M 4          // solver steps per workgroup barrier of the barrier-stepped solver waves
-#endif
 #endif
 
 __device__ __forceinline__ float2 lds_d_ld(int idx) { return __builtin_bit_cast(float2, fotg_lds64[FOTG_LDS_HDR + idx]); }
 __device__ __forceinline__ void lds_d_st(int idx, float2 v) { fotg_lds64[FOTG_LDS_HDR + idx] = __builtin_bit_cast(unsigned long long, v); }
-#define FOTG_CBAR() asm volatile("" ::: "memory")
 
-// call with all threads of the block, then __syncthreads()
-__device__ __forceinline__ void sor_pipe_reset_progress()
-{
-  int *progress = reinterpret_cast<int *>(fotg_lds64);
-  if (threadIdx.x < 32) progress[threadIdx.x] = threadIdx.x == 31 ? 0x7fffffff : -1;   // slot 31: always-ready dummy leader
-}
-
-// one sweep by the calling wave `wv` (0 <= wv < nsweeps)
-template <int K, int P, int U, bool NT>
-__device__ __forceinline__ void sor_pipe_wave(const VrArgs &a, int pair, float omega, int wv, int lane)
-{
-  int *progress = reinterpret_cast<int *>(fotg_lds64);
-  auto prog_load = [&](int i) { const int v = __hip_atomic_load(&progress[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); FOTG_CBAR(); return v; };
-  auto prog_store = [&](int i, int v) { FOTG_CBAR(); __hip_atomic_store(&progress[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  // lanes beyond the image own K padding rows (columns RP.. of D, all zero) and run with omega = 0: they read zeros,
-  // compute zeros and write zeros, so the loop body needs no exec-mask branches
-  const bool act = lane < a.nlanes;
-  const int r0 = act ? lane * K : a.RP;
-  const float om_lane = act ? omega : 0.f;
-  const int S = a.S, RP = a.RP, RPD = a.RPD;
-  const int lead = wv > 0 ? wv - 1 : 31;
-  const unsigned lead_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long *)fotg_lds64 + 4u * (unsigned)lead;
-
-  struct Stage { float4 c[K][2]; };
-  Stage ring[P];
-  struct Old { float2 nxt[K + 1]; };                             // (du,dv) of the NEXT diagonal at rows r0 .. r0+K
-  Old oldq[2];
-  typedef float vf4 __attribute__((ext_vector_type(4)));
-  // Running addresses instead of per-step products: every issue slot of this single wave is on the critical path.
-  const unsigned c_row = (unsigned)RP * 32u;
-  const char *cptr = reinterpret_cast<const char *>(a.Cp(pair)) + (size_t)r0 * 32u;   // row of C to prefetch next
-  const char *cend = cptr + (size_t)S * c_row;                                          // the spare all-zero row S
-  int lrow = r0;                                                                        // LDS cell of (diagonal s, first own row)
-  auto load_c = [&](Stage &st, const char *ptr) {
-    const vf4 *cp = reinterpret_cast<const vf4 *>(ptr);
-#pragma unroll
-    for (int m = 0; m < K; ++m) {
-      const vf4 x = NT ? __builtin_nontemporal_load(cp + 2 * m) : cp[2 * m], y = NT ? __builtin_nontemporal_load(cp + 2 * m + 1) : cp[2 * m + 1];
-      st.c[m][0] = make_float4(x.x, x.y, x.z, x.w); st.c[m][1] = make_float4(y.x, y.y, y.z, y.w);
-    }
-  };
-  auto fetch_nxt = [&](Old &o, int d1) {                       // LDS reads of one diagonal
-#pragma unroll
-    for (int m = 0; m <= K; ++m) o.nxt[m] = lds_d_ld(d1 + m);
-  };
-  // A follower may read diagonal d once its leader has completed it.  The spin is inline asm on purpose: a C loop
-  // here makes the compiler flush vmcnt (drain the C prefetch ring) in front of it.
-  auto wait_need = [&](int need, int &seen) {
-    if (seen < need) {
-      int v;
-      asm volatile("L_fotg_spin_%=:\n\t"
-                   "ds_read_b32 %0, %1\n\t"
-                   "s_waitcnt lgkmcnt(0)\n\t"
-                   "v_cmp_lt_i32 vcc, %0, %2\n\t"
-                   "s_cbranch_vccz L_fotg_done_%=\n\t"
-                   "s_sleep 1\n\t"
-                   "s_branch L_fotg_spin_%=\n\t"
-                   "L_fotg_done_%=:"
-                   : "=&v"(v) : "v"(lead_addr), "v"(need) : "vcc", "memory");
-      seen = v;
-    }
-  };
-  constexpr int CHK = 4;                                         // progress is published / checked every CHK steps
-#pragma unroll
-  for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }      // host guarantees S >= 24
-  int seen = -1;
-  // start with slack: the steady-state check at step s (s % CHK == 0) wants the leader CHK+3 diagonals ahead
-  wait_need(2 * CHK + 4 < S - 1 ? 2 * CHK + 4 : S - 1, seen);
-  float2 own[K];                                                 // old values of the current diagonal = last step's nxt[0..K-1]
-#pragma unroll
-  for (int m = 0; m < K; ++m) own[m] = lds_d_ld(lrow + m);
-  fetch_nxt(oldq[0], lrow + RPD);
-  fetch_nxt(oldq[1], lrow + 2 * RPD);
-  float2 prev[K];
-  float hl[K];
-#pragma unroll
-  for (int m = 0; m < K; ++m) { prev[m] = make_float2(0.f, 0.f); hl[m] = 0.f; }
-  const int rpd3 = 3 * RPD;
-  // one step = one anti-diagonal.  TAIL = false: every row it touches (s .. s+P, s+3) is inside the image, so no
-  // clamps, no omega select; TAIL = true: the last chunks, where prefetches clamp to the spare rows and steps
-  // beyond S-1 run with omega = 0 into the scratch row.
-  auto step = [&](auto tail_tag, int u, int s) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    Stage &st = ring[u % P];
-    Old &od = oldq[u & 1];                                       // diagonal s+1
-    const float om = (!TAIL || s < S) ? om_lane : 0.f;
-    float2 top0;
-    top0.x = dpp_wave_shr1(prev[K - 1].x);
-    top0.y = dpp_wave_shr1(prev[K - 1].y);
-    float2 res[K];
-#pragma unroll
-    for (int m = 0; m < K; ++m)
-      res[m] = sor_update(own[m], st.c[m][0], st.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], od.nxt[m], od.nxt[m + 1], om);
-    {
-      const int dst = (!TAIL || s < S) ? lrow : (S + 1) * RPD + r0;          // tail steps write the scratch row
-#pragma unroll
-      for (int m = 0; m < K; ++m) lds_d_st(dst + m, res[m]);
-      if ((u % CHK) == CHK - 1 || (TAIL && s == S - 1)) prog_store(wv, (!TAIL || s < S) ? s : S - 1);   // after the data: LDS keeps a wave's order
-    }
-#pragma unroll
-    for (int m = 0; m < K; ++m) { prev[m] = res[m]; hl[m] = st.c[m][1].y; own[m] = od.nxt[m]; }
-    load_c(st, cptr);                                            // row s+P
-    if (!TAIL || cptr < cend) cptr += c_row;                     // (clamped at the spare zero row S)
-    // refill this slot with diagonal s+3 (consumed two steps from now: LDS latency is off the chain).  Every CHK
-    // steps make sure the leader is far enough ahead for the next CHK refills; `seen` comes from a poll issued
-    // CHK steps ago, so in steady state nothing waits here.
-    if (!TAIL) {
-      if ((u % CHK) == 0) { wait_need(s + 3 + CHK - 1, seen); seen = prog_load(lead); }
-      fetch_nxt(od, lrow + rpd3);
-    } else {
-      if ((u % CHK) == 0) { wait_need(s + 3 + CHK - 1 < S - 1 ? s + 3 + CHK - 1 : S - 1, seen); seen = prog_load(lead); }
-      fetch_nxt(od, (s + 3 < S ? s + 3 : S) * RPD + r0);
-    }
-    lrow += RPD;
-  };
-  int t0 = 0;
-  for (; t0 + U + P + CHK + 3 <= S; t0 += U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) step(std::false_type{}, u, t0 + u);
-  }
-  for (; t0 < S; t0 += U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) step(std::true_type{}, u, t0 + u);
-  }
-}
-
-// Banded two-lanes-per-row variant of the sweep pipeline.  A wave owns a BAND of <= 32 consecutive image rows of one
-// sweep; lane l handles row (l & 31) of the band and ONE component (l >> 5: du or dv), so the ~28 flops of a pixel
-// update are split over two lanes (the two right-hand sides B1, B2 are exchanged with one v_permlane32_swap) and a
-// step costs ~2/3 of the instructions of the one-lane-per-row form -- the loop is bound by single-wave instruction
-// issue, so that is time.  Rows beyond 32 go to further waves: wave (sweep n, band b) trails (n-1, b) and (n-1, b+1)
-// [old values] and (n, b-1) [new top value of its first row, read from LDS instead of DPP], again only the
-// dependencies of the sequential sweep, so the result stays bit-identical.
-template <int P, int U, bool NT>
-__device__ __forceinline__ void sor_band_wave(const VrArgs &a, int pair, float omega, int wv, int lane)
-{
-  int *progress = reinterpret_cast<int *>(fotg_lds64);
-  float *Df = reinterpret_cast<float *>(fotg_lds64 + FOTG_LDS_HDR);          // D as floats: cell c -> Df[2c], Df[2c+1]
-  auto prog_load = [&](int i) { const int v = __hip_atomic_load(&progress[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); FOTG_CBAR(); return v; };
-  auto prog_store = [&](int i, int v) { FOTG_CBAR(); __hip_atomic_store(&progress[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  const int NB = a.nbands, n = wv / NB, b = wv % NB;
-  const int rb = b * a.band_rows, nrows = (rb + a.band_rows <= a.h ? a.band_rows : a.h - rb);
-  const int rr = lane & 31, comp = lane >> 5;
-  const bool isv = comp != 0, first_row = rr == 0;
-  const bool act = rr < nrows;
-  const int r = act ? rb + rr : a.RP;                          // idle lanes park on the zero padding cells with omega = 0
-  const float om_lane = act ? omega : 0.f;
-  const int S = a.S, RP = a.RP, RPD = a.RPD;
-  auto slot = [&](int nn, int bb) { return nn * 5 + bb; };
-  const int my_slot = slot(n, b);
-  const int lead_sw = n > 0 ? slot(n - 1, b) : 31;                               // old values of my rows
-  const int lead_bot = (n > 0 && b + 1 < NB) ? slot(n - 1, b + 1) : 31;          // old value below my last row
-  const int lead_top = b > 0 ? slot(n, b - 1) : 31;                              // new value above my first row
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long *)fotg_lds64;
-  auto wait_need = [&](int lead, int need, int &seen) {
-    if (seen < need) {
-      int v;
-      asm volatile("L_fotg_bspin_%=:\n\t"
-                   "ds_read_b32 %0, %1\n\t"
-                   "s_waitcnt lgkmcnt(0)\n\t"
-                   "v_cmp_lt_i32 vcc, %0, %2\n\t"
-                   "s_cbranch_vccz L_fotg_bdone_%=\n\t"
-                   "s_sleep 1\n\t"
-                   "s_branch L_fotg_bspin_%=\n\t"
-                   "L_fotg_bdone_%=:"
-                   : "=&v"(v) : "v"(lds0 + 4u * (unsigned)lead), "v"(need) : "vcc", "memory");
-      seen = v;
-    }
-  };
-  struct Stage { float a_self, a12, bb, hr, vb, vt; };          // this lane's component of the system cell
-  Stage ring[P];
-  typedef float vf4 __attribute__((ext_vector_type(4)));
-  const unsigned c_row = (unsigned)RP * 32u;
-  const char *cptr = reinterpret_cast<const char *>(a.Cp(pair)) + (size_t)r * 32u;
-  const char *cend = cptr + (size_t)S * c_row;
-  auto load_c = [&](Stage &st, const char *ptr) {
-    const vf4 *cp = reinterpret_cast<const vf4 *>(ptr);
-    const vf4 x = NT ? __builtin_nontemporal_load(cp) : cp[0], y = NT ? __builtin_nontemporal_load(cp + 1) : cp[1];
-    st.a_self = isv ? y.x : x.x; st.a12 = x.y; st.bb = isv ? x.w : x.z; st.hr = y.y; st.vb = y.z; st.vt = y.w;
-  };
-  constexpr int CHK = 4;
-  const int rpd2 = 2 * RPD;
-  int lf = 2 * r + comp;                                         // float index of (diagonal s, my row, my component)
-  int tf = 2 * (b > 0 ? rb - 1 : RP) + comp;                     // ... of (diagonal s, row above the band) [band 0: a zero cell]
-#pragma unroll
-  for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }
-  int seen_sw = -1, seen_bot = -1, seen_top = -1;
-  {
-    const int w0 = 2 * CHK + 4 < S - 1 ? 2 * CHK + 4 : S - 1;
-    wait_need(lead_sw, w0, seen_sw); wait_need(lead_bot, w0, seen_bot); wait_need(lead_top, w0, seen_top);
-  }
-  // old values of the next diagonal at my row (= my own old value one step later) and the row below; top value of the
-  // band's first row; two slots each, refilled two steps ahead
-  float own = Df[lf];
-  float nxr[2], nxb[2], tpl[2];
-  nxr[0] = Df[lf + rpd2]; nxb[0] = Df[lf + rpd2 + 2]; tpl[0] = 0.f;          // diagonal 1 (step 0 has no top: diagonal -1)
-  nxr[1] = Df[lf + 2 * rpd2]; nxb[1] = Df[lf + 2 * rpd2 + 2]; tpl[1] = Df[tf];   // diagonal 2; top for step 1 = (diagonal 0, row above)
-  float prev = 0.f, hl = 0.f;
-  auto step = [&](auto tail_tag, int u, int s) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    Stage &st = ring[u % P];
-    const int q = u & 1;
-    const float om = (!TAIL || s < S) ? om_lane : 0.f;
-    // the DPP read must execute with ALL lanes enabled (a lane reads its neighbour: a neighbour masked off by EXEC reads
-    // as 0), so it is computed unconditionally and pinned before the per-lane select
-    float dppv = dpp_wave_shr1(prev);
-    asm volatile("" : "+v"(dppv));
-    const float top = first_row ? tpl[q] : dppv;
-    float sv = st.hr * nxr[q];
-    sv = sv + st.vt * top;
-    sv = sv + st.vb * nxb[q];
-    sv = sv + st.bb;
-    const float B = hl * prev + sv;
-    // the other component's right-hand side (lane ^ 32)
-    // v_permlane32_swap swaps lanes 32-63 of its first register with lanes 0-31 of its second.  Two DISTINCT
-    // registers are required (with one register the low half of the result is lost), hence the asm with two
-    // read-write operands: afterwards lo = {B[0:31], B[0:31]}, hi = {B[32:63], B[32:63]}.
-    float lo = B, hi = B;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
-    const float Bo = isv ? lo : hi;
-    const float res = own + om * (st.a_self * B + st.a12 * Bo - own);
-    {
-      const int dst = (!TAIL || s < S) ? lf : 2 * ((S + 1) * RPD + r) + comp;   // tail steps write the scratch row
-      Df[dst] = res;
-      if ((u % CHK) == CHK - 1 || (TAIL && s == S - 1)) prog_store(my_slot, (!TAIL || s < S) ? s : S - 1);
-    }
-    prev = res; hl = st.hr; own = nxr[q];
-    load_c(st, cptr);
-    if (!TAIL || cptr < cend) cptr += c_row;
-    if (!TAIL) {
-      if ((u % CHK) == 0) {
-        wait_need(lead_sw, s + 3 + CHK - 1, seen_sw); wait_need(lead_bot, s + 3 + CHK - 1, seen_bot); wait_need(lead_top, s + 1 + CHK - 1, seen_top);
-        seen_sw = prog_load(lead_sw); seen_bot = prog_load(lead_bot); seen_top = prog_load(lead_top);
-      }
-      nxr[q] = Df[lf + 3 * rpd2]; nxb[q] = Df[lf + 3 * rpd2 + 2];             // diagonal s+3
-      tpl[q] = Df[tf + rpd2];                                                // (diagonal s+1, row above): top of step s+2
-    } else {
-      // same scheme with the diagonals clamped to the last one (the leader's final publish is S-1)
-      if ((u % CHK) == 0) {
-        const int lim = S - 1, n3 = s + 3 + CHK - 1 < lim ? s + 3 + CHK - 1 : lim, n1 = s + 1 + CHK - 1 < lim ? s + 1 + CHK - 1 : lim;
-        wait_need(lead_sw, n3, seen_sw); wait_need(lead_bot, n3, seen_bot); wait_need(lead_top, n1, seen_top);
-        seen_sw = prog_load(lead_sw); seen_bot = prog_load(lead_bot); seen_top = prog_load(lead_top);
-      }
-      const int d3 = s + 3 < S ? s + 3 : S, d1 = s + 1 < S ? s + 1 : S;
-      nxr[q] = Df[2 * (d3 * RPD + r) + comp]; nxb[q] = Df[2 * (d3 * RPD + r + 1) + comp];
-      tpl[q] = Df[2 * (d1 * RPD + (b > 0 ? rb - 1 : RP)) + comp];
-    }
-    lf += rpd2; tf += rpd2;
-  };
-  int t0 = 0;
-  for (; t0 + U + P + CHK + 3 <= S; t0 += U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) step(std::false_type{}, u, t0 + u);
-  }
-  for (; t0 < S; t0 += U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) step(std::true_type{}, u, t0 + u);
-  }
-}
-
-// Banded one-lane-per-row variant: like sor_pipe_wave with K = 1, but a wave owns only a band of <= 64 rows of its
-// sweep, so a level taller than 64 rows keeps one row per lane (2 bands of 34 rows at 1080p level 4) instead of two
-// rows per lane.  Dependencies across bands as in sor_band_wave: the first row's new top value comes from LDS
-// (written by band b-1 of the same sweep), the last row's old bottom value is band b+1's row of the previous sweep.
-template <int P, int U, bool NT>
-__device__ __forceinline__ void sor_rows_wave(const VrArgs &a, int pair, float omega, int wv, int lane)
-{
-  int *progress = reinterpret_cast<int *>(fotg_lds64);
-  auto prog_load = [&](int i) { const int v = __hip_atomic_load(&progress[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); FOTG_CBAR(); return v; };
-  auto prog_store = [&](int i, int v) { FOTG_CBAR(); __hip_atomic_store(&progress[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  const int NB = a.nbands, n = wv / NB, b = wv % NB;
-  const int rb = b * a.band_rows, nrows = (rb + a.band_rows <= a.h ? a.band_rows : a.h - rb);
-  const bool first_row = lane == 0;
-  const bool act = lane < nrows;
-  const int r = act ? rb + lane : a.RP;                         // idle lanes park on the zero padding cells with omega = 0
-  const float om_lane = act ? omega : 0.f;
-  const int S = a.S, RP = a.RP, RPD = a.RPD;
-  auto slot = [&](int nn, int bb) { return nn * 5 + bb; };
-  const int my_slot = slot(n, b);
-  const int lead_sw = n > 0 ? slot(n - 1, b) : 31;
-  const int lead_bot = (n > 0 && b + 1 < NB) ? slot(n - 1, b + 1) : 31;
-  const int lead_top = b > 0 ? slot(n, b - 1) : 31;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long *)fotg_lds64;
-  auto wait_need = [&](int lead, int need, int &seen) {
-    if (seen < need) {
-      int v;
-      asm volatile("L_fotg_rspin_%=:\n\t"
-                   "ds_read_b32 %0, %1\n\t"
-                   "s_waitcnt lgkmcnt(0)\n\t"
-                   "v_cmp_lt_i32 vcc, %0, %2\n\t"
-                   "s_cbranch_vccz L_fotg_rdone_%=\n\t"
-                   "s_sleep 1\n\t"
-                   "s_branch L_fotg_rspin_%=\n\t"
-                   "L_fotg_rdone_%=:"
-                   : "=&v"(v) : "v"(lds0 + 4u * (unsigned)lead), "v"(need) : "vcc", "memory");
-      seen = v;
-    }
-  };
-  struct Stage { float4 c0, c1; };
-  Stage ring[P];
-  typedef float vf4 __attribute__((ext_vector_type(4)));
-  const unsigned c_row = (unsigned)RP * 32u;
-  const char *cptr = reinterpret_cast<const char *>(a.Cp(pair)) + (size_t)r * 32u;
-  const char *cend = cptr + (size_t)S * c_row;
-  auto load_c = [&](Stage &st, const char *ptr) {
-    const vf4 *cp = reinterpret_cast<const vf4 *>(ptr);
-    const vf4 x = NT ? __builtin_nontemporal_load(cp) : cp[0], y = NT ? __builtin_nontemporal_load(cp + 1) : cp[1];
-    st.c0 = make_float4(x.x, x.y, x.z, x.w); st.c1 = make_float4(y.x, y.y, y.z, y.w);
-  };
-  constexpr int CHK = 4;
-  int lrow = r;                                                  // LDS cell of (diagonal s, my row)
-  int trow = b > 0 ? rb - 1 : RP;                                // ... of (diagonal s, row above the band) [band 0: a zero cell]
-#pragma unroll
-  for (int p = 0; p < P; ++p) { load_c(ring[p], cptr); cptr += c_row; }
-  int seen_sw = -1, seen_bot = -1, seen_top = -1;
-  {
-    const int w0 = 2 * CHK + 4 < S - 1 ? 2 * CHK + 4 : S - 1;
-    wait_need(lead_sw, w0, seen_sw); wait_need(lead_bot, w0, seen_bot); wait_need(lead_top, w0, seen_top);
-  }
-  float2 own = lds_d_ld(lrow);
-  float2 nxr[2], nxb[2], tpl[2];
-  nxr[0] = lds_d_ld(lrow + RPD); nxb[0] = lds_d_ld(lrow + RPD + 1); tpl[0] = make_float2(0.f, 0.f);
-  nxr[1] = lds_d_ld(lrow + 2 * RPD); nxb[1] = lds_d_ld(lrow + 2 * RPD + 1); tpl[1] = lds_d_ld(trow);
-  float2 prev = make_float2(0.f, 0.f);
-  float hl = 0.f;
-  const int rpd3 = 3 * RPD;
-  auto step = [&](auto tail_tag, int u, int s) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    Stage &st = ring[u % P];
-    const int q = u & 1;
-    const float om = (!TAIL || s < S) ? om_lane : 0.f;
-    // DPP reads must run with all lanes enabled: compute, pin, then select
-    float dx = dpp_wave_shr1(prev.x), dy = dpp_wave_shr1(prev.y);
-    asm volatile("" : "+v"(dx), "+v"(dy));
-    const float2 top = first_row ? tpl[q] : make_float2(dx, dy);
-    const float2 res = sor_update(own, st.c0, st.c1, hl, prev, top, nxr[q], nxb[q], om);
-    {
-      const int dst = (!TAIL || s < S) ? lrow : (S + 1) * RPD + r;
-      lds_d_st(dst, res);
-      if ((u % CHK) == CHK - 1 || (TAIL && s == S - 1)) prog_store(my_slot, (!TAIL || s < S) ? s : S - 1);
-    }
-    prev = res; hl = st.c1.y; own = nxr[q];
-    load_c(st, cptr);
-    if (!TAIL || cptr < cend) cptr += c_row;
-    if (!TAIL) {
-      if ((u % CHK) == 0) {
-        wait_need(lead_sw, s + 3 + CHK - 1, seen_sw); wait_need(lead_bot, s + 3 + CHK - 1, seen_bot); wait_need(lead_top, s + 1 + CHK - 1, seen_top);
-        seen_sw = prog_load(lead_sw); seen_bot = prog_load(lead_bot); seen_top = prog_load(lead_top);
-      }
-      nxr[q] = lds_d_ld(lrow + rpd3); nxb[q] = lds_d_ld(lrow + rpd3 + 1);    // diagonal s+3
-      tpl[q] = lds_d_ld(trow + RPD);                                         // (diagonal s+1, row above): top of step s+2
-    } else {
-      if ((u % CHK) == 0) {
-        const int lim = S - 1, n3 = s + 3 + CHK - 1 < lim ? s + 3 + CHK - 1 : lim, n1 = s + 1 + CHK - 1 < lim ? s + 1 + CHK - 1 : lim;
-        wait_need(lead_sw, n3, seen_sw); wait_need(lead_bot, n3, seen_bot); wait_need(lead_top, n1, seen_top);
-        seen_sw = prog_load(lead_sw); seen_bot = prog_load(lead_bot); seen_top = prog_load(lead_top);
-      }
-      const int d3 = s + 3 < S ? s + 3 : S, d1 = s + 1 < S ? s + 1 : S;
-      nxr[q] = lds_d_ld(d3 * RPD + r); nxb[q] = lds_d_ld(d3 * RPD + r + 1);
-      tpl[q] = lds_d_ld(d1 * RPD + (b > 0 ? rb - 1 : RP));
-    }
-    lrow += RPD; trow += RPD;
-  };
-  int t0 = 0;
-  for (; t0 + U + P + CHK + 3 <= S; t0 += U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) step(std::false_type{}, u, t0 + u);
-  }
-  for (; t0 < S; t0 += U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) step(std::true_type{}, u, t0 + u);
-  }
-}
 
 // Barrier-stepped solver waves: every wave of the workgroup executes one s_barrier per M solver steps, so the sweep /
 // band stagger is a fixed number of steps instead of a progress-counter handshake:
@@ -1179,8 +807,8 @@ __device__ __forceinline__ void sor_sync_wave(const VrArgs &a, int pair, float o
 }
 
 // stand-alone launch of one sor_coupled call: D global -> LDS, sweeps, LDS -> global
-template <int K, int P, int U, int BANDED>
-__global__ __launch_bounds__(BANDED == 1 || BANDED == 3 ? 1024 : BANDED == 2 ? 512 : 256) void vr_sor_pipe_kernel(VrArgs a, float omega)
+template <int P, int U>
+__global__ __launch_bounds__(1024) void vr_sor_pipe_kernel(VrArgs a, float omega)
 {
   const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float2 *Dg = a.Dp(pair);
@@ -1189,7 +817,7 @@ __global__ __launch_bounds__(BANDED == 1 || BANDED == 3 ? 1024 : BANDED == 2 ? 5
   {
     const float4 *g4 = reinterpret_cast<const float4 *>(Dg);
     const int n2 = ncell >> 1;
-    constexpr int Q = BANDED == 3 ? 8 : 4;                        // loads in flight per lane
+    constexpr int Q = 8;                                          // loads in flight per lane
     for (int k = threadIdx.x; k < n2; k += Q * blockDim.x) {
       float4 v[Q];
 #pragma unroll
@@ -1201,12 +829,8 @@ __global__ __launch_bounds__(BANDED == 1 || BANDED == 3 ? 1024 : BANDED == 2 ? 5
       }
     }
   }
-  sor_pipe_reset_progress();
   __syncthreads();
-  if constexpr (BANDED == 1) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, false>(a, pair, omega, wv, lane); }
-  else if constexpr (BANDED == 2) { if (wv < a.nsweeps * a.nbands) sor_rows_wave<P, U, false>(a, pair, omega, wv, lane); }
-  else if constexpr (BANDED == 3) sor_sync_wave<P, U, false, FOTG_SYNC_M>(a, pair, omega, wv, lane);
-  else { if (wv < a.nsweeps) sor_pipe_wave<K, P, U, false>(a, pair, omega, wv, lane); }
+  sor_sync_wave<P, U, false, FOTG_SYNC_M>(a, pair, omega, wv, lane);
   __syncthreads();
   {
     float4 *g4 = reinterpret_cast<float4 *>(Dg);
@@ -1258,7 +882,7 @@ __device__ __forceinline__ void glds16(const void *src, unsigned lds_dst_byte)
 // second row costs no prefetch registers, its top neighbour is the lane's own previous result, the two rows are
 // independent within a step (better issue than one dependent chain), and three solver waves have a SIMD each (the
 // loaders and the writer sit on the fourth).
-template <int RD, int RCW, int M, int U, int K>
+template <int RD, int RCW, int M, int U>
 __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float omega)
 {
   using GEO = StreamGeom<RD, RCW>;
@@ -1267,7 +891,7 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
   static_assert(U % M == 0 && UT % M == 0, "barrier phase is a compile-time property of the unrolled step");
   static_assert(RCW > 64 && RCW <= 128, "two direct loads per C plane and diagonal");
   const int pair = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int NB = K == 2 ? 1 : (a.nbands > 0 ? a.nbands : 1);
+  constexpr int NB = 1;
   constexpr int DBS = M, DS1 = ((M + 2 + M - 1) / M) * M, DSB = ((2 * M + 2 + M - 1) / M) * M;
   const int DS = NB > 1 ? DSB : DS1;
   const int S = a.S, RP = a.RP, RPD = a.RPD;
@@ -1279,8 +903,8 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
   const int RDN = M * (LI + WO + 1), RCN = RDN - M;               // ring slots
   const int NI = (E + omax) / M + 1;                              // barrier intervals every wave goes through
   const int nsolver = a.nsweeps * NB;
-  // roles: K = 1: solver waves, then three loaders and the writer.  K = 2: solver waves 0..2, helpers on SIMD 3 (waves 3, 7, 11, 15)
-  const int wvL0 = K == 2 ? 3 : nsolver, wvL1 = K == 2 ? 7 : nsolver + 1, wvL2 = K == 2 ? 11 : nsolver + 2, wvW = K == 2 ? 15 : nsolver + 3;
+  // roles: solver waves 0..2, helpers on SIMD 3 (waves 3, 7, 11, 15)
+  const int wvL0 = 3, wvL1 = 7, wvL2 = 11, wvW = 15;
   const unsigned CRING = (unsigned)RCN * CSLOT, DRING = (unsigned)RDN * DB;     // bytes
   const unsigned DBASE = CRING, DUMP = CRING + DRING;             // C ring | D ring | one spare D row for the no-op tail steps
   char *Dg = reinterpret_cast<char *>(a.Dp(pair));
@@ -1358,7 +982,7 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
     return;
   }
 
-  if constexpr (K == 2) {
+  {
     // ---------------- solver wave of sweep n, rows 2L and 2L+1 per lane ----------------
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int off = wv * DS;
@@ -1418,56 +1042,6 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
     for (int t = off / M; t < omax / M + 1; ++t) asm volatile("s_barrier" ::: "memory");
     return;
   }
-  // ---------------- solver wave (sweep n, band b): sor_sync_wave's schedule on the rings ----------------
-  const int n = wv / NB, b = wv % NB, off = n * DS + b * DBS;
-  const int rb = b * a.band_rows, nrows = NB > 1 ? (rb + a.band_rows <= a.h ? a.band_rows : a.h - rb) : a.h;
-  const bool first_row = lane == 0;
-  const bool act = lane < nrows;
-  const int r = act ? rb + lane : RP;                             // idle lanes park on the padding row with omega = 0
-  const float om_lane = act ? omega : 0.f;
-  const unsigned vD = DBASE + (unsigned)r * 8;
-  const unsigned vC = (unsigned)r * 16;                           // (the second load's rows 64.. follow the first's at +1024)
-  const unsigned vT = DBASE + (unsigned)(b > 0 ? rb - 1 : RP + 1) * 8;               // row above the band [band 0: a zero padding cell]
-  for (int t = 0; t < off / M; ++t) asm volatile("s_barrier" ::: "memory");
-  unsigned d0 = 0, d1 = DB, d2 = 2 * DB, c1o = CSLOT;              // D slots of diagonals s, s+1, s+2; C slot of diagonal s+1
-  float2 own = ld_f2(d0 + vD), nxr = ld_f2(d1 + vD), nxb = ld_f2(d1 + vD + 8);
-  float4 c0 = ld_f4(vC), c1 = ld_f4(vC + CB);
-  float2 tpl = make_float2(0.f, 0.f), prev = make_float2(0.f, 0.f);
-  float hl = 0.f;
-  auto step = [&](auto tail_tag, int u, int s) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    const float om = (!TAIL || s < S) ? om_lane : 0.f;
-    float dx = dpp_wave_shr1(prev.x), dy = dpp_wave_shr1(prev.y);
-    asm volatile("" : "+v"(dx), "+v"(dy));
-    const float2 top = first_row ? tpl : make_float2(dx, dy);
-    const float a11 = c0.x, a12 = c0.y, b1 = c0.z, b2 = c0.w, a22 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
-    float s1 = hr * nxr.x, s2 = hr * nxr.y;
-    s1 = s1 + vt * top.x;  s2 = s2 + vt * top.y;
-    s1 = s1 + vb * nxb.x;  s2 = s2 + vb * nxb.y;
-    if (u % M == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(s1), "+v"(s2) :: "memory");
-    const float2 nr = ld_f2(d2 + vD), nb = ld_f2(d2 + vD + 8);   // diagonal s+2: right / bottom of step s+1
-    const float2 tp = ld_f2(d0 + vT);                            // (diagonal s, row above the band): top of step s+1
-    const float4 n0 = ld_f4(c1o + vC), n1 = ld_f4(c1o + vC + CB); // system cells of diagonal s+1
-    s1 = s1 + b1;          s2 = s2 + b2;
-    const float B1 = hl * prev.x + s1, B2 = hl * prev.y + s2;
-    float2 res;
-    res.x = own.x + om * (a11 * B1 + a12 * B2 - own.x);
-    res.y = own.y + om * (a12 * B1 + a22 * B2 - own.y);
-    st_f2((!TAIL || s < S) ? d0 + vD : DUMP + (unsigned)r * 8, res);
-    prev = res; hl = hr; own = nxr; nxr = nr; nxb = nb; tpl = tp; c0 = n0; c1 = n1;
-    d0 = d1; d1 = d2; d2 += DB; if (d2 == DRING) d2 = 0;
-    c1o += CSLOT; if (c1o == CRING) c1o = 0;
-  };
-  int t0 = 0;
-  for (; t0 + U <= S; t0 += U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) step(std::false_type{}, u, t0 + u);
-  }
-  for (; t0 < S; t0 += UT) {
-#pragma unroll
-    for (int u = 0; u < UT; ++u) step(std::true_type{}, u, t0 + u);
-  }
-  for (int t = off / M; t < omax / M + 1; ++t) asm volatile("s_barrier" ::: "memory");
 }
 
 // The whole fixed-point loop of one level in ONE launch, one workgroup per pair (refine_variational.cpp:182-221):
@@ -1476,7 +1050,7 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
 // solver waves of the same workgroup.  Replaces 2*inner + 2 launches (and the LDS copy-in/out of D) per level.
 // CL (barrier-stepped waves only): the system cells C stay in LDS too -- the data phase writes them there and the solver
 // waves read them with ds_read_b128, so nothing but the level's input planes crosses the CU boundary inside the loop.
-template <int NOC, int K, int P, int U, int BANDED, bool CL, bool RES = false>
+template <int NOC, int P, int U, bool CL, bool RES = false>
 __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
                                                              float half_gamma_over3, float omega, float *__restrict__ flow, long flow_stride,
                                                              const float *__restrict__ I0, const float *__restrict__ I1, long img_stride, int tw, int pad)
@@ -1675,11 +1249,8 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
         }
       }
     }
-    sor_pipe_reset_progress();
     __syncthreads();                                             // also drains the C stores (vmcnt(0)) before the solver reads them
-    if constexpr (BANDED == 3) sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M, CL, true, true>(a, pair, omega, wv, lane, lc);   // host: single band only
-    else if constexpr (BANDED) { if (wv < a.nsweeps * a.nbands) sor_band_wave<P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
-    else { if (wv < a.nsweeps) sor_pipe_wave<K, P, U, FOTG_FUSED_NT>(a, pair, omega, wv, lane); }
+    sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M, CL, true, true>(a, pair, omega, wv, lane, lc);   // host: single band only
     __syncthreads();
   }
   float *f = flow + (size_t)pair * flow_stride;                  // refine_variational.cpp:208-221
@@ -1697,7 +1268,6 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
     for (int k = threadIdx.x; k < a.SC * a.RP; k += blockDim.x) { Cg[2 * k] = lc[k]; Cg[2 * k + 1] = lc[k + a.SC * a.RP + 1]; }
   }
 }
-#undef FOTG_CBAR
 
 // red-black ordering of the same block update (throughput mode; deviates from the reference by ~0.07 px)
 __global__ __launch_bounds__(1024) void vr_sor_redblack_kernel(VrArgs a, int iterations, float omega)
@@ -1713,8 +1283,14 @@ __global__ __launch_bounds__(1024) void vr_sor_redblack_kernel(VrArgs a, int ite
         if (((i + j) & 1) != col) continue;
         const float4 *c = C + a.cidx(i, j);
         const float hl = i > 0 ? C[a.cidx(i - 1, j) + 1].y : 0.f;
-        D[a.didx(i, j)] = sor_update(D[a.didx(i, j)], c[0], c[1], hl, i > 0 ? D[a.didx(i - 1, j)] : z, j > 0 ? D[a.didx(i, j - 1)] : z,
-                                     i < w - 1 ? D[a.didx(i + 1, j)] : z, j < h - 1 ? D[a.didx(i, j + 1)] : z, omega);
+        // neighbours outside the image: load the cell itself and zero the value (no select between addresses)
+        float2 nl = D[a.didx(i > 0 ? i - 1 : i, j)], nt = D[a.didx(i, j > 0 ? j - 1 : j)];
+        float2 nr = D[a.didx(i < w - 1 ? i + 1 : i, j)], nb = D[a.didx(i, j < h - 1 ? j + 1 : j)];
+        if (i == 0) nl = z;
+        if (j == 0) nt = z;
+        if (i == w - 1) nr = z;
+        if (j == h - 1) nb = z;
+        D[a.didx(i, j)] = sor_update(D[a.didx(i, j)], c[0], c[1], hl, nl, nt, nr, nb, omega);
       }
       __syncthreads();
     }

@@ -33,13 +33,20 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """the caller's current stream ON THE CONTEXT'S DEVICE (not on whatever device happens to be current)"""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _dev_f32(t, name):
-    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
-        raise FotgError("%s must be a contiguous float32 CUDA(HIP) tensor" % name)
+def _dev_f32(t, name, device=None, shape=None, dtype=torch.float32):
+    """The C-ABI takes raw pointers and trusts the sizes: everything a kernel will read or write is checked here --
+    dtype, contiguity, device and, where the caller knows it, the exact shape."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise FotgError("%s must be a contiguous %s CUDA(HIP) tensor" % (name, str(dtype).replace("torch.", "")))
+    if device is not None and t.device != device:
+        raise FotgError("%s lives on %s, the context on %s" % (name, t.device, device))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise FotgError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
     return t
 
 
@@ -98,33 +105,41 @@ class OFClass:
 
     def calc_batch(self, I0, I1, initflow=None, outflow=None):
         """n frame pairs at once: I0, I1 (n, h, w[, channels]); outflow (n, h_l, w_l, 2)"""
-        I0, I1 = _dev_f32(I0, "I0"), _dev_f32(I1, "I1")
+        I0, I1 = _dev_f32(I0, "I0", self.device), _dev_f32(I1, "I1", self.device)
         n = I0.shape[0]
         exp = (n, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
         if tuple(I0.shape) != exp and tuple(I0.shape) != exp + (1,):
             raise FotgError("frame shape %s does not match the configured %s" % (tuple(I0.shape), exp))
         if I1.shape != I0.shape:
             raise FotgError("I0 and I1 differ in shape")
-        if outflow is None:
-            outflow = self.new_outflow(n)
-        _dev_f32(outflow, "outflow")
-        if initflow is not None:
-            _dev_f32(initflow, "initflow")
-        check(lib().fotg_calc_batch(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(outflow), _stream()))
+        outflow, initflow = self._flow_args(n, outflow, initflow)
+        check(lib().fotg_calc_batch(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(outflow), _stream(self.device)))
         return outflow
+
+    def _flow_args(self, n, outflow, initflow):
+        """outflow (n, Hp >> finest, Wp >> finest, nch), allocated if None; initflow None or (n, Hp >> (coarsest+1),
+        Wp >> (coarsest+1), nch) -- the sizes fotg_calc_batch reads and writes (include/fotg.h)"""
+        if n < 1 or n > self.max_batch:
+            raise FotgError("batch of %d pairs, context created for max_batch = %d" % (n, self.max_batch))
+        w, h = self.out_size()
+        if outflow is None:
+            outflow = torch.empty((n, h, w, self.nch), dtype=torch.float32, device=self.device)
+        _dev_f32(outflow, "outflow", self.device, (n, h, w, self.nch))
+        if initflow is not None:
+            sc = self.op.coarsest_scale + 1
+            _dev_f32(initflow, "initflow", self.device, (n, self.height >> sc, self.width >> sc, self.nch))
+        return outflow, initflow
 
     def calc_batch_u8(self, I0, I1, initflow=None, outflow=None):
         """n pairs of 8-bit frames (n, h, w[, channels]) uint8 on the device; same result as calc_batch on float frames"""
-        for t in (I0, I1):
-            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
-                raise FotgError("frames must be contiguous uint8 CUDA(HIP) tensors")
+        for t, nm in ((I0, "I0"), (I1, "I1")):
+            _dev_f32(t, nm, self.device, dtype=torch.uint8)
         n = I0.shape[0]
         exp = (n, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
         if tuple(I0.shape) != exp or I1.shape != I0.shape:
             raise FotgError("frame shape %s does not match the configured %s" % (tuple(I0.shape), exp))
-        if outflow is None:
-            outflow = self.new_outflow(n)
-        check(lib().fotg_calc_batch_u8(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(_dev_f32(outflow, "outflow")), _stream()))
+        outflow, initflow = self._flow_args(n, outflow, initflow)
+        check(lib().fotg_calc_batch_u8(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(outflow), _stream(self.device)))
         return outflow
 
     def calc_sequence(self, frames, initflow=None, outflow=None):
@@ -132,30 +147,40 @@ class OFClass:
         frame's pyramid is built once.  Same bits as calc_batch(frames[:-1], frames[1:])"""
         if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.is_contiguous() and frames.dtype in (torch.float32, torch.uint8)):
             raise FotgError("frames must be a contiguous float32 or uint8 CUDA(HIP) tensor")
+        if frames.device != self.device:
+            raise FotgError("frames live on %s, the context on %s" % (frames.device, self.device))
         n = frames.shape[0] - 1
         exp = (n + 1, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
         if n < 1 or tuple(frames.shape) != exp:
             raise FotgError("frame shape %s does not match the configured %s" % (tuple(frames.shape), exp))
-        if outflow is None:
-            outflow = self.new_outflow(n)
+        outflow, initflow = self._flow_args(n, outflow, initflow)
         fn = lib().fotg_calc_sequence if frames.dtype == torch.float32 else lib().fotg_calc_sequence_u8
-        check(fn(self._h, n + 1, _ptr(frames), _ptr(initflow), _ptr(_dev_f32(outflow, "outflow")), _stream()))
+        check(fn(self._h, n + 1, _ptr(frames), _ptr(initflow), _ptr(outflow), _stream(self.device)))
         return outflow
 
     def upsample_crop(self, flow, out=None):
         """src/run_dense.cpp:293-303: x 2^finest, bilinear upsample, crop the padding -> (n, h_org, w_org, 2)"""
-        flow = _dev_f32(flow, "flow")
-        n = flow.shape[0]
+        n = flow.shape[0] if isinstance(flow, torch.Tensor) and flow.dim() == 4 else 0
+        if n < 1 or n > self.max_batch:
+            raise FotgError("flow must be (n, h_l, w_l, %d) with 1 <= n <= max_batch" % self.nch)
+        w, h = self.out_size()
+        flow = _dev_f32(flow, "flow", self.device, (n, h, w, self.nch))
         if out is None:
             out = torch.empty((n, self.height_org, self.width_org, self.nch), dtype=torch.float32, device=self.device)
-        check(lib().fotg_upsample_crop(self._h, n, _ptr(flow), _ptr(out), _stream()))
+        _dev_f32(out, "out", self.device, (n, self.height_org, self.width_org, self.nch))
+        check(lib().fotg_upsample_crop(self._h, n, _ptr(flow), _ptr(out), _stream(self.device)))
         return out
 
     # -- pyramid (src/oflow.cpp:182-207 ConstructImgPyramids) -----------------------------------------------
     def ConstructImgPyramids(self, I0, I1):
-        I0, I1 = _dev_f32(I0, "I0"), _dev_f32(I1, "I1")
-        check(lib().fotg_pyramid(self._h, I0.shape[0], _ptr(I0), 0, _stream()))
-        check(lib().fotg_pyramid(self._h, I1.shape[0], _ptr(I1), 1, _stream()))
+        n = I0.shape[0]
+        exp = (n, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
+        for t, nm in ((I0, "I0"), (I1, "I1")):
+            _dev_f32(t, nm, self.device)
+            if tuple(t.shape) != exp and tuple(t.shape) != exp + (1,):
+                raise FotgError("%s shape %s does not match the configured %s" % (nm, tuple(t.shape), exp))
+        check(lib().fotg_pyramid(self._h, n, _ptr(I0), 0, _stream(self.device)))
+        check(lib().fotg_pyramid(self._h, n, _ptr(I1), 1, _stream(self.device)))
 
     def level(self, which, sl, kind=0, n=1):
         """padded pyramid plane as a tensor VIEW-COPY (n, h+2ps, w+2ps, channels); kind 0 image, 1 dx, 2 dy"""
@@ -225,33 +250,40 @@ class PatGridClass:
         return (float(x * steps + offw), float(y * steps + offh))
 
     def InitializeGrid(self, _I0, _I0x, _I0y):
-        ts = [_dev_f32(t, "I0") for t in (_I0, _I0x, _I0y)]
-        self._n = ts[0].shape[0]
+        n = _I0.shape[0] if isinstance(_I0, torch.Tensor) and _I0.dim() == 4 else 0
+        if n < 1 or n > self._ofc.max_batch:
+            raise FotgError("level images must be (n, h+2ps, w+2ps, channels) with 1 <= n <= max_batch")
+        ts = [_dev_f32(t, nm, self._ofc.device, self._lvl_shape(n)) for t, nm in ((_I0, "I0"), (_I0x, "I0x"), (_I0y, "I0y"))]
+        self._n = n
         self._keep = ts
         stride = ts[0][0].numel()
-        check(lib().fotg_grid_init(self._ofc._h, self.lvl, self._n, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), stride, _stream()))
+        check(lib().fotg_grid_init(self._ofc._h, self.lvl, self._n, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), stride, _stream(self._ofc.device)))
+
+    def _lvl_shape(self, n):
+        return (n, self.i_params.height_pad, self.i_params.width_pad, self._ofc.op.channels)
 
     def SetTargetImage(self, _I1):
-        _dev_f32(_I1, "I1")
+        _dev_f32(_I1, "I1", self._ofc.device, self._lvl_shape(self._n))
         self._keep.append(_I1)
         check(lib().fotg_grid_set_target(self._ofc._h, self.lvl, _ptr(_I1), _I1[0].numel()))
 
     def InitializeFromCoarserOF(self, flow_prev):
-        _dev_f32(flow_prev, "flow_prev")
+        _dev_f32(flow_prev, "flow_prev", self._ofc.device, (self._n, self.i_params.height // 2, self.i_params.width // 2, self._ofc.nch))
         self._keep.append(flow_prev)
-        check(lib().fotg_grid_init_from_coarser(self._ofc._h, self.lvl, self._n, _ptr(flow_prev), _stream()))
+        check(lib().fotg_grid_init_from_coarser(self._ofc._h, self.lvl, self._n, _ptr(flow_prev), _stream(self._ofc.device)))
 
     def SetCamera(self, camlr):
         """depth mode: camparam::camlr of this grid (kroeger/oflow.h:28; 0 left: displacement <= 0, 1 right: >= 0)"""
         check(lib().fotg_grid_set_camera(self._ofc._h, self.lvl, int(camlr)))
 
     def Optimize(self):
-        check(lib().fotg_grid_optimize(self._ofc._h, self.lvl, self._n, _stream()))
+        check(lib().fotg_grid_optimize(self._ofc._h, self.lvl, self._n, _stream(self._ofc.device)))
 
     def AggregateFlowDense(self, flowout=None):
         if flowout is None:
             flowout = torch.empty((self._n, self.i_params.height, self.i_params.width, self._ofc.nch), dtype=torch.float32, device=self._ofc.device)
-        check(lib().fotg_grid_aggregate(self._ofc._h, self.lvl, self._n, _ptr(_dev_f32(flowout, "flowout")), _stream()))
+        _dev_f32(flowout, "flowout", self._ofc.device, (self._n, self.i_params.height, self.i_params.width, self._ofc.nch))
+        check(lib().fotg_grid_aggregate(self._ofc._h, self.lvl, self._n, _ptr(flowout), _stream(self._ofc.device)))
         return flowout
 
     def printTimings(self):
@@ -281,7 +313,12 @@ class VarRefClass:
     _I0/_I1: padded level images (n, h+2ps, w+2ps, channels) on the device; flowout (n, h, w, 2) on the device."""
 
     def __init__(self, ofc: OFClass, _I0, _I1, _i_params: img_params, _op: opt_params, flowout):
-        _dev_f32(_I0, "I0"); _dev_f32(_I1, "I1"); _dev_f32(flowout, "flowout")
-        check(lib().fotg_varref(ofc._h, _i_params.curr_lvl, flowout.shape[0], _ptr(_I0), _ptr(_I1), _I0[0].numel(),
-                                _ptr(flowout), _stream()))
+        n = flowout.shape[0] if isinstance(flowout, torch.Tensor) and flowout.dim() == 4 else 0
+        if n < 1 or n > ofc.max_batch:
+            raise FotgError("flowout must be (n, h, w, %d) with 1 <= n <= max_batch" % ofc.nch)
+        lshape = (n, _i_params.height_pad, _i_params.width_pad, ofc.op.channels)
+        _dev_f32(_I0, "I0", ofc.device, lshape); _dev_f32(_I1, "I1", ofc.device, lshape)
+        _dev_f32(flowout, "flowout", ofc.device, (n, _i_params.height, _i_params.width, ofc.nch))
+        check(lib().fotg_varref(ofc._h, _i_params.curr_lvl, n, _ptr(_I0), _ptr(_I1), _I0[0].numel(),
+                                _ptr(flowout), _stream(ofc.device)))
         self.flowout = flowout

@@ -51,10 +51,25 @@ def build(force=False):
     return so
 
 
+_SO_NAME = "libdis_oracle.so"
+
+
+def use_native():
+    """bench.py's cpu_baseline leg only: rebuild the port with -march=native ON the box being timed (`make native`) and switch
+    to it.  Same source, same -ffp-contract=off: same bits, only the instruction selection differs.  Returns the flags line."""
+    global _LIB, _SO_NAME
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return "gcc -O3 -msse4 -ffp-contract=off (native rebuild failed)"
+    _SO_NAME, _LIB = "libdis_oracle_native.so", None
+    return "gcc -O3 -msse4 -march=native -ffp-contract=off"
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libdis_oracle.so")
+        so = os.path.join(_HERE, _SO_NAME)
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)

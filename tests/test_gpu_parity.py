@@ -189,14 +189,13 @@ def test_end_to_end_parity(case, op_point, sor_mode, alley):
     assert np.array_equal(ofc.calc(dev(f0), dev(f1)).cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("path,bands", [("1", "0"), ("0", "0"), ("2", "0"), ("0", "1"), ("2", "1"), ("2", "2"), ("2", "3")])
-def test_solver_fallback_paths(path, bands, alley, monkeypatch):
+@pytest.mark.parametrize("path", ["1", "2"])
+def test_solver_fallback_paths(path, alley, monkeypatch):
     """the automatic dispatch picks the fused / sweep-pipelined LDS solvers at these sizes; force the single-wave
-    global-memory solver (path 1), the unfused LDS solver (path 2) and every solver-wave flavour (bands 0: progress
-    counters, 1: two lanes per row, 2: row bands with counters, 3: barrier-stepped = the default) and require the same bits"""
+    global-memory solver (FOTG_VR_PATH=1) and the unfused sequence set-up -> data -> LDS solver (2) and require the same
+    bits.  The switches are read when the context is created."""
     F, OFClass, _, O = _mods()
     monkeypatch.setenv("FOTG_VR_PATH", path)
-    monkeypatch.setenv("FOTG_VR_BANDS", bands)
     for case, op_point in (("alley", 2), ("synth_rgb", 2), ("synth_odd", 3)):
         f0, f1, noc = frames(case, alley)
         h, w = f0.shape[:2]
@@ -207,11 +206,34 @@ def test_solver_fallback_paths(path, bands, alley, monkeypatch):
         assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (path, case)
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_switches_are_read_at_creation_and_debug_switches_are_compiled_out(alley, monkeypatch):
+    """(a) FOTG_DEBUG_NOSOR / FOTG_DEBUG_SWEEPS (timing experiments that return wrong flow) do nothing in the shipped
+    library; (b) a switch set AFTER the context exists is not seen by it (nothing under fotg_calc_batch reads the
+    environment)"""
+    F, OFClass, _, O = _mods()
+    f0, f1, noc = frames("alley", alley)
+    op = F.operating_point(2, 1024, 1)
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    monkeypatch.setenv("FOTG_DEBUG_NOSOR", "1")
+    monkeypatch.setenv("FOTG_DEBUG_SWEEPS", "1")
+    ofc = OFClass(op, F.img_params(width=1024, height=436, padding=8))
+    assert np.array_equal(ofc.calc(dev(f0), dev(f1)).cpu().numpy(), ref)
+    monkeypatch.delenv("FOTG_DEBUG_NOSOR"); monkeypatch.delenv("FOTG_DEBUG_SWEEPS")
+    before = F.lib().fotg_debug_counter(b"sor_stream")
+    f0, f1 = synth_pair(1080, 1920, seed=9)
+    op = F.operating_point(2, 1920, 1)
+    ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=8))
+    monkeypatch.setenv("FOTG_VR_STREAM", "0")             # too late for this context
+    ofc.calc(dev(f0), dev(f1))
+    assert F.lib().fotg_debug_counter(b"sor_stream") > before
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
 def test_streaming_solver_kernel(mode, monkeypatch):
     """levels of 65..96 rows are solved by vr_sor_stream_kernel: (du,dv) and the system travel through LDS rings filled by
-    direct-to-LDS loads, results are written back by a writer wave while the solve runs.  FOTG_VR_STREAM: 2 (default) two
-    rows per lane + packed f32, 1 one row per lane in two row bands, 0 the resident-D kernel -- same bits.  Sizes: 1080p
+    direct-to-LDS loads, results are written back by a writer wave while the solve runs (two rows per lane, packed f32).
+    FOTG_VR_STREAM=0 at context creation: the resident-D kernel instead -- same bits.  Sizes: 1080p
     (68-row level), a narrower 68-row level, a 75-row level (second LDS geometry) and an odd row count (67)"""
     F, OFClass, _, O = _mods()
     monkeypatch.setenv("FOTG_VR_STREAM", mode)
@@ -227,7 +249,7 @@ def test_streaming_solver_kernel(mode, monkeypatch):
         a, b = O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f)
         assert np.array_equal(out[0], O.flow(a, b, p, 0)) and np.array_equal(out[1], O.flow(b, a, p, 0)), (w, h)
         rows = a.shape[0] >> 4
-        expect += 5 if (mode == "2" and 65 <= rows <= 96) or (mode == "1" and 65 <= rows <= 69) else 0     # 5 inner iterations at level 4
+        expect += 5 if (mode == "1" and 65 <= rows <= 96) else 0     # 5 inner iterations at level 4
         ofc.close()
     assert F.lib().fotg_debug_counter(b"sor_stream") == before + expect
 
@@ -621,6 +643,41 @@ def test_batch_1080p_parity_and_independence():
     # recovered flow is sane: median close to the synthetic ground truth
     _, _, gt = synth_pair(1080, 1920, seed=1234, truth=True)
     full = ofc.upsample_crop(torch.from_numpy(out[:1]).cuda())[0].cpu().numpy()
+    assert np.median(epe(full, gt)) < 0.5
+
+
+def test_single_1080p_pair_no_refinement():
+    """BASELINE configs[1] exactly: ONE 1920x1080 pair, patch_size 8, stride 4 (overlap 0.4), 3 pyramid levels (6-5-4), no
+    variational refinement -- finest-scale flow, full-resolution flow and the patch state of every scale against the oracle"""
+    F, OFClass, _, O = _mods()
+    f0, f1 = synth_pair(1080, 1920, seed=4321)
+    op = F.operating_point(2, 1920, 1)
+    op.use_var_ref = False
+    assert (op.patch_size, op.steps, op.coarsest_scale, op.finest_scale, op.n_scales) == (8, 4, 6, 4, 3)
+    ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=8), max_batch=1)
+    got = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+    p = oracle_params(O, op)
+    assert p.usetvref == 0
+    P0 = O.Pyramid(O.pad_frame(f0, p.sc_f), p.sc_f, p.ps); P1 = O.Pyramid(O.pad_frame(f1, p.sc_f), p.sc_f, p.ps)
+    ref = O.flow_pyr(P0, P1, p)
+    assert got.shape == (68, 120, 2) and np.array_equal(got, ref)
+    prev = None
+    for sl in (6, 5, 4):                                           # patch displacements and weights of every scale
+        lw, lh = P0.level_wh(sl)
+        og = O.Grid(lw, lh, sl, p)
+        og.init(P0.im[sl], P0.dx[sl], P0.dy[sl])
+        if prev is not None:
+            og.init_from_coarser(prev)
+        og.optimize(P1.im[sl])
+        st = ofc.grid[sl - 4].read_state(0)
+        assert og.nop == {6: 40, 5: 135, 4: 510}[sl]
+        assert np.array_equal(st["p_iter"], og.p_iter), sl
+        assert np.array_equal(st["pweight"], og.pweight), sl
+        prev = og.aggregate()
+    assert np.array_equal(prev, ref)
+    full = ofc.upsample_crop(torch.from_numpy(got[None]).cuda())[0].cpu().numpy()
+    assert np.array_equal(full, O.upsample_crop(ref, p.sc_l, 0, 8, 1920, 1080))
+    _, _, gt = synth_pair(1080, 1920, seed=4321, truth=True)
     assert np.median(epe(full, gt)) < 0.5
 
 

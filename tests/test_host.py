@@ -135,3 +135,32 @@ def test_cpp_shim_example_builds(tmp_path):
     F.lib()
     exe = _build_example(tmp_path)
     assert os.path.exists(exe)
+
+
+def test_no_kernel_uses_scratch_memory():
+    """the build keeps the compiler's per-kernel resource table (flowonthego_amd/libfotg.resusage.txt, written by the
+    Makefile with -Rpass-analysis=kernel-resource-usage): no kernel of the product may have a private-memory segment --
+    spills and dynamically indexed private arrays are HBM traffic the algorithm does not have (round 1: the four-patch LK
+    kernel wrote 13x its algorithmic bytes this way)"""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "flowonthego_amd", "csrc")], stdout=subprocess.DEVNULL)
+    txt = open(os.path.join(ROOT, "flowonthego_amd", "libfotg.resusage.txt")).read()
+    names = re.findall(r"Function Name: (\S+)", txt)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", txt)]
+    assert len(names) == len(scratch) and len(names) > 100
+    bad = [(n, b) for n, b in zip(names, scratch) if b != 0]
+    assert not bad, bad
+    for must in ("lk_kernel", "vr_sor_wide_kernel", "pyr_base_kernel", "vr_sor_stream_kernel"):
+        assert any(must in n for n in names), must
+
+
+def test_launch_path_reads_no_environment():
+    """every FOTG_* switch is read once at fotg_create; the only getenv in the library sits in the helper fotg_create uses,
+    and the switches that change results (timing experiments) exist only in -DFOTG_DEBUG builds"""
+    src = open(os.path.join(ROOT, "flowonthego_amd", "csrc", "fotg_capi.hip")).read()
+    body = re.sub(r"#ifdef FOTG_DEBUG.*?#endif", "", src, flags=re.S)
+    assert body.count("getenv(") == 1 and "static int env_int" in body
+    for hdr in ("varref.hip.h", "lk.hip.h", "pyramid.hip.h", "densify.hip.h", "varref_depth.hip.h", "common.h"):
+        assert "getenv" not in open(os.path.join(ROOT, "flowonthego_amd", "csrc", hdr)).read()
+    mk = [l for l in open(os.path.join(ROOT, "flowonthego_amd", "csrc", "Makefile")).read().splitlines() if not l.lstrip().startswith("#")]
+    assert not any("FOTG_DEBUG" in l for l in mk)
