@@ -12,6 +12,7 @@
 #include "lk.hip.h"
 #include "densify.hip.h"
 #include "varref.hip.h"
+#include "varref_stage.hip.h"
 #include "varref_depth.hip.h"
 #include "upsample.hip.h"
 
@@ -61,6 +62,8 @@ struct FotgTune {
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
   int vr_wide;      // FOTG_VR_WIDE: 0 = single-wave kernel instead of the wide one
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
+  int vr_stage;     // FOTG_VR_STAGE: 0 = no stage-pipelined levels (varref_stage.hip.h)
+  int vr_stage_mins;// FOTG_VR_STAGE_MINS: fewest anti-diagonals of a level that takes the stage pipeline
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
@@ -88,6 +91,15 @@ struct fotg_ctx {
   float4 *vrC[FOTG_MAXLEV];          // skewed system per level (cells outside the image stay zero forever)
   float2 *vrD[FOTG_MAXLEV];          // skewed (du,dv) per level
   VrArgs vra[FOTG_MAXLEV];
+  // stage-pipelined refinement (varref_stage.hip.h): skewed constant planes, hand-over buffers, ticket / progress words
+  int stage_geo[FOTG_MAXLEV];        // 0: level not eligible; 1, 2, 3: ring geometry (RD, RCW) = (48, 38), (80, 70), (112, 98)
+  int stage_used[FOTG_MAXLEV];       // the last fotg_varref of the level took the pipeline (fotg_varref_plane de-skews)
+  VrArgs vraq[FOTG_MAXLEV];          // the level's arguments with the planes in the skewed workspace
+  float *vrQ;
+  float2 *vrDS;
+  long ds_pair_stride, ds_stage_stride[FOTG_MAXLEV];
+  int *vrSync;
+  unsigned long long *stamps;        // -DFOTG_STAGE_STAMPS builds only
   GridState gs[FOTG_MAXLEV];
   // sub-batch pipelining (fotg_calc_batch): the solver's dependent chain has a latency that does not depend on the
   // batch size while every other stage is throughput bound, so a batch is cut into sub-batches on internal streams
@@ -187,7 +199,7 @@ void fotg_destroy(fotg_ctx *c)
     (void)hipFree(c->trace_dev[l]);
     (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]);
   }
-  (void)hipFree(c->vr);
+  (void)hipFree(c->vr); (void)hipFree(c->vrQ); (void)hipFree(c->vrDS); (void)hipFree(c->vrSync);
   for (int i = 0; i < 8; ++i) {
     if (c->sub_stream[i]) (void)hipStreamDestroy(c->sub_stream[i]);
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -213,6 +225,14 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   memset((void *)c, 0, sizeof(*c));
   c->p = *p; c->w_org = w_org; c->h_org = h_org; c->device = device; c->max_batch = max_batch;
   c->noc = p->noc; c->ps = p->ps; c->nch = p->depth ? 1 : 2;
+  c->tune.lk_np = env_int("FOTG_LK_NP", 0);
+  c->tune.vr_path = env_int("FOTG_VR_PATH", 0);
+  c->tune.vr_stream = env_int("FOTG_VR_STREAM", 1);
+  c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
+  c->tune.vr_wide = env_int("FOTG_VR_WIDE", 1);
+  c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
+  c->tune.vr_stage = env_int("FOTG_VR_STAGE", 1);
+  c->tune.vr_stage_mins = env_int("FOTG_VR_STAGE_MINS", 80);
   fotg_padded_size(w_org, h_org, p->sc_f, &c->Wp, &c->Hp, &c->padw, &c->padh);
   c->base_lv = p->sc_l < 4 ? p->sc_l : 4;
   const size_t B = (size_t)max_batch;
@@ -271,15 +291,46 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       if (hipMemset(c->vrC[l], 0, cbytes) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       a.C = c->vrC[l]; a.D = c->vrD[l];
     }
+    // Levels that take the stage pipeline: lexicographic order, 1..3 sweeps (one solver wave each), 2..16 inner iterations
+    // (one workgroup each), enough anti-diagonals to amortise the pipeline fill, a ring geometry that holds the rows.
+    if (!p->depth && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->tune.vr_stage && c->tune.vr_path == 0 && p->tv_solverit >= 1 && p->tv_solverit <= 3) {
+      long qmax = 0, ds_total = 0;
+      for (int l = p->sc_l; l <= p->sc_f; ++l) {
+        const VrArgs &a = c->vra[l];
+        const int inner = p->tv_innerit * (l + 1);
+        if (inner < 2 || inner > FOTG_STAGE_MAXINNER || a.S < c->tune.vr_stage_mins || a.K > 2) continue;
+        const StageGeom q = stage_geom(a.w, a.h, p->tv_solverit);
+        if (q.NBW > FOTG_STAGE_NDW) continue;
+        int geo = 0, rd = 0;
+        if (a.h + 2 <= 48 && q.HR <= 38) { geo = 1; rd = 48; }
+        else if (a.h + 2 <= 80 && q.HR <= 70) { geo = 2; rd = 80; }
+        else if (a.h + 2 <= 112 && q.HR <= 98) { geo = 3; rd = 112; }
+        if (!geo) continue;
+        c->stage_geo[l] = geo;
+        const long pl = (long)(a.S + 1) * a.RPD;
+        const long need = pl * (P_NSINGLE + C_NCOLOR * c->noc);
+        if (need > qmax) qmax = need;
+        c->ds_stage_stride[l] = (long)(a.S + FOTG_STAGE_M + 1) * rd;
+        const long t = c->ds_stage_stride[l] * (inner - 1);
+        if (t > ds_total) ds_total = t;
+      }
+      if (qmax) {
+        ALLOC(c->vrQ, B * qmax * sizeof(float));
+        ALLOC(c->vrDS, B * ds_total * sizeof(float2) + 4096);
+        ALLOC(c->vrSync, stage_sync_words((int)B) * sizeof(int));
+        if (hipMemset(c->vrSync, 0, stage_sync_words((int)B) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+        c->ds_pair_stride = ds_total;
+        for (int l = p->sc_l; l <= p->sc_f; ++l) {
+          if (!c->stage_geo[l]) continue;
+          VrArgs &aq = c->vraq[l];
+          aq = c->vra[l];
+          aq.skew = 1; aq.base = c->vrQ; aq.pair_stride = qmax; aq.pl = (long)(aq.S + 1) * aq.RPD;
+        }
+      }
+    }
   }
 #undef ALLOC
   {
-    c->tune.lk_np = env_int("FOTG_LK_NP", 0);
-    c->tune.vr_path = env_int("FOTG_VR_PATH", 0);
-    c->tune.vr_stream = env_int("FOTG_VR_STREAM", 1);
-    c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
-    c->tune.vr_wide = env_int("FOTG_VR_WIDE", 1);
-    c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
     c->nsub = env_int("FOTG_SUBBATCH", 1);     // measured on MI355X, 64 x 1080p: no gain (the host launch path is the wall), so off by default
     if (c->nsub < 1) c->nsub = 1;
     if (c->nsub > 8) c->nsub = 8;
@@ -641,6 +692,7 @@ static bool launch_sor_pipe(int n, float omega, hipStream_t s, const VrArgs &b)
 }
 
 static long g_wide_launches = 0;        // fotg_debug_counter("sor_wide")
+static long g_stage_launches = 0;       // fotg_debug_counter("vr_stage")
 static long g_stream_launches = 0;      // fotg_debug_counter("sor_stream"): tests assert the kernel really ran
 // streaming solver (vr_sor_stream_kernel): diagonals travel through LDS rings, two rows per lane.
 template <int RD, int RCW>
@@ -796,6 +848,40 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     LAUNCHCHK();
     return FOTG_OK;
   }
+  if (c->stage_geo[l] && c->tune.vr_path == 0) {
+    // stage pipeline: set-up launch into the skewed planes (it also zeroes the ticket / progress words), then ONE launch of
+    // inner x n workgroups, workgroup = one inner iteration of one pair
+    c->stage_used[l] = 1;
+    VrArgs aq = c->vraq[l];
+    aq.taps = c->taps ? 1 : 0;
+    aq.nsweeps = c->p.tv_solverit;
+    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(aq, I0, I1, img_stride, g.tw, c->ps, flow, fs, 2, c->vrSync, stage_sync_words(n));
+    LAUNCHCHK();
+    StageArgs sa;
+    sa.inner = inner; sa.npairs = n; sa.qa = quarter_alpha; sa.hd = half_delta_over3; sa.hg = half_gamma_over3; sa.omega = c->p.tv_sor;
+    sa.flow = flow; sa.flow_stride = fs; sa.DS = c->vrDS; sa.ds_pair_stride = c->ds_pair_stride; sa.ds_stage_stride = c->ds_stage_stride[l];
+    sa.sync = c->vrSync;
+    sa.stamps = nullptr;
+#ifdef FOTG_STAGE_STAMPS
+    if (!c->stamps) { if (hipMalloc((void **)&c->stamps, (size_t)FOTG_STAGE_MAXINNER * c->max_batch * 16 * 8 * 8) != hipSuccess) return FOTG_ERR_HIP; }
+    (void)hipMemsetAsync(c->stamps, 0, (size_t)FOTG_STAGE_MAXINNER * c->max_batch * 16 * 8 * 8, s);
+    sa.stamps = c->stamps;
+#endif
+    const StageGeom q = stage_geom(g.w, g.h, c->p.tv_solverit);
+    static int lds_set[3][32];
+#define STAGE(GEO, RD_, RCW_) \
+    { const int lds = stage_lds_bytes<RD_, RCW_>(q); \
+      if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_stage_kernel<NOC, RD_, RCW_>), lds, lds_set[GEO - 1])) return FOTG_ERR_HIP; \
+      vr_stage_kernel<NOC, RD_, RCW_><<<inner * n, 1024, lds, s>>>(aq, sa); }
+    if (c->stage_geo[l] == 1) STAGE(1, 48, 38)
+    else if (c->stage_geo[l] == 2) STAGE(2, 80, 70)
+    else STAGE(3, 112, 98)
+#undef STAGE
+    ++g_stage_launches;
+    LAUNCHCHK();
+    return FOTG_OK;
+  }
+  c->stage_used[l] = 0;
   if (c->tune.vr_setup) {
     // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
     // (tune.vr_setup = 0: memset + the three plane-at-a-time launches; tests)
@@ -949,6 +1035,24 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
         HIPCHK(hipMemcpy(host_out, de_plane(a, pair, k), pl * 4, hipMemcpyDeviceToHost));
         return FOTG_OK;
       }
+  }
+  if (c->stage_used[l]) {
+    // the level took the stage pipeline: its planes live in the skewed workspace (pixel (i,j) at [(i+j) * RPD + j]); de-skew on the host
+    const VrArgs &aq = c->vraq[l];
+    int first = -1, cnt = 1;
+    for (int i = 0; i < P_NSINGLE; ++i) if (!strcmp(name, singles[i])) first = i;
+    for (int i = 0; i < C_NCOLOR; ++i) if (!strcmp(name, colors[i])) { first = P_NSINGLE + i * c->noc; cnt = c->noc; }
+    if (first >= 0) {
+      float *tmp = (float *)malloc((size_t)aq.pl * cnt * sizeof(float));
+      if (!tmp) return FOTG_ERR_ARG;
+      hipError_t e = hipMemcpy(tmp, aq.base + (size_t)pair * aq.pair_stride + (size_t)first * aq.pl, (size_t)aq.pl * cnt * sizeof(float), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { free(tmp); g_last_hip = (int)e; return FOTG_ERR_HIP; }
+      memset(host_out, 0, pl * cnt * 4);
+      for (int ch = 0; ch < cnt; ++ch)
+        for (int j = 0; j < g.h; ++j) for (int i = 0; i < g.w; ++i) host_out[(size_t)ch * pl + (size_t)j * g.st + i] = tmp[(size_t)ch * aq.pl + aq.pix(i, j)];
+      free(tmp);
+      return FOTG_OK;
+    }
   }
   for (int i = 0; i < P_NSINGLE; ++i)
     if (!strcmp(name, singles[i])) {
@@ -1189,6 +1293,22 @@ long fotg_debug_counter(const char *name)
 {
   if (name && !strcmp(name, "sor_stream")) return g_stream_launches;
   if (name && !strcmp(name, "sor_wide")) return g_wide_launches;
+  if (name && !strcmp(name, "vr_stage")) return g_stage_launches;
+  return -1;
+}
+
+long fotg_ctx_counter(fotg_ctx *c, const char *name)
+{
+  if (!c || !name) return -1;
+  if (!strcmp(name, "stage_stamps_ptr")) return (long)(size_t)c->stamps;
+  if (!strcmp(name, "vr_stage_timeouts")) {
+    // bounded waits of the stage pipeline that gave up since the context was created (0 unless something is broken)
+    if (!c->vrSync) return 0;
+    DevGuard dg(c->device);
+    int v = 0;
+    if (!dg.ok || hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, c->vrSync + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+  }
   return -1;
 }
 

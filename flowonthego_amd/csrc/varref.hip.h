@@ -41,6 +41,9 @@ struct VrArgs {
   long c_pair_stride;    // in float4
   long d_pair_stride;    // in float2
   int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows, band_mode, taps;
+  int skew;              // 1: the planes are stored skewed like D (pixel (i,j) at [(i+j) * RPD + j], pl = (S+1) * RPD floats): the
+                         // stage-pipelined refinement (varref_stage.hip.h) reads them along anti-diagonals, coalesced
+  __host__ __device__ int pix(int i, int j) const { return skew ? (i + j) * RPD + j : j * st + i; }
   __host__ __device__ float4 *Cp(int pair) const { return C + (size_t)pair * c_pair_stride; }
   __host__ __device__ float2 *Dp(int pair) const { return D + (size_t)pair * d_pair_stride; }
   __host__ __device__ size_t cidx(int i, int j) const { return ((size_t)(i + j) * RP + j) * 2; }
@@ -107,7 +110,7 @@ __device__ __forceinline__ PrepVal<NOC> prep_values(const VrArgs &a, int pair, i
 template <int NOC>
 __device__ __forceinline__ void prep_store(const VrArgs &a, int pair, int i, int j, const PrepVal<NOC> &v)
 {
-  const int o = j * a.st + i;
+  const int o = a.pix(i, j);
   a.single(pair, P_WX)[o] = v.wx;
   a.single(pair, P_WY)[o] = v.wy;
   a.single(pair, P_MASK)[o] = v.mask;
@@ -189,17 +192,23 @@ __global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
 template <int NOC, int NCH = 2>
 __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__restrict__ I0, const float *__restrict__ I1,
                                                        long img_stride, int tw, int pad,
-                                                       const float *__restrict__ flow, long flow_stride, int zero_d = 0)
+                                                       const float *__restrict__ flow, long flow_stride, int zero_d = 0,
+                                                       int *__restrict__ zero_words = nullptr, long zero_n = 0)
 {
   constexpr int TW_ = 32, TH_ = 8, XW = TW_ + 8, XH = TH_ + 8, YW = TW_ + 4, YH = TH_ + 4;
   __shared__ float Xa[NOC][XH * XW], Xz[NOC][XH * XW], Yx[NOC][YH * YW], Yy[NOC][YH * YW];
   const WgId wg = xcd_local_wg();
   const int pair = wg.y, w = a.w, h = a.h;
   const int tiles_x = (w + TW_ - 1) / TW_;
-  if (zero_d) {
+  if (zero_d == 1) {
     // image_erase(du), image_erase(dv) (refine_variational.cpp:185-186): the pair's tiles share the zeroing of its skewed D
     float2 *D = a.Dp(pair);
     for (long k = (long)wg.x * 256 + threadIdx.x; k < a.d_pair_stride; k += (long)gridDim.x * 256) D[k] = make_float2(0.f, 0.f);
+  }
+  if (zero_d == 2 && zero_words) {
+    // stage-pipelined refinement: the ticket counter and the per-(pair, stage) progress words of the launch that follows
+    for (long k = ((long)wg.y * gridDim.x + wg.x) * 256 + threadIdx.x; k < zero_n; k += (long)gridDim.x * gridDim.y * 256)
+      if (k != 1) zero_words[k] = 0;                              // word 1 counts timed-out waits over the life of the context
   }
   const int tx0 = (wg.x % tiles_x) * TW_, ty0 = (wg.x / tiles_x) * TH_;
   // stage A: warp + mask + average / difference at the clamped coordinate of every tile+4 position
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
       const float ixz = conv_h5(zrow, gx, w), iyz = conv_v5(zcol, gy, h, XW);
       Yx[c][e] = ix; Yy[c][e] = iy;
       if (own) {
-        const int o = cy * a.st + cx;
+        const int o = a.pix(cx, cy);
         a.color(pair, C_IX, c)[o] = ix; a.color(pair, C_IY, c)[o] = iy; a.color(pair, C_IXZ, c)[o] = ixz; a.color(pair, C_IYZ, c)[o] = iyz;
       }
     }
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
   // stage C: second derivatives of the tile's own pixels (:95-99)
   const int i = tx0 + (threadIdx.x % TW_), j = ty0 + (threadIdx.x / TW_);
   if (i < w && j < h) {
-    const int o = j * a.st + i;
+    const int o = a.pix(i, j);
 #pragma unroll
     for (int c = 0; c < NOC; ++c) {
       const float *xrow = Yx[c] + (j - ty0 + 2) * YW - tx0 + 2, *xcol = Yx[c] + (2 - ty0) * YW + i - tx0 + 2, *ycol = Yy[c] + (2 - ty0) * YW + i - tx0 + 2;

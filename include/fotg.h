@@ -152,8 +152,11 @@ int fotg_varref(fotg_ctx *ctx, int level, int n, const float *I0, const float *I
  * depth mode: "wx","mask","du","uu","s","a11","b1","sh","sv" and the image planes (a11/b1: the scalar system of compute_data_DE) */
 int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, float *host_out);
 
-/* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_wide"); -1 for unknown names */
+/* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_wide", "vr_stage"); -1 for unknown names */
 long fotg_debug_counter(const char *name);
+/* test tap, per context (synchronises the device): "vr_stage_timeouts" = bounded waits of the stage-pipelined refinement that
+ * gave up since the context was created -- 0 unless something is broken; -1 for unknown names */
+long fotg_ctx_counter(fotg_ctx *ctx, const char *name);
 const char *fotg_strerror(int status);
 int fotg_last_hip_error(void);
 const char *fotg_version(void);

@@ -223,10 +223,56 @@ def test_switches_are_read_at_creation_and_debug_switches_are_compiled_out(alley
     before = F.lib().fotg_debug_counter(b"sor_stream")
     f0, f1 = synth_pair(1080, 1920, seed=9)
     op = F.operating_point(2, 1920, 1)
+    monkeypatch.setenv("FOTG_VR_STAGE", "0")
     ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=8))
     monkeypatch.setenv("FOTG_VR_STREAM", "0")             # too late for this context
     ofc.calc(dev(f0), dev(f1))
     assert F.lib().fotg_debug_counter(b"sor_stream") > before
+
+
+@pytest.mark.parametrize("mins", ["24", "80"])
+def test_stage_pipeline(mins, alley, monkeypatch):
+    """the stage-pipelined refinement (varref_stage.hip.h: one workgroup per inner iteration, (du,dv) handed from stage to
+    stage through global memory) against the oracle: the three ring geometries (levels of <= 36, <= 69, <= 97 rows), odd row
+    counts, RGB, batches larger than the chip holds at once (tickets), 1 and 2 sweeps; FOTG_VR_STAGE_MINS=24 also sends
+    the small coarse levels through it.  No wait may have timed out."""
+    F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_STAGE_MINS", mins)
+    L = F.lib()
+    before = L.fotg_debug_counter(b"vr_stage")
+    cases = [((1024, 436), 2, 1, 3, 1), ((1920, 1080), 2, 1, 3, 2), ((1600, 1200), 2, 1, 3, 1), ((1904, 1064), 2, 1, 3, 1),
+             ((328, 200), 2, 3, 3, 2), ((500, 270), 2, 1, 2, 1), ((500, 270), 2, 1, 1, 1), ((720, 1000), 2, 1, 3, 1)]
+    for (w, h), op_point, noc, sweeps, n in cases:
+        pairs = [synth_pair(h, w, seed=31 + k, noc=noc) for k in range(n)]
+        op = F.operating_point(op_point, 1920 if (w, h) in ((1600, 1200), (1904, 1064)) else w, noc)
+        op.var_ref_iter = sweeps
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=n)
+        out = ofc.calc_batch(dev(np.stack([p[0] for p in pairs])), dev(np.stack([p[1] for p in pairs]))).cpu().numpy()
+        p = oracle_params(O, op)
+        for k in range(n):
+            ref = O.flow(O.pad_frame(pairs[k][0], p.sc_f), O.pad_frame(pairs[k][1], p.sc_f), p, 0)
+            assert np.array_equal(out[k], ref), ((w, h), noc, sweeps, k, float(np.abs(out[k] - ref).max()))
+        assert L.fotg_ctx_counter(ofc._h, b"vr_stage_timeouts") == 0
+        ofc.close()
+    assert L.fotg_debug_counter(b"vr_stage") > before
+
+
+def test_stage_pipeline_more_workgroups_than_cus():
+    """80 pairs x 5 stages = 400 workgroups of one per CU on 256 CUs: the late tickets start when the early ones exit; every pair
+    still equals its single-pair result (and pair 0 the oracle)"""
+    F, OFClass, _, O = _mods()
+    n = 80
+    f0, f1 = synth_pair(1080, 1920, seed=77)
+    I0 = dev(f0)[None].repeat(n, 1, 1).contiguous(); I1 = dev(f1)[None].repeat(n, 1, 1).contiguous()
+    I0[1::2] = dev(f1); I1[1::2] = dev(f0)
+    op = F.operating_point(2, 1920, 1)
+    ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=8), max_batch=n)
+    out = ofc.calc_batch(I0, I1)
+    assert torch.equal(out[0::2], out[0:1].expand(n // 2, -1, -1, -1)) and torch.equal(out[1::2], out[1:2].expand(n // 2, -1, -1, -1))
+    p = oracle_params(O, op)
+    assert np.array_equal(out[0].cpu().numpy(), O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0))
+    assert np.array_equal(out[1].cpu().numpy(), O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0))
+    assert F.lib().fotg_ctx_counter(ofc._h, b"vr_stage_timeouts") == 0
 
 
 @pytest.mark.parametrize("mode", ["0", "1"])
@@ -237,6 +283,7 @@ def test_streaming_solver_kernel(mode, monkeypatch):
     (68-row level), a narrower 68-row level, a 75-row level (second LDS geometry) and an odd row count (67)"""
     F, OFClass, _, O = _mods()
     monkeypatch.setenv("FOTG_VR_STREAM", mode)
+    monkeypatch.setenv("FOTG_VR_STAGE", "0")                 # (these levels take the stage pipeline by default)
     before = F.lib().fotg_debug_counter(b"sor_stream")
     sizes = ((1920, 1080), (1280, 1050), (1600, 1200), (1904, 1072 - 8))
     expect = 0
@@ -317,6 +364,7 @@ def test_fused_level_system_in_global_memory(alley, monkeypatch):
     through global memory (what larger levels use): same bits"""
     F, OFClass, _, O = _mods()
     monkeypatch.setenv("FOTG_VR_CLDS", "0")
+    monkeypatch.setenv("FOTG_VR_STAGE", "0")
     for case, op_point in (("alley", 2), ("synth_rgb", 2)):
         f0, f1, noc = frames(case, alley)
         h, w = f0.shape[:2]
