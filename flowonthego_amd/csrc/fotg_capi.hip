@@ -62,7 +62,7 @@ struct FotgTune {
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
   int vr_wide;      // FOTG_VR_WIDE: 0 = single-wave kernel instead of the wide one
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
-  int vr_stage;     // FOTG_VR_STAGE: 0 = no stage-pipelined levels (varref_stage.hip.h)
+  int vr_stage;     // FOTG_VR_STAGE: 1 = stage-pipelined refinement of the levels it fits (varref_stage.hip.h); default 0
   int vr_stage_mins;// FOTG_VR_STAGE_MINS: fewest anti-diagonals of a level that takes the stage pipeline
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
@@ -99,6 +99,8 @@ struct fotg_ctx {
   float2 *vrDS;
   long ds_pair_stride, ds_stage_stride[FOTG_MAXLEV];
   int *vrSync;
+  int sync_block;                    // which block of vrSync this (view of the) context uses
+  void *vrZero;
   unsigned long long *stamps;        // -DFOTG_STAGE_STAMPS builds only
   GridState gs[FOTG_MAXLEV];
   // sub-batch pipelining (fotg_calc_batch): the solver's dependent chain has a latency that does not depend on the
@@ -199,7 +201,7 @@ void fotg_destroy(fotg_ctx *c)
     (void)hipFree(c->trace_dev[l]);
     (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]);
   }
-  (void)hipFree(c->vr); (void)hipFree(c->vrQ); (void)hipFree(c->vrDS); (void)hipFree(c->vrSync);
+  (void)hipFree(c->vr); (void)hipFree(c->vrQ); (void)hipFree(c->vrDS); (void)hipFree(c->vrSync); (void)hipFree(c->vrZero);
   for (int i = 0; i < 8; ++i) {
     if (c->sub_stream[i]) (void)hipStreamDestroy(c->sub_stream[i]);
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -231,7 +233,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
   c->tune.vr_wide = env_int("FOTG_VR_WIDE", 1);
   c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
-  c->tune.vr_stage = env_int("FOTG_VR_STAGE", 1);
+  c->tune.vr_stage = env_int("FOTG_VR_STAGE", 0);      // opt-in: measured slower than the per-iteration launches at batch 64
   c->tune.vr_stage_mins = env_int("FOTG_VR_STAGE_MINS", 80);
   fotg_padded_size(w_org, h_org, p->sc_f, &c->Wp, &c->Hp, &c->padw, &c->padh);
   c->base_lv = p->sc_l < 4 ? p->sc_l : 4;
@@ -302,13 +304,14 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
         const StageGeom q = stage_geom(a.w, a.h, p->tv_solverit);
         if (q.NBW > FOTG_STAGE_NDW) continue;
         int geo = 0, rd = 0;
-        if (a.h + 2 <= 48 && q.HR <= 38) { geo = 1; rd = 48; }
-        else if (a.h + 2 <= 80 && q.HR <= 70) { geo = 2; rd = 80; }
-        else if (a.h + 2 <= 112 && q.HR <= 98) { geo = 3; rd = 112; }
-        if (!geo) continue;
+        int lds = 0;
+        if (a.h + 2 <= 48 && q.HR <= 38) { geo = 1; rd = 48; lds = stage_lds_bytes<48, 38>(q); }
+        else if (a.h + 2 <= 80 && q.HR <= 70) { geo = 2; rd = 80; lds = stage_lds_bytes<80, 70>(q); }
+        else if (a.h + 2 <= 112 && q.HR <= 98) { geo = 3; rd = 112; lds = stage_lds_bytes<112, 98>(q); }
+        if (!geo || lds > 160 * 1024) continue;
         c->stage_geo[l] = geo;
         const long pl = (long)(a.S + 1) * a.RPD;
-        const long need = pl * (P_NSINGLE + C_NCOLOR * c->noc);
+        const long need = pl * (P_NSINGLE + C_NCOLOR * c->noc + FOTG_VR_NEXTRA) + 1024;      // (+ slack: the row loads of the stage loader run up to 2 rows past a plane)
         if (need > qmax) qmax = need;
         c->ds_stage_stride[l] = (long)(a.S + FOTG_STAGE_M + 1) * rd;
         const long t = c->ds_stage_stride[l] * (inner - 1);
@@ -317,8 +320,11 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       if (qmax) {
         ALLOC(c->vrQ, B * qmax * sizeof(float));
         ALLOC(c->vrDS, B * ds_total * sizeof(float2) + 4096);
-        ALLOC(c->vrSync, stage_sync_words((int)B) * sizeof(int));
-        if (hipMemset(c->vrSync, 0, stage_sync_words((int)B) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+        ALLOC(c->vrZero, 4096);
+        if (hipMemset(c->vrZero, 0, 4096) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+        // one block of ticket / progress words per sub-batch stream (their stage launches run concurrently)
+        ALLOC(c->vrSync, 8 * stage_sync_words((int)B) * sizeof(int));
+        if (hipMemset(c->vrSync, 0, 8 * stage_sync_words((int)B) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
         c->ds_pair_stride = ds_total;
         for (int l = p->sc_l; l <= p->sc_f; ++l) {
           if (!c->stage_geo[l]) continue;
@@ -841,13 +847,6 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   const float half_gamma_over3 = c->p.tv_gamma * 0.5f / 3.0f;
   const float half_delta_over3 = c->p.tv_delta * 0.5f / 3.0f;
   const int inner = c->p.tv_innerit * (l + 1);
-  // small levels: the whole level (set-up stages, fixed-point loop, final w + d) in one launch, one workgroup per pair
-  if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && c->tune.vr_path == 0 &&
-      dispatch_inner_fused<NOC>(c, a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s,
-                                I0, I1, img_stride, g.tw, c->ps, c->taps ? 1 : 0)) {
-    LAUNCHCHK();
-    return FOTG_OK;
-  }
   if (c->stage_geo[l] && c->tune.vr_path == 0) {
     // stage pipeline: set-up launch into the skewed planes (it also zeroes the ticket / progress words), then ONE launch of
     // inner x n workgroups, workgroup = one inner iteration of one pair
@@ -855,12 +854,14 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     VrArgs aq = c->vraq[l];
     aq.taps = c->taps ? 1 : 0;
     aq.nsweeps = c->p.tv_solverit;
-    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(aq, I0, I1, img_stride, g.tw, c->ps, flow, fs, 2, c->vrSync, stage_sync_words(n));
+    int *sync = c->vrSync + (size_t)c->sync_block * stage_sync_words(c->max_batch);
+    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(aq, I0, I1, img_stride, g.tw, c->ps, flow, fs, 2, sync, stage_sync_words(n));
     LAUNCHCHK();
     StageArgs sa;
     sa.inner = inner; sa.npairs = n; sa.qa = quarter_alpha; sa.hd = half_delta_over3; sa.hg = half_gamma_over3; sa.omega = c->p.tv_sor;
     sa.flow = flow; sa.flow_stride = fs; sa.DS = c->vrDS; sa.ds_pair_stride = c->ds_pair_stride; sa.ds_stage_stride = c->ds_stage_stride[l];
-    sa.sync = c->vrSync;
+    sa.sync = sync;
+    sa.zero = c->vrZero;
     sa.stamps = nullptr;
 #ifdef FOTG_STAGE_STAMPS
     if (!c->stamps) { if (hipMalloc((void **)&c->stamps, (size_t)FOTG_STAGE_MAXINNER * c->max_batch * 16 * 8 * 8) != hipSuccess) return FOTG_ERR_HIP; }
@@ -882,6 +883,13 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     return FOTG_OK;
   }
   c->stage_used[l] = 0;
+  // small levels: the whole level (set-up stages, fixed-point loop, final w + d) in one launch, one workgroup per pair
+  if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && c->tune.vr_path == 0 &&
+      dispatch_inner_fused<NOC>(c, a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s,
+                                I0, I1, img_stride, g.tw, c->ps, c->taps ? 1 : 0)) {
+    LAUNCHCHK();
+    return FOTG_OK;
+  }
   if (c->tune.vr_setup) {
     // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
     // (tune.vr_setup = 0: memset + the three plane-at-a-time launches; tests)
@@ -1190,10 +1198,15 @@ static void make_view(const fotg_ctx *c, int p0, fotg_ctx *v)
     if (c->vr) {
       VrArgs &a = v->vra[l];
       a.base += (size_t)p0 * a.pair_stride; a.C += (size_t)p0 * a.c_pair_stride; a.D += (size_t)p0 * a.d_pair_stride;
+      if (c->stage_geo[l]) {
+        VrArgs &aq = v->vraq[l];
+        aq.base += (size_t)p0 * aq.pair_stride; aq.C += (size_t)p0 * aq.c_pair_stride; aq.D += (size_t)p0 * aq.d_pair_stride;
+      }
     }
     if (p0 != 0) v->gs[l].trace_host = nullptr;
   }
   if (c->vr) v->vr += (size_t)p0 * c->vr_pair_stride;
+  if (c->vrDS) v->vrDS += (size_t)p0 * c->ds_pair_stride;
 }
 
 // enqueue the whole batch on stream s (forking to the internal sub-batch streams and joining back)
@@ -1211,10 +1224,11 @@ static int calc_enqueue(fotg_ctx *c, int n, const float *I0, const float *I1, co
     HIPCHK(hipStreamWaitEvent(c->sub_stream[k], c->ev_fork, 0));
     fotg_ctx v;
     make_view(c, p0, &v);
+    v.sync_block = k;
     const int st = calc_range(&v, p1 - p0, I0 + frame * p0, I1 + frame * p0, initflow ? initflow + iflow * p0 : nullptr,
                               outflow + oflow * p0, c->sub_stream[k]);
     if (st && !status) status = st;
-    for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) c->gs[l] = v.gs[l];      // keep the last grid state observable (taps)
+    for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) { c->gs[l] = v.gs[l]; c->stage_used[l] = v.stage_used[l]; }      // keep the last grid state observable (taps)
     HIPCHK(hipEventRecord(c->ev_join[k], c->sub_stream[k]));
     HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
   }
@@ -1305,9 +1319,14 @@ long fotg_ctx_counter(fotg_ctx *c, const char *name)
     // bounded waits of the stage pipeline that gave up since the context was created (0 unless something is broken)
     if (!c->vrSync) return 0;
     DevGuard dg(c->device);
-    int v = 0;
-    if (!dg.ok || hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, c->vrSync + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return v;
+    long tot = 0;
+    if (!dg.ok || hipDeviceSynchronize() != hipSuccess) return -1;
+    for (int b = 0; b < 8; ++b) {
+      int v = 0;
+      if (hipMemcpy(&v, c->vrSync + (size_t)b * stage_sync_words(c->max_batch) + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      tot += v;
+    }
+    return tot;
   }
   return -1;
 }

@@ -48,6 +48,7 @@ struct StageArgs {
   long flow_stride;
   float2 *DS;             // hand-over buffers [pair][inner-1][rows][RD] float2 (stage k writes buffer k)
   long ds_pair_stride, ds_stage_stride;   // in float2
+  const void *zero;       // >= 2 KB of zeros (rows that do not exist: stage 0's input, diagonals >= S)
   int *sync;              // [0] ticket counter, [1] timed-out waits, progress word of (pair, stage k) at [32 * (1 + pair * 16 + k)]
   unsigned long long *stamps;   // -DFOTG_STAGE_STAMPS builds only: [ticket][wave][8] s_memrealtime stamps (100 MHz)
 };
@@ -59,10 +60,18 @@ struct StageGeom { int nl, HR, E, omax, NBW, NG, T0, tW, RDN, NCW, NCB, NI; };
 #define FOTG_STAGE_M 4
 #define FOTG_STAGE_SD 8        // diagonals between consecutive sweeps (sor_sync_wave's DS1 for M = 4)
 #define FOTG_STAGE_TB 5
-#define FOTG_STAGE_LA 3        // intervals between the issue of a chunk's hand-over loads and its arrival in the D ring
+#ifndef FOTG_STAGE_LA
+#define FOTG_STAGE_LA 2
+#endif
+#ifndef FOTG_STAGE_AUX
+#define FOTG_STAGE_AUX 16       // cache policy of the hand-over row loads: sc1
+#endif
+// intervals between the issue of a chunk's loads (direct to LDS) and the interval it has landed in
 #define FOTG_STAGE_RCN 32      // C ring slots (diagonals)
 #define FOTG_STAGE_NS 24       // smoothness ring slots
-#define FOTG_STAGE_NDW 11      // data waves
+#define FOTG_STAGE_RWN 16      // (wx,wy) ring slots
+#define FOTG_STAGE_RUN 16      // (uu,vv) = (wx+du, wy+dv) ring slots
+#define FOTG_STAGE_NDW 10      // data waves
 #ifndef FOTG_STAGE_DBG
 #define FOTG_STAGE_DBG 0       // timing experiments in separate builds only (wrong results): 1 loader loads nothing, 2 no data term,
 #endif                         // 4 no smoothness weights, 8 writer stores nothing, 16 solver waves only count barriers
@@ -81,7 +90,7 @@ __host__ __device__ inline StageGeom stage_geom(int w, int h, int nsweeps)
   q.NG = 2 * q.NBW <= FOTG_STAGE_NDW ? 2 : 1;
   q.T0 = FOTG_STAGE_TB + q.NG + 1;
   q.tW = q.T0 + q.omax / M + 1;
-  q.RDN = M * (q.tW + 1);
+  q.RDN = M * (q.tW + FOTG_STAGE_LA + 1);
   q.NCW = (S + M - 1) / M;
   q.NCB = (E + 1 + M) / M;
   q.NI = q.T0 + E / M + q.omax / M + 4;
@@ -90,7 +99,7 @@ __host__ __device__ inline StageGeom stage_geom(int w, int h, int nsweeps)
 template <int RD, int RCW>
 __host__ __device__ inline int stage_lds_bytes(const StageGeom &q)
 {
-  return 128 + FOTG_STAGE_RCN * 2 * RCW * 16 + q.RDN * RD * 8 + FOTG_STAGE_NS * RD * 4 + RD * 8;
+  return 128 + FOTG_STAGE_RCN * 2 * RCW * 16 + (q.RDN + FOTG_STAGE_RWN + FOTG_STAGE_RUN) * RD * 8 + FOTG_STAGE_NS * RD * 4 + RD * 8;
 }
 
 // relaxed agent-scope accesses: global_load / global_store ... sc1
@@ -104,8 +113,13 @@ __device__ __forceinline__ void st_agent_f2(float2 *p, float2 v)
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifndef FOTG_STAGE_WPE
+#define FOTG_STAGE_WPE 4
+#endif
+// (a 1024-thread workgroup is 4 waves per SIMD whatever the register count: tell the scheduler, so it spends registers on
+// instruction-level parallelism instead of saving them for an occupancy this kernel cannot have)
 template <int NOC, int RD, int RCW>
-__global__ __launch_bounds__(1024) void vr_stage_kernel(VrArgs a, StageArgs g)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FOTG_STAGE_WPE, FOTG_STAGE_WPE))) void vr_stage_kernel(VrArgs a, StageArgs g)
 {
   constexpr int M = FOTG_STAGE_M, SD = FOTG_STAGE_SD, TB = FOTG_STAGE_TB, RCN = FOTG_STAGE_RCN, NS = FOTG_STAGE_NS, U = 16, UT = 8;
   constexpr int DB = RD * 8, CB = RCW * 16, CSLOT = 2 * CB, SB = RD * 4;          // bytes per ring slot: D, C plane, C, smoothness
@@ -117,11 +131,24 @@ __global__ __launch_bounds__(1024) void vr_stage_kernel(VrArgs a, StageArgs g)
   const StageGeom q = stage_geom(w, h, a.nsweeps);
   const int NI = q.NI, RDN = q.RDN, NG = q.NG, T0 = q.T0;
   const unsigned CRING = (unsigned)RCN * CSLOT, DRING = (unsigned)RDN * DB;
-  const unsigned CBASE = 128, DBASE = CBASE + CRING, SBASE = DBASE + DRING, DUMP = SBASE + NS * SB;
+  constexpr int RWN = FOTG_STAGE_RWN, RUN = FOTG_STAGE_RUN;
+  const unsigned CBASE = 128, DBASE = CBASE + CRING, WBASE = DBASE + DRING, UBASE = WBASE + RWN * DB, SBASE = UBASE + RUN * DB, DUMP = SBASE + NS * SB;
   char *lds = lds_bytes();
   auto ld_f2 = [&](unsigned off) { return *reinterpret_cast<const float2 *>(lds + off); };
   auto ld_f4 = [&](unsigned off) { return *reinterpret_cast<const float4 *>(lds + off); };
   auto ld_f1 = [&](unsigned off) { return *reinterpret_cast<const float *>(lds + off); };
+#if defined(FOTG_STAGE_STAMPS) && FOTG_STAGE_STAMPS == 2
+  // arrival / release time of this wave at barriers #FOTG_STAGE_B0 .. +3 (slots 2k, 2k+1)
+#ifndef FOTG_STAGE_B0
+#define FOTG_STAGE_B0 30
+#endif
+  int stamp_ticket = 0, bc = 0;
+#define FOTG_STAMPB(k) do { if (g.stamps && lane == 0) g.stamps[((size_t)stamp_ticket * 16 + wv) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FOTG_BAR() do { const bool st_ = bc >= FOTG_STAGE_B0 && bc < FOTG_STAGE_B0 + 4; if (st_) FOTG_STAMPB(2 * (bc - FOTG_STAGE_B0)); \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); if (st_) FOTG_STAMPB(2 * (bc - FOTG_STAGE_B0) + 1); ++bc; } while (0)
+#define FOTG_STAMP(slot) do { } while (0)
+#define FOTG_STAMP_AT(I) do { } while (0)
+#else
 #define FOTG_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #ifdef FOTG_STAGE_STAMPS
   int stamp_ticket = 0;
@@ -131,7 +158,7 @@ __global__ __launch_bounds__(1024) void vr_stage_kernel(VrArgs a, StageArgs g)
 #define FOTG_STAMP(slot) do { } while (0)
 #define FOTG_STAMP_AT(I) do { } while (0)
 #endif
-
+#endif
   // ---- role: ticket -> (stage, pair), stage-major: every stage k-1 workgroup holds a lower ticket than any stage k one
   if (threadIdx.x == 0) *reinterpret_cast<int *>(lds) = atomicAdd(&g.sync[0], 1);
   if (threadIdx.x < RD) *reinterpret_cast<float2 *>(lds + DUMP + threadIdx.x * 8) = make_float2(0.f, 0.f);
@@ -150,9 +177,16 @@ __global__ __launch_bounds__(1024) void vr_stage_kernel(VrArgs a, StageArgs g)
   const float2 *const in_buf = g.DS + (size_t)pair * g.ds_pair_stride + (size_t)(stage > 0 ? stage - 1 : 0) * g.ds_stage_stride;
 
   // ================================================= solver waves =================================================
-  if (wv < 3) {
-    if (wv >= a.nsweeps || (FOTG_STAGE_DBG & 16)) { for (int I = 0; I < NI; ++I) FOTG_BAR(); return; }
-    const int off = T0 * M + wv * SD;
+  // Roles by wave id.  Waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically: class = wave & 3).
+  // Measured SIMD time per interval on full diagonals: a data wave's half pass 0.45 us, a solver wave 0.25 us, uv / zero 0.25,
+  // writer 0.15, loader 0.05 -- dealt so that every class carries about 1.4 us and waves of both data groups:
+  //   class 0: 0 solver (sweep 0), 4 solver (sweep 1), 8 data, 12 data      class 1: 1 solver (sweep 2), 5 uv / zero, 9 data, 13 data
+  //   class 2: 2 writer, 6 data, 10 data, 14 data                           class 3: 3 loader, 7 data, 11 data, 15 data
+  constexpr int WV_WRITER = 2, WV_LOADER = 3, WV_UV = 5;
+  if (wv == 0 || wv == 4 || wv == 1) {
+    const int sweep = wv == 0 ? 0 : wv == 4 ? 1 : 2;
+    if (sweep >= a.nsweeps || (FOTG_STAGE_DBG & 16)) { for (int I = 0; I < NI; ++I) FOTG_BAR(); return; }
+    const int off = T0 * M + sweep * SD;
     const int nl = q.nl;
     const float om0 = g.omega, om1 = (2 * lane + 1 < h) ? g.omega : 0.f;
     const unsigned vD = DBASE + (unsigned)lane * 16, vC = CBASE + (unsigned)lane * 32;
@@ -215,71 +249,70 @@ __global__ __launch_bounds__(1024) void vr_stage_kernel(VrArgs a, StageArgs g)
   }
 
   // ================================================= loader =================================================
-  if (wv == 3) {
-    // Chunk c (diagonals 4c .. 4c+3) is written to the D ring in interval c and visible to everybody from interval c+1; its loads
-    // are ISSUED LA intervals earlier (an agent-scope load is a 0.5-2 us round trip behind the data waves' traffic -- more than an
-    // interval), as soon as the predecessor's progress word covers it.  Rows >= S and stage 0 (du = dv = 0 before the first
-    // iteration, refine_variational.cpp:185-186) are zero rows.
+  if (wv == WV_LOADER) {
+    // Chunk c (diagonals 4c .. 4c+3): its rows of the predecessor's (du,dv) and of (wx,wy) are loaded DIRECTLY INTO the D and w
+    // rings (global_load_lds_dwordx4: 16 bytes per lane, no registers; the hand-over rows agent-scope = sc1), issued in interval
+    // c - LA, as soon as the predecessor's progress word covers them, and waited for with a counted vmcnt in interval c: they
+    // have landed before barrier #c+1.  Exactly 2M loads per interval (rows that do not exist -- stage 0's input: du = dv = 0
+    // before the first iteration, refine_variational.cpp:185-186; diagonals >= S -- come from a zero buffer), so "all but the
+    // newest 2M * LA" is chunk c.  Nothing else in this wave touches vector memory except the poll, which drains the counter.
     constexpr int LA = FOTG_STAGE_LA;
     int ready = stage > 0 ? 0 : S;
-    const bool hi = lane + 64 < RD;
-    struct Chunk { float2 v0[M], v1[M]; };
-    auto issue = [&](Chunk &ck, int c) {
-      if (FOTG_STAGE_DBG & 1) {
-#pragma unroll
-        for (int k = 0; k < M; ++k) { ck.v0[k] = make_float2(0.f, 0.f); ck.v1[k] = make_float2(0.f, 0.f); }
-        return;
-      }
-      const int need = (c * M + M < S) ? c * M + M : S;
-      if (ready < need) {
-        int spins = 0;
-        do {
-          ready = __hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (ready >= need) break;
-          __builtin_amdgcn_s_sleep(1);
-        } while (++spins < (1 << 21));
-        if (ready < need) {                                       // bounded wait: report and go on (the result is wrong, nothing hangs)
-          if (lane == 0) atomicAdd(&g.sync[1], 1);
-          ready = S;
+    const bool act = lane < RD / 2;
+    const char *zrow = reinterpret_cast<const char *>(g.zero) + lane * 16;
+    const char *inb = reinterpret_cast<const char *>(in_buf) + lane * 16;
+    const char *wq = reinterpret_cast<const char *>(a.extra(pair, 8)) + lane * 16;
+    auto issue = [&](int c) {
+      if (!(FOTG_STAGE_DBG & 1) && stage > 0) {
+        const int need = (c * M + M < S) ? c * M + M : S;
+        if (ready < need) {
+          int spins = 0;
+          do {
+            int v;
+            asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(prog_in) : "memory");
+            ready = __builtin_amdgcn_readfirstlane(v);
+            if (ready >= need) break;
+            __builtin_amdgcn_s_sleep(1);
+          } while (++spins < (1 << 21));
+          if (ready < need) {                                     // bounded wait: report and go on (the result is wrong, nothing hangs)
+            if (lane == 0) atomicAdd(&g.sync[1], 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ready = S;
+          }
         }
       }
+      unsigned dslot = (unsigned)((c * M) % RDN) * DB, wslot = (unsigned)((c * M) % RWN) * DB;
 #pragma unroll
       for (int k = 0; k < M; ++k) {
-        const int d = c * M + k;
-        ck.v0[k] = make_float2(0.f, 0.f); ck.v1[k] = make_float2(0.f, 0.f);
-        if (stage > 0 && d < S) {
-          const float2 *row = in_buf + (size_t)d * RD;
-          if (lane < RD) ck.v0[k] = ld_agent_f2(row + lane);
-          if (hi) ck.v1[k] = ld_agent_f2(row + lane + 64);
+        const int row = c * M + k;
+        const char *sd = (stage > 0 && row < S && !(FOTG_STAGE_DBG & 1)) ? inb + (size_t)row * DB : zrow;
+        const char *sw = row < S ? wq + (size_t)row * (RQ * 8) : zrow;
+        if (act) {
+          typedef __attribute__((address_space(1))) const void gvoid;
+          typedef __attribute__((address_space(3))) void lvoid;
+          __builtin_amdgcn_global_load_lds((gvoid *)sd, (lvoid *)(lds + DBASE + dslot), 16, 0, FOTG_STAGE_AUX);      // aux 16 = sc1
+          __builtin_amdgcn_global_load_lds((gvoid *)sw, (lvoid *)(lds + WBASE + wslot), 16, 0, 0);
         }
+        dslot += DB; if (dslot == DRING) dslot = 0;
+        wslot += DB; if (wslot == RWN * DB) wslot = 0;
       }
     };
-    auto write = [&](const Chunk &ck, int c) {
-      unsigned slot = (unsigned)((c * M) % RDN) * DB;
-#pragma unroll
-      for (int k = 0; k < M; ++k) {
-        if (lane < RD) *reinterpret_cast<float2 *>(lds + DBASE + slot + lane * 8) = ck.v0[k];
-        if (hi) *reinterpret_cast<float2 *>(lds + DBASE + slot + (lane + 64) * 8) = ck.v1[k];
-        slot += DB; if (slot == DRING) slot = 0;
-      }
-    };
-    static_assert(LA == 3, "the loop below rotates four chunk buffers");
-    Chunk b0, b1, b2, b3;
-    issue(b0, 0); issue(b1, 1); issue(b2, 2);
-    for (int I = 0; I < NI; I += 4) {
-      FOTG_BAR(); FOTG_STAMP_AT(I); issue(b3, I + 3); write(b0, I);
-      if (I + 1 < NI) { FOTG_BAR(); issue(b0, I + 4); write(b1, I + 1); }
-      if (I + 2 < NI) { FOTG_BAR(); issue(b1, I + 5); write(b2, I + 2); }
-      if (I + 3 < NI) { FOTG_BAR(); issue(b2, I + 6); write(b3, I + 3); }
+    for (int c = 0; c < LA; ++c) issue(c);
+    for (int I = 0; I < NI; ++I) {
+      FOTG_BAR();
+      FOTG_STAMP_AT(I);
+      issue(I + LA);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * M * LA) : "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may land after the workgroup's LDS is released
     FOTG_STAMP(6);
     return;
   }
 
   // ================================================= writer =================================================
-  if (wv == 7) {
+  if (wv == WV_WRITER) {
     const bool hi = lane + 64 < RD;
-    const float *wxq = a.single(pair, P_WX), *wyq = a.single(pair, P_WY);
+    const float2 *wq2 = reinterpret_cast<const float2 *>(a.extra(pair, 8));
     float *fl = g.flow + (size_t)pair * g.flow_stride;
     float2 *Dtap = a.taps ? a.Dp(pair) : nullptr;
     // Not the last stage: per interval exactly NST * M row stores + 1 progress store (rows >= S go to the spare rows behind the
@@ -331,7 +364,7 @@ __global__ __launch_bounds__(1024) void vr_stage_kernel(VrArgs a, StageArgs g)
             const int dd = cn * M + k, r = lane + 64 * half, i = dd - r;
             const bool ok = cn >= 0 && r < h && i >= 0 && i < w;
             const int qi = ok ? dd * RQ + r : 0;
-            wq_n[k][half] = make_float2(wxq[qi], wyq[qi]);
+            wq_n[k][half] = wq2[qi];
           }
       }
       if (c < 0 || c >= q.NCW) continue;
@@ -361,111 +394,210 @@ __global__ __launch_bounds__(1024) void vr_stage_kernel(VrArgs a, StageArgs g)
     return;
   }
 
+  // ================================================= uv / zero wave =================================================
+  if (wv == WV_UV) {
+    // interval I: (uu,vv) = (wx + du, wy + dv) (refine_variational.cpp:208-214) of chunk I-1, whose rows have landed in the D and w
+    // rings before barrier #I, into the uv ring (read by the smoothness weights from interval I+1 on).
+    // It also zeroes the C-ring cells of chunk I - TB that lie OUTSIDE the image (rows < max(0, s-w+1) or > min(h-1, s) of
+    // diagonal s, up to the solver's HR rows): the data waves write the cells inside in the same intervals, the previous
+    // occupant of the slots was last read in interval I - 1, the first sweep reads them from I + NG on.  A zero system cell
+    // keeps a zero (du,dv) cell zero (fixed point), which is what the solver's predicate-free steps rely on.
+    // (all LDS reads of a chunk are issued before the first use: branch-free, lanes beyond the row repeat its last cell)
+    const unsigned cell0 = (unsigned)(lane < RD ? lane : RD - 1) * 8, cell1 = (unsigned)(lane + 64 < RD ? lane + 64 : RD - 1) * 8;
+    auto uv = [&](int c) {
+      if (c < 0) return;
+      unsigned dslot = (unsigned)((c * M) % RDN) * DB, wslot = (unsigned)((c * M) % RWN) * DB, uslot = (unsigned)((c * M) % RUN) * DB;
+      float2 dv_[M][2], wv_[M][2];
+      unsigned us_[M];
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        dv_[k][0] = ld_f2(DBASE + dslot + cell0); wv_[k][0] = ld_f2(WBASE + wslot + cell0);
+        if constexpr (RD > 64) { dv_[k][1] = ld_f2(DBASE + dslot + cell1); wv_[k][1] = ld_f2(WBASE + wslot + cell1); }
+        us_[k] = uslot;
+        dslot += DB; dslot = dslot == DRING ? 0 : dslot;
+        wslot += DB; wslot = wslot == RWN * DB ? 0 : wslot;
+        uslot += DB; uslot = uslot == RUN * DB ? 0 : uslot;
+      }
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        *reinterpret_cast<float2 *>(lds + UBASE + us_[k] + cell0) = make_float2(wv_[k][0].x + dv_[k][0].x, wv_[k][0].y + dv_[k][0].y);
+        if constexpr (RD > 64)
+          *reinterpret_cast<float2 *>(lds + UBASE + us_[k] + cell1) = make_float2(wv_[k][1].x + dv_[k][1].x, wv_[k][1].y + dv_[k][1].y);
+      }
+    };
+    auto zero_c = [&](int c) {
+      if (c < 0 || c >= q.NCB) return;
+      // (wave-uniform early out: chunks whose four diagonals are full rows -- the middle of the level -- have nothing to zero)
+      const int s_first = c * M, s_last = c * M + M - 1;
+      if (s_first >= h - 1 && s_last <= w - 1 && q.HR == h) return;
+      const unsigned cb0 = CBASE + (unsigned)((c * M) % RCN) * CSLOT;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const int sd = c * M + k;
+        const int lo = sd - (w - 1) > 0 ? sd - (w - 1) : 0, hi2 = sd < h - 1 ? sd : h - 1;
+#pragma unroll
+        for (int half = 0; half < (RCW > 64 ? 2 : 1); ++half) {
+          const int rr = lane + 64 * half;
+          if (rr < q.HR && (rr < lo || rr > hi2)) {
+            *reinterpret_cast<float4 *>(lds + cb0 + k * CSLOT + rr * 16) = z;
+            *reinterpret_cast<float4 *>(lds + cb0 + k * CSLOT + CB + rr * 16) = z;
+          }
+        }
+      }
+    };
+    for (int I = 0; I < NI; ++I) {
+      FOTG_BAR();
+      uv(I - 1);
+      zero_c(I - TB);
+    }
+    FOTG_STAMP(6);
+    return;
+  }
+
   // ================================================= data waves =================================================
   {
-    int dw;                                                       // waves 4,5,6, 8,9,10, 12,13,14, 11, 15 -> 0 .. 10
-    if ((wv & 3) != 3) dw = (wv / 4 - 1) * 3 + (wv & 3); else dw = wv == 11 ? 9 : 10;
+    // data waves 8, 9, 6, 7, 10 (group 0) and 12, 13, 14, 11, 15 (group 1)
+    int dw;
+    switch (wv) { case 8: dw = 0; break; case 9: dw = 1; break; case 6: dw = 2; break; case 7: dw = 3; break; case 10: dw = 4; break;
+                  case 12: dw = 5; break; case 13: dw = 6; break; case 14: dw = 7; break; case 11: dw = 8; break; default: dw = 9; break; }
     const int NBW = q.NBW, HR = q.HR;
     const int grp = dw / NBW, kk = dw - grp * NBW;
     if (grp >= NG) { for (int I = 0; I < NI; ++I) FOTG_BAR(); return; }
-    // this lane's cell of a chunk: (diagonal d of the chunk, row r), the same in every pass
+    // The cells of a chunk: only the pixels INSIDE the image are enumerated (a diagonal s holds rows max(0, s-w+1) .. min(h-1, s);
+    // the skewed bounding parallelogram is 1.5-2x the image), densely over the lanes of the group's waves: lane slot e = 64 kk + lane
+    // -> (diagonal d of the chunk, row r) through the prefix sums of the four diagonals' lengths (wave-uniform).  Waves whose
+    // slots lie beyond the chunk's cell count skip the pass (they only keep the barriers).  The cells outside the image are
+    // zeroed in the C ring by wave 15.  All rings are a whole number of chunks long, so a chunk's M slots are contiguous.
     const int e = kk * 64 + lane;
-    const bool cellok = e < M * HR;
-    const int d = cellok ? e / HR : 0, r = cellok ? e - d * HR : 0;
-    // first pass: chunk c = -3 (only A'(-1), i.e. the smoothness weight of diagonal 0), groups alternate
-    int c = NG == 2 ? (grp == 1 ? -3 : -2) : -3;
+    struct Cell { int d, r, i; bool ok; };
+    auto cell_of = [&](int cc, int &ntot) {
+      int off[M + 1], rmin[M];
+      off[0] = 0;
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const int sd = cc * M + k;
+        const int lo = sd - (w - 1) > 0 ? sd - (w - 1) : 0, hi = sd < h - 1 ? sd : h - 1;
+        rmin[k] = lo;
+        off[k + 1] = off[k] + ((sd >= 0 && hi >= lo) ? hi - lo + 1 : 0);
+      }
+      ntot = off[M];
+      Cell cl;
+      cl.d = (e >= off[1]) + (e >= off[2]) + (e >= off[3]);
+      const int o = cl.d == 0 ? off[0] : cl.d == 1 ? off[1] : cl.d == 2 ? off[2] : off[3];
+      const int rm = cl.d == 0 ? rmin[0] : cl.d == 1 ? rmin[1] : cl.d == 2 ? rmin[2] : rmin[3];
+      cl.ok = e < off[M];
+      cl.r = cl.ok ? rm + e - o : 0;
+      if (!cl.ok) cl.d = 0;
+      cl.i = cc * M + cl.d - cl.r;
+      return cl;
+    };
+    // addresses of a cell and of its (s-1) / (s+1) neighbours in a ring of pitch `pb` given the bases of chunks x-1, x, x+1
+    auto nb3 = [&](const Cell &cl, unsigned bm, unsigned b0, unsigned bp, unsigned pb, unsigned rb, unsigned &ac, unsigned &am, unsigned &ap) {
+      ac = b0 + (unsigned)cl.d * pb + rb;
+      am = cl.d > 0 ? ac - pb : bm + (M - 1) * pb + rb;
+      ap = cl.d < M - 1 ? ac + pb : bp + rb;
+    };
+    auto wrapm = [](int x, int n) { return x < 0 ? x + n : (x >= n ? x - n : x); };
+    constexpr int NU = RUN / M, NSC = NS / M, NCC = RCN / M;
+    const int ND = RDN / M;
+    // first pass: chunk c = -2 (only A(0): the smoothness weights of chunk 0), groups alternate
+    int c = NG == 2 ? (grp == 0 ? -2 : -1) : -2;
+    int kU = wrapm(c % NU + NU, NU), kS = wrapm(c % NSC + NSC, NSC), kC = wrapm(c % NCC + NCC, NCC), kD = wrapm(c + ND, ND);
     int nbar = 0;
     for (; nbar < c + TB; ++nbar) FOTG_BAR();
-    const float *Qm = a.single(pair, P_MASK), *Qwx = a.single(pair, P_WX), *Qwy = a.single(pair, P_WY);
-    // Everything a pass reads from global memory (the constant planes of its cells) is loaded ONE PASS AHEAD: an L2 round trip
-    // under the CU's own traffic is as long as the arithmetic of a pass.
-    struct AW { float wxc, wxl, wxr, wxt, wxb, wyc, wyl, wyr, wyt, wyb; };
-    auto load_b = [&](int cc, PixIn<NOC> &pin) {                  // the cell (4 cc + d, r) of B(cc)
-      const int sD = cc * M + d, iB = sD - r;
-      const bool inB = cellok && cc >= 0 && r < h && iB >= 0 && iB < w;
-      const int qB = inB ? sD * RQ + r : 0;
-      const int ql = (inB && iB > 0) ? qB - RQ : qB, qr = (inB && iB < w - 1) ? qB + RQ : qB;
-      const int qt = (inB && r > 0) ? qB - RQ - 1 : qB, qb = (inB && r < h - 1) ? qB + RQ + 1 : qB;
+    const float *Qm = a.single(pair, P_MASK);
+    // the planes of a pass's cell are loaded ONE PASS AHEAD: an L2 round trip under the CU's own traffic is as long as a pass
+    typedef PixDiff<NOC> Planes;
+    auto load_b = [&](int cc, const Cell &cl, Planes &pl) {       // this lane's cell of B(cc)
+      const unsigned qB = cl.ok ? (unsigned)((cc * M + cl.d) * RQ + cl.r) : 0u;
 #pragma unroll
       for (int ch = 0; ch < NOC; ++ch) {
-        pin.Ix[ch] = a.color(pair, C_IX, ch)[qB]; pin.Iy[ch] = a.color(pair, C_IY, ch)[qB]; pin.Iz[ch] = a.color(pair, C_IZ, ch)[qB];
-        pin.Ixx[ch] = a.color(pair, C_IXX, ch)[qB]; pin.Ixy[ch] = a.color(pair, C_IXY, ch)[qB]; pin.Iyy[ch] = a.color(pair, C_IYY, ch)[qB];
-        pin.Ixz[ch] = a.color(pair, C_IXZ, ch)[qB]; pin.Iyz[ch] = a.color(pair, C_IYZ, ch)[qB];
+        pl.Ix[ch] = a.color(pair, C_IX, ch)[qB]; pl.Iy[ch] = a.color(pair, C_IY, ch)[qB]; pl.Iz[ch] = a.color(pair, C_IZ, ch)[qB];
+        pl.Ixx[ch] = a.color(pair, C_IXX, ch)[qB]; pl.Ixy[ch] = a.color(pair, C_IXY, ch)[qB]; pl.Iyy[ch] = a.color(pair, C_IYY, ch)[qB];
+        pl.Ixz[ch] = a.color(pair, C_IXZ, ch)[qB]; pl.Iyz[ch] = a.color(pair, C_IYZ, ch)[qB];
       }
-      pin.m = Qm[qB];
-      pin.wxc = Qwx[qB]; pin.wxl = Qwx[ql]; pin.wxr = Qwx[qr]; pin.wxt = Qwx[qt]; pin.wxb = Qwx[qb];
-      pin.wyc = Qwy[qB]; pin.wyl = Qwy[ql]; pin.wyr = Qwy[qr]; pin.wyt = Qwy[qt]; pin.wyb = Qwy[qb];
+      pl.m = Qm[qB];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pl.d[k] = a.extra(pair, k)[qB];
     };
-    auto load_a = [&](int cc, AW &aw) {                           // the cell (4 (cc+2) + 1 + d, r) of A'(cc + 2)
-      const int sA = (cc + 2) * M + 1 + d, iA = sA - r;
-      const bool inA = cellok && sA >= 0 && r < h && iA >= 0 && iA < w;
-      const int qA = inA ? sA * RQ + r : 0;
-      const int ql = (inA && iA > 0) ? qA - RQ : qA, qr = (inA && iA < w - 1) ? qA + RQ : qA;
-      const int qt = (inA && r > 0) ? qA - RQ - 1 : qA, qb = (inA && r < h - 1) ? qA + RQ + 1 : qA;
-      aw.wxc = Qwx[qA]; aw.wxl = Qwx[ql]; aw.wxr = Qwx[qr]; aw.wxt = Qwx[qt]; aw.wxb = Qwx[qb];
-      aw.wyc = Qwy[qA]; aw.wyl = Qwy[ql]; aw.wyr = Qwy[qr]; aw.wyt = Qwy[qt]; aw.wyb = Qwy[qb];
-    };
-    constexpr bool PFB = NOC == 1;                                // (RGB: 35 values per cell -- a second set does not fit the registers)
-    PixIn<NOC> pin_n = {};
-    AW aw_n = {};
-    if (PFB && !(FOTG_STAGE_DBG & 2)) load_b(c, pin_n);
-    if (!(FOTG_STAGE_DBG & 4)) load_a(c, aw_n);
+    constexpr bool PFB = NOC == 1;                                // (RGB: 33 values per cell -- a second set does not fit the registers)
+    Planes pl_n = {};
+    // cell maps: of this pass's B chunk (c), and of chunk c+2 = this pass's A chunk; with NG = 2 the latter is also the next
+    // pass's B chunk, so one map is computed per pass
+    int nB, nA;
+    Cell cb = cell_of(c, nB), ca = cell_of(c + 2, nA);
+    if (PFB && !(FOTG_STAGE_DBG & 2)) load_b(c, cb, pl_n);
     for (; c + TB + NG - 1 < NI; c += NG) {
       FOTG_BAR(); ++nbar;                                         // barrier #(c + TB)
       FOTG_STAMP_AT(c + TB); FOTG_STAMP_AT(c + TB - 1);
-      PixIn<NOC> pin = pin_n;
-      const AW aw = aw_n;
-      if (!(FOTG_STAGE_DBG & 2)) { if constexpr (PFB) load_b(c + NG, pin_n); else load_b(c, pin); }
-      if (!(FOTG_STAGE_DBG & 4)) load_a(c + NG, aw_n);
-      const int sD = c * M + d, iB = sD - r;
-      const bool inB = cellok && c >= 0 && r < h && iB >= 0 && iB < w;          // (sD < S follows)
-      const bool doB = cellok && c >= 0 && c < q.NCB;
-      const bool fl_ = inB && iB > 0, fr_ = inB && iB < w - 1, ft_ = inB && r > 0, fb_ = inB && r < h - 1;
-      // ---------- A'(c + 2): smoothness weight (compute_smoothness first half, opticalflow_aux.c:126-139) of diagonal 4(c+2)+1+d
-      if (!(FOTG_STAGE_DBG & 4)) {
-        const int sA = (c + 2) * M + 1 + d, iA = sA - r;
-        const bool inA = cellok && sA >= 0 && r < h && iA >= 0 && iA < w;
-        const bool al = inA && iA > 0, ar = inA && iA < w - 1, at = inA && r > 0, ab = inA && r < h - 1;
-        // (du,dv) of the five cells from the D ring (replicate at the image border like the 3-tap filters, image.c:436-464)
-        const int sAc = inA ? sA : 0;
-        const unsigned s0 = (unsigned)(sAc % RDN), sm = s0 == 0 ? RDN - 1 : s0 - 1, sp = s0 + 1 == (unsigned)RDN ? 0 : s0 + 1;
-        const unsigned oc = DBASE + s0 * DB + r * 8;
-        const unsigned ol = al ? DBASE + sm * DB + r * 8 : oc, orr = ar ? DBASE + sp * DB + r * 8 : oc;
-        const unsigned ot = at ? DBASE + sm * DB + (r - 1) * 8 : oc, ob = ab ? DBASE + sp * DB + (r + 1) * 8 : oc;
-        const float2 dc = ld_f2(oc), dl = ld_f2(ol), dr = ld_f2(orr), dt = ld_f2(ot), db = ld_f2(ob);
-        const int jj = at ? (ab ? 1 : h - 1) : 0;                  // smooth_w only tests j == 0 / j == h-1
-        const float sval = smooth_w(make_float2(aw.wxl + dl.x, aw.wyl + dl.y), make_float2(aw.wxc + dc.x, aw.wyc + dc.y), make_float2(aw.wxr + dr.x, aw.wyr + dr.y),
-                                    make_float2(aw.wxt + dt.x, aw.wyt + dt.y), make_float2(aw.wxb + db.x, aw.wyb + db.y), jj, h, g.qa);
-        if (inA) *reinterpret_cast<float *>(lds + SBASE + (unsigned)(sA % NS) * SB + r * 4) = sval;
+      Planes pl = pl_n;
+      if (!(FOTG_STAGE_DBG & 2)) {
+        if constexpr (PFB) {
+          if (NG == 2) load_b(c + 2, ca, pl_n);
+          else { int nn; const Cell cn = cell_of(c + 1, nn); load_b(c + 1, cn, pl_n); }
+        } else load_b(c, cb, pl);
       }
-      if (NG == 2) { FOTG_BAR(); ++nbar; }                        // barrier #(c + TB + 1)
-      // ---------- B(c): pair sums of the smoothness weights (:141-163), data term, laplacian, block inverse -> C ring
-      if (doB) {
-        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-        {
-          const int sDc = inB ? sD : 1;
-          const unsigned n0 = (unsigned)(sDc % NS), nm = n0 == 0 ? NS - 1 : n0 - 1, np = n0 + 1 == NS ? 0 : n0 + 1;
-          const float s_o = ld_f1(SBASE + n0 * SB + r * 4);
-          const float s_r = ld_f1(SBASE + np * SB + r * 4), s_l = ld_f1(SBASE + nm * SB + r * 4);
-          const float s_b = ld_f1(SBASE + np * SB + (r + 1) * 4), s_t = ld_f1(SBASE + nm * SB + (r > 0 ? r - 1 : 0) * 4);
-          const float hr = fr_ ? s_o + s_r : 0.0f, hl = fl_ ? s_l + s_o : 0.0f, vb = fb_ ? s_o + s_b : 0.0f, vt = ft_ ? s_t + s_o : 0.0f;
-          const float2 duv = ld_f2(DBASE + (unsigned)(sDc % RDN) * DB + r * 8);
-          // data_term_cell only tests i > 0, i < w-1, j > 0, j < h-1: hand it border-equivalent coordinates
-          const int ii = fl_ ? (fr_ ? 1 : w - 1) : 0, jj = ft_ ? (fb_ ? 1 : h - 1) : 0;
-          float4 x0, x1;
-          if (!(FOTG_STAGE_DBG & 2)) {
-            data_term_cell<NOC>(a, ii, jj, pin, hr, hl, vb, vt, duv.x, duv.y, g.hd, g.hg, x0, x1);
-            if (inB) { c0 = x0; c1 = x1; }                         // cells outside the image are zero (a fixed point of the update)
+      // ---------- A(c + 2): smoothness weights (compute_smoothness first half, opticalflow_aux.c:126-139) of chunk c+2 from the
+      // (uu,vv) ring: cell, left (s-1, r), right (s+1, r), top (s-1, r-1), bottom (s+1, r+1); replicate at the image border
+      // like the 3-tap filters (image.c:436-464)
+      if (!(FOTG_STAGE_DBG & 4) && kk * 64 < nA) {                 // (wave-uniform)
+        const bool inA = ca.ok;
+        const bool al = inA && ca.i > 0, ar = inA && ca.i < w - 1, at = inA && ca.r > 0, ab = inA && ca.r < h - 1;
+        unsigned ac, am, ap;
+        nb3(ca, UBASE + (unsigned)wrapm(kU + 1, NU) * (M * DB), UBASE + (unsigned)wrapm(kU + 2, NU) * (M * DB), UBASE + (unsigned)wrapm(kU + 3, NU) * (M * DB),
+            DB, (unsigned)ca.r * 8, ac, am, ap);
+        const float2 uc = ld_f2(ac), ul = ld_f2(al ? am : ac), ur = ld_f2(ar ? ap : ac), ut = ld_f2(at ? am - 8 : ac), ub = ld_f2(ab ? ap + 8 : ac);
+        const int jj = at ? (ab ? 1 : h - 1) : 0;                  // smooth_w only tests j == 0 / j == h-1
+        const float sval = smooth_w(ul, uc, ur, ut, ub, jj, h, g.qa);
+        if (inA) *reinterpret_cast<float *>(lds + SBASE + (unsigned)wrapm(kS + 2, NSC) * (M * SB) + (unsigned)ca.d * SB + ca.r * 4) = sval;
+      }
+      // ---------- B(c): pair sums of the smoothness weights (:141-163), data term (:310-438), sub_laplacian (:172-199), block
+      // inverse (solver.c:115-120) -> C ring
+      // With two intervals per pass (NG = 2) the pass's second barrier sits INSIDE the data term, between its colour and its
+      // gradient part (about half of the pass's arithmetic on either side); a wave without cells just executes it.
+      const bool has_b = c >= 0 && kk * 64 < nB && !(FOTG_STAGE_DBG & 2);      // (wave-uniform)
+      if (!has_b && NG == 2) { FOTG_BAR(); ++nbar; }              // barrier #(c + TB + 1)
+      if (has_b) {
+        const bool inB = cb.ok;
+        const int iB = cb.i, r = cb.r;
+        const bool fl_ = inB && iB > 0, fr_ = inB && iB < w - 1, ft_ = inB && r > 0, fb_ = inB && r < h - 1;
+        unsigned sc, sm, sp;
+        nb3(cb, SBASE + (unsigned)wrapm(kS - 1, NSC) * (M * SB), SBASE + (unsigned)kS * (M * SB), SBASE + (unsigned)wrapm(kS + 1, NSC) * (M * SB),
+            SB, (unsigned)r * 4, sc, sm, sp);
+        const float s_o = ld_f1(sc), s_r = ld_f1(fr_ ? sp : sc), s_l = ld_f1(fl_ ? sm : sc), s_b = ld_f1(fb_ ? sp + 4 : sc), s_t = ld_f1(ft_ ? sm - 4 : sc);
+        const float hr = fr_ ? s_o + s_r : 0.0f, hl = fl_ ? s_l + s_o : 0.0f, vb = fb_ ? s_o + s_b : 0.0f, vt = ft_ ? s_t + s_o : 0.0f;
+        const float2 duv = ld_f2(DBASE + (unsigned)kD * (M * DB) + (unsigned)cb.d * DB + r * 8);
+        const Planes &pin = pl;
+        // data_term_cell only tests i > 0, i < w-1, j > 0, j < h-1: hand it border-equivalent coordinates
+        const int ii = fl_ ? (fr_ ? 1 : w - 1) : 0, jj = ft_ ? (fb_ ? 1 : h - 1) : 0;
+        float4 c0, c1;
+        auto mid = [&](float &x0, float &x1, float &x2, float &x3, float &x4) {
+          if (NG == 2) {
+#if defined(FOTG_STAGE_STAMPS) && FOTG_STAGE_STAMPS == 2
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4));
+            FOTG_BAR();
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4));
+#else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4) :: "memory");
+#endif
+          }
+        };
+        data_term_cell<NOC>(a, ii, jj, pin, hr, hl, vb, vt, duv.x, duv.y, g.hd, g.hg, c0, c1, mid);
+        if (NG == 2) ++nbar;                                       // barrier #(c + TB + 1), executed inside the data term
+        if (inB) {
+          const unsigned co = CBASE + (unsigned)kC * (M * CSLOT) + (unsigned)cb.d * CSLOT + r * 16;
+          *reinterpret_cast<float4 *>(lds + co) = c0;
+          *reinterpret_cast<float4 *>(lds + co + CB) = c1;
+          if (last && a.taps) {                                     // test taps: the last system in the global skewed array
+            float4 *Cg = a.Cp(pair) + a.cidx(iB, r);
+            Cg[0] = c0; Cg[1] = c1;
           }
         }
-        const unsigned co = CBASE + (unsigned)(((sD % RCN) + RCN) % RCN) * CSLOT + r * 16;
-        *reinterpret_cast<float4 *>(lds + co) = c0;
-        *reinterpret_cast<float4 *>(lds + co + CB) = c1;
-        if (last && a.taps && inB) {                                // test taps: the last system in the global skewed array
-          float4 *Cg = a.Cp(pair) + a.cidx(iB, r);
-          Cg[0] = c0; Cg[1] = c1;
-        }
       }
+      if (NG == 2) { cb = ca; nB = nA; } else cb = cell_of(c + 1, nB);
+      ca = cell_of(c + NG + 2, nA);
+      kU = wrapm(kU + NG, NU); kS = wrapm(kS + NG, NSC); kC = wrapm(kC + NG, NCC); kD = wrapm(kD + NG, ND);
     }
     for (; nbar < NI; ++nbar) FOTG_BAR();
     FOTG_STAMP(6);

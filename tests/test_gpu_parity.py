@@ -133,11 +133,16 @@ def test_patchgrid_stages_parity(case, op_point, alley):
         prev_o = fo
 
 
+@pytest.mark.parametrize("stage", ["0", "1"])
 @pytest.mark.parametrize("noc", [1, 3])
-def test_varref_golden_reference_vectors(noc):
+def test_varref_golden_reference_vectors(noc, stage, monkeypatch):
     """VarRefClass against outputs of the reference's own FDF1.0.1 code (tests/golden/fdf_ref_*.npz): every
-    intermediate plane of the last inner iteration and the refined flow, bit for bit"""
+    intermediate plane of the last inner iteration and the refined flow, bit for bit -- through the per-iteration
+    launches / fused levels (stage 0) and through the stage pipeline (stage 1: planes live skewed, taps from the last stage)"""
     F, OFClass, VarRefClass, O = _mods()
+    monkeypatch.setenv("FOTG_VR_STAGE", stage)
+    monkeypatch.setenv("FOTG_VR_STAGE_MINS", "24")
+    before = F.lib().fotg_debug_counter(b"vr_stage")
     for name, c in load_fdf(noc).items():
         im1, im2, wx, wy, lvl = c["im1"], c["im2"], c["wx"], c["wy"], int(c["lvl"])
         _, h, w = im1.shape
@@ -164,6 +169,8 @@ def test_varref_golden_reference_vectors(noc):
         for nm in ("Ix", "Iy", "Iz", "Ixx", "Ixy", "Iyy", "Ixz", "Iyz"):
             assert np.array_equal(plane(nm, noc), c[nm]), (name, nm)
         assert np.array_equal(out[..., 0], c["out_x"]) and np.array_equal(out[..., 1], c["out_y"]), name
+        assert F.lib().fotg_ctx_counter(ofc._h, b"vr_stage_timeouts") == 0
+    assert (F.lib().fotg_debug_counter(b"vr_stage") > before) == (stage == "1")
 
 
 @pytest.mark.parametrize("case,op_point,sor_mode", [("alley", 2, 0), ("alley", 2, 1), ("alley_rgb", 2, 0),
@@ -237,6 +244,7 @@ def test_stage_pipeline(mins, alley, monkeypatch):
     counts, RGB, batches larger than the chip holds at once (tickets), 1 and 2 sweeps; FOTG_VR_STAGE_MINS=24 also sends
     the small coarse levels through it.  No wait may have timed out."""
     F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_STAGE", "1")
     monkeypatch.setenv("FOTG_VR_STAGE_MINS", mins)
     L = F.lib()
     before = L.fotg_debug_counter(b"vr_stage")
@@ -257,10 +265,12 @@ def test_stage_pipeline(mins, alley, monkeypatch):
     assert L.fotg_debug_counter(b"vr_stage") > before
 
 
-def test_stage_pipeline_more_workgroups_than_cus():
+def test_stage_pipeline_more_workgroups_than_cus(monkeypatch):
     """80 pairs x 5 stages = 400 workgroups of one per CU on 256 CUs: the late tickets start when the early ones exit; every pair
     still equals its single-pair result (and pair 0 the oracle)"""
     F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_STAGE", "1")
+    before = F.lib().fotg_debug_counter(b"vr_stage")
     n = 80
     f0, f1 = synth_pair(1080, 1920, seed=77)
     I0 = dev(f0)[None].repeat(n, 1, 1).contiguous(); I1 = dev(f1)[None].repeat(n, 1, 1).contiguous()
@@ -273,6 +283,7 @@ def test_stage_pipeline_more_workgroups_than_cus():
     assert np.array_equal(out[0].cpu().numpy(), O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0))
     assert np.array_equal(out[1].cpu().numpy(), O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0))
     assert F.lib().fotg_ctx_counter(ofc._h, b"vr_stage_timeouts") == 0
+    assert F.lib().fotg_debug_counter(b"vr_stage") > before
 
 
 @pytest.mark.parametrize("mode", ["0", "1"])

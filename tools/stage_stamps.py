@@ -27,6 +27,11 @@ assert hip.hipMemcpy(buf.ctypes.data, C.c_void_p(ptr), buf.nbytes, 2) == 0
 buf = buf[:inner * n].astype(np.int64)
 t0 = buf[:, :, 0][buf[:, :, 0] > 0].min()
 us = lambda x: (x - t0) / 100.0
+r0 = buf[0, 3]; r3 = buf[3 * n, 3] if inner > 3 else r0
+print("   stage-0 loader stamps (I=8,24,40,56,end):", [round(us(x), 1) for x in r0[1:5]], round(us(buf[0, :, 6].max()), 1))
+print("SUMMARY %s: stage-0 interval %.3f us, stage-3 interval %.3f us, stage0 end %.1f, last end %.1f" % (os.path.basename(sys.argv[1]), (r0[4] - r0[1]) / 100.0 / 48, (r3[4] - r3[1]) / 100.0 / 48, us(buf[0, :, 6].max()), us(buf[:, :, 6].max())))
+if os.environ.get("BRIEF"):
+    sys.exit(0)
 print("level 4 stage kernel, batch", n, "-- times in us since the first workgroup started; slots: start | I=8 | I=24 | I=40 | I=56 | solver-done | end")
 for stage in range(inner):
     for pair in (0, n - 1):
