@@ -31,6 +31,8 @@ SYMBOLS = [
     ("fotg_calc_batch_u8", C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp]),
     ("fotg_debug_counter", C.c_long, [C.c_char_p]),
     ("fotg_ctx_counter", C.c_long, [vp, C.c_char_p]),
+    ("fotg_set_verbosity", C.c_int, [vp, C.c_int]),
+    ("fotg_level_timings", C.c_int, [vp, C.c_int, f32p]),
     ("fotg_calc_sequence", C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     ("fotg_calc_sequence_u8", C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     ("fotg_calc", C.c_int, [vp, vp, vp, vp, vp]),

@@ -98,6 +98,12 @@ struct fotg_ctx {
   float *vrQ;
   float2 *vrDS;
   long ds_pair_stride, ds_stage_stride[FOTG_MAXLEV];
+  // verbosity (the reference's op.verbosity, src/oflow.cpp:246-365 / kroeger/oflow.cpp:298-360): > 0 makes the flow calls
+  // synchronous and prints the reference's timing lines from HIP-event times of the stages
+  int verbosity;
+  hipEvent_t tev[4 * FOTG_MAXLEV + 4];
+  float tt[FOTG_MAXLEV][5];          // last measured ms per level: pconst, pinit, poptim, cflow, tvopt
+  float tt_pyr, tt_total;
   int *vrSync;
   int sync_block;                    // which block of vrSync this (view of the) context uses
   void *vrZero;
@@ -207,6 +213,7 @@ void fotg_destroy(fotg_ctx *c)
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (auto &e : c->tev) if (e) (void)hipEventDestroy(e);
   if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   delete c;
@@ -1113,6 +1120,17 @@ static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float 
   int st;
   const bool seq = I1 == nullptr, fb = c->p.usefbcon != 0;
   const int nimg = seq ? n + 1 : n;
+  // stage timing for the reference's verbosity output: events on the launch stream (not while a graph is being captured)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &cap);
+  const bool timing = c->verbosity > 0 && cap == hipStreamCaptureStatusNone;
+  int nev = 0;
+  auto mark = [&]() {
+    if (!timing || nev >= (int)(sizeof(c->tev) / sizeof(c->tev[0]))) return;
+    if (!c->tev[nev] && hipEventCreate(&c->tev[nev]) != hipSuccess) return;
+    (void)hipEventRecord(c->tev[nev++], stream);
+  };
+  mark();
   // the backward grid lives in a view of the context whose grid arrays are the *_bw ones (nothing is owned by the view)
   fotg_ctx *vb = nullptr;
   struct ViewGuard { fotg_ctx *&v; ~ViewGuard() { free(v); } } guard{vb};
@@ -1138,6 +1156,7 @@ static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float 
     free(v1);
     if (st) return st;
   } else if ((st = c->noc == 1 ? pyramid_impl<1, T>(c, nimg, I0, I1, stream) : pyramid_impl<3, T>(c, nimg, I0, I1, stream))) return st;
+  mark();
   for (int l = c->p.sc_f; l >= c->p.sc_l; --l) {
     const long ls = c->lev_stride[l];
     const float *tgt = seq ? c->im[0][l] + ls : c->im[1][l];
@@ -1154,13 +1173,16 @@ static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float 
       } else if (initflow) { if ((st = fotg_grid_init_from_coarser(c, l, n, initflow, stream))) return st; }
       if ((st = fotg_grid_optimize(c, l, n, stream))) return st;
       if ((st = fotg_grid_optimize(vb, l, n, stream))) return st;
+      mark();
       float *out = (l == c->p.sc_l) ? outflow : c->flow[l];
       if ((st = aggregate_impl(c, l, n, c->p_iter[l], c->pweight[l], c->p_iter_bw[l], c->pweight_bw[l], out, stream))) return st;
       if (l > c->p.sc_l && (st = aggregate_impl(c, l, n, c->p_iter_bw[l], c->pweight_bw[l], c->p_iter[l], c->pweight[l], c->flow_bw[l], stream))) return st;
+      mark();
       if (c->p.usetvref) {
         if ((st = varref_dispatch(c, l, n, c->im[0][l], tgt, ls, out, stream, 0))) return st;
         if (l > c->p.sc_l && (st = varref_dispatch(c, l, n, tgt, c->im[0][l], ls, c->flow_bw[l], stream, 1))) return st;
       }
+      mark();
       continue;
     }
     if ((st = fotg_grid_init(c, l, n, c->im[0][l], c->dx0[l], c->dy0[l], c->lev_stride[l], stream))) return st;
@@ -1168,10 +1190,31 @@ static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float 
     if (l < c->p.sc_f) { if ((st = fotg_grid_init_from_coarser(c, l, n, c->flow[l + 1], stream))) return st; }
     else if (initflow) { if ((st = fotg_grid_init_from_coarser(c, l, n, initflow, stream))) return st; }
     if ((st = fotg_grid_optimize(c, l, n, stream))) return st;
+    mark();
     float *out = (l == c->p.sc_l) ? outflow : c->flow[l];
     if ((st = fotg_grid_aggregate(c, l, n, out, stream))) return st;
+    mark();
     if (c->p.usetvref)
       if ((st = varref_dispatch(c, l, n, c->im[0][l], tgt, c->lev_stride[l], out, stream, 0))) return st;
+    mark();
+  }
+  if (timing && nev == 2 + 3 * (c->p.sc_f - c->p.sc_l + 1)) {
+    // The reference's lines (src/oflow.cpp:343, :356; kroeger/oflow.cpp:303, :358), from the GPU times of the stages.  Patch
+    // construction and initialisation from the coarser flow are part of the LK launch here (pconst = pinit = 0 by construction).
+    HIPCHK(hipEventSynchronize(c->tev[nev - 1]));
+    auto ms = [&](int a_, int b_) { float t = 0.f; (void)hipEventElapsedTime(&t, c->tev[a_], c->tev[b_]); return t; };
+    c->tt_pyr = ms(0, 1);
+    c->tt_total = ms(1, nev - 1);
+    int k = 1;
+    for (int l = c->p.sc_f; l >= c->p.sc_l; --l, k += 3) {
+      float *t = c->tt[l];
+      t[0] = 0.f; t[1] = 0.f; t[2] = ms(k, k + 1); t[3] = ms(k + 1, k + 2); t[4] = ms(k + 2, k + 3);
+      if (c->verbosity > 1)
+        printf("TIME (Sc: %i, #p:%6i, pconst, pinit, poptim, cflow, tvopt, total): %8.2f %8.2f %8.2f %8.2f %8.2f -> %8.2f ms.\n", l, c->geom[l].nop * n,
+               t[0], t[1], t[2], t[3], t[4], t[2] + t[3] + t[4]);
+    }
+    printf("TIME (O.Flow Run-Time   ) (ms): %3g\n", c->tt_total);
+    fflush(stdout);
   }
   return FOTG_OK;
 }
@@ -1309,6 +1352,20 @@ long fotg_debug_counter(const char *name)
   if (name && !strcmp(name, "sor_wide")) return g_wide_launches;
   if (name && !strcmp(name, "vr_stage")) return g_stage_launches;
   return -1;
+}
+
+int fotg_set_verbosity(fotg_ctx *c, int verbosity)
+{
+  if (!c) return FOTG_ERR_ARG;
+  c->verbosity = verbosity;
+  return FOTG_OK;
+}
+
+int fotg_level_timings(fotg_ctx *c, int l, float *ms5)
+{
+  if (!c || !ms5 || l < c->p.sc_l || l > c->p.sc_f) return FOTG_ERR_ARG;
+  memcpy(ms5, c->tt[l], 5 * sizeof(float));
+  return FOTG_OK;
 }
 
 long fotg_ctx_counter(fotg_ctx *c, const char *name)

@@ -20,6 +20,17 @@ from .params import img_params, opt_params, padded_size
 
 
 _LIVE = weakref.WeakSet()
+# id(opt_params handed out by an OFClass) -> that OFClass: how PatGridClass(_i_params, _op) and VarRefClass(.., _op, ..) -- the
+# reference's constructor signatures, src/patchgrid.h:16 and src/refine_variational.h:38-39 -- find their engine context
+# (the same registry the C++ shim keeps, include/fotg/patchgrid.h)
+_REGISTRY = weakref.WeakValueDictionary()
+
+
+def _context_of(_op):
+    ofc = _REGISTRY.get(id(_op))
+    if ofc is None or ofc._h is None:
+        raise FotgError("these opt_params do not belong to a live OFClass (use the object's own `ofc.op`, as src/oflow.cpp:101,332 do)")
+    return ofc
 
 
 @atexit.register
@@ -72,6 +83,8 @@ class OFClass:
         check(lib().fotg_create(cp, self.width_org, self.height_org, device, self.max_batch, h))
         self._h = h
         _LIVE.add(self)
+        _REGISTRY[id(self.op)] = self
+        check(lib().fotg_set_verbosity(self._h, int(self.op.verbosity)))
         # per-scale img_params exactly as src/oflow.cpp:84-95
         self.iparams = []
         ps = self.op.patch_size
@@ -81,7 +94,7 @@ class OFClass:
             self.iparams.append(img_params(width=w, height=hh, padding=ps, l_bound=-ps / 2.0,
                                            u_bound_width=float(w + ps // 2 - 2), u_bound_height=float(hh + ps // 2 - 2),
                                            width_pad=w + 2 * ps, height_pad=hh + 2 * ps, scale_fact=2.0 ** -sl, curr_lvl=sl))
-        self.grid = [PatGridClass(self, ip) for ip in self.iparams]
+        self.grid = [PatGridClass(ip, self.op) for ip in self.iparams]        # src/oflow.cpp:101
 
     # -- geometry -------------------------------------------------------------------------------------------
     def out_size(self):
@@ -226,7 +239,9 @@ class PatGridClass:
     """src/patchgrid.h:13-86: the grid of patches of one scale.  Methods take device tensors in the reference's padded
     level layout (h+2ps, w+2ps, channels) with a leading batch dimension."""
 
-    def __init__(self, ofc: OFClass, _i_params: img_params):
+    def __init__(self, _i_params: img_params, _op: opt_params):
+        """src/patchgrid.h:16; `_op` is the owning OFClass's `op` (src/oflow.cpp:101 passes &op)"""
+        ofc = _context_of(_op)
         self._ofc = ofc
         self.i_params = _i_params
         self.lvl = _i_params.curr_lvl
@@ -287,9 +302,14 @@ class PatGridClass:
         return flowout
 
     def printTimings(self):
-        """src/patchgrid.cpp:334-345 prints host-side launch times that never synchronise; per-kernel times here
-        come from rocprofv3 (profiles/)."""
-        print("[timings] use rocprofv3 --kernel-trace --stats (see profiles/)")
+        """src/patchgrid.cpp:334-345, from the GPU times of the last flow call with op.verbosity > 0 (HIP events of the stages
+        on the launch stream): patch extraction and the initialisation from the coarser flow are part of the LK launch"""
+        t = (C.c_float * 5)()
+        check(lib().fotg_level_timings(self._ofc._h, self.lvl, t))
+        print("\n===============Timings (ms)===============")
+        print("[extract]      %g\n[coarse]       %g\n[optiTime]      %g\n[aggregate]    %g\n[flow norm]    %g" % (t[0], t[1], t[2], t[3], 0.0))
+        print("==========================================")
+        return list(t)
 
     # test taps
     def read_state(self, pair=0, taps=False):
@@ -312,7 +332,9 @@ class VarRefClass:
     """src/refine_variational.h:35-57: like the reference, the constructor does all the work, in place on flowout.
     _I0/_I1: padded level images (n, h+2ps, w+2ps, channels) on the device; flowout (n, h, w, 2) on the device."""
 
-    def __init__(self, ofc: OFClass, _I0, _I1, _i_params: img_params, _op: opt_params, flowout):
+    def __init__(self, _I0, _I1, _i_params: img_params, _op: opt_params, flowout):
+        """src/refine_variational.h:38-39; `_op` is the owning OFClass's `op` (src/oflow.cpp:332 passes &op)"""
+        ofc = _context_of(_op)
         n = flowout.shape[0] if isinstance(flowout, torch.Tensor) and flowout.dim() == 4 else 0
         if n < 1 or n > ofc.max_batch:
             raise FotgError("flowout must be (n, h, w, %d) with 1 <= n <= max_batch" % ofc.nch)

@@ -102,6 +102,16 @@ int fotg_calc(fotg_ctx *ctx, const float *I0, const float *I1, const float *init
  * padding.  in: n x hl x wl x 2 (device), out: n x h_org x w_org x 2 (device). */
 int fotg_upsample_crop(fotg_ctx *ctx, int n, const float *flow, float *out, void *stream);
 
+/* op.verbosity of the reference (src/oflow.cpp:246-365, kroeger/oflow.cpp:298-360).  0 (default): silent, asynchronous.
+ * > 0: every flow call (fotg_calc, fotg_calc_batch, ...) waits for its launches and prints "TIME (O.Flow Run-Time   ) (ms): ..."
+ * (the flow without the pyramid, like the reference); > 1: also one "TIME (Sc: .., #p: .., pconst, pinit, poptim, cflow, tvopt,
+ * total): ..." line per scale, from HIP-event times of the stages on the launch stream (patch construction and initialisation
+ * are part of the LK launch: pconst = pinit = 0). */
+int fotg_set_verbosity(fotg_ctx *ctx, int verbosity);
+/* the five times (ms) of `level` measured by the last flow call with verbosity > 0: pconst, pinit, poptim, cflow, tvopt
+ * (PatGridClass::printTimings, src/patchgrid.cpp:334-345, prints from these) */
+int fotg_level_timings(fotg_ctx *ctx, int level, float *ms5);
+
 /* geometry queries */
 int fotg_level_size(const fotg_ctx *ctx, int level, int *w, int *h);        /* unpadded level size */
 int fotg_out_size(const fotg_ctx *ctx, int *w, int *h);                     /* finest-scale flow size */

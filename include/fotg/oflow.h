@@ -14,6 +14,7 @@
 #include <vector>
 #include "params.h"
 #include "patchgrid.h"
+#include "refine_variational.h"
 
 namespace OFC {
 
@@ -27,6 +28,8 @@ class OFClass {
     op.n_scales = op.coarsest_scale - op.finest_scale + 1;
     fotg_params p = to_fotg(op);
     fotgCheck(fotg_create(&p, _i_params.width, _i_params.height, device, max_batch, &ctx), "OFClass");
+    fotgCheck(fotg_set_verbosity(ctx, op.verbosity), "OFClass");
+    ContextRegistry::get().add(&op, ctx);                 // every grid / VarRefClass built from &op finds this context
     int Wp, Hp;
     fotg_padded_size(_i_params.width, _i_params.height, op.coarsest_scale, &Wp, &Hp, nullptr, nullptr);
     iparams.resize(op.n_scales);
@@ -44,19 +47,25 @@ class OFClass {
       iparams[i].height_pad = iparams[i].height + 2 * op.patch_size;
       iparams[i].curr_lvl = sl;
     }
-    for (int i = 0; i < op.n_scales; ++i) grid[i] = new PatGridClass(ctx, &iparams[i], &op);
+    for (int i = 0; i < op.n_scales; ++i) grid[i] = new PatGridClass(&iparams[i], &op);   // src/oflow.cpp:101
   }
   ~OFClass()
   {
     for (auto g : grid) delete g;
+    ContextRegistry::get().remove(&op);
     fotg_destroy(ctx);
   }
   OFClass(const OFClass &) = delete;
   OFClass &operator=(const OFClass &) = delete;
 
-  // src/oflow.cpp:211-368
+  // src/oflow.cpp:211-368 (with op.verbosity > 0 the library prints the reference's TIME lines; > 1 also the grids' tables,
+  // src/oflow.cpp:362-366)
   void calc(const float *_I0, const float *_I1, img_params /*_iparams*/, const float *initflow, float *outflow)
-  { fotgCheck(fotg_calc(ctx, _I0, _I1, initflow, outflow), "OFClass::calc"); }
+  {
+    fotgCheck(fotg_calc(ctx, _I0, _I1, initflow, outflow), "OFClass::calc");
+    if (op.verbosity > 1)
+      for (auto &g : grid) g->printTimings();
+  }
   // n pairs, device output, asynchronous on `stream` (hipStream_t)
   void calc_batch(int n, const float *_I0, const float *_I1, const float *initflow, float *outflow_dev, void *stream = nullptr)
   { fotgCheck(fotg_calc_batch(ctx, n, _I0, _I1, initflow, outflow_dev, stream), "OFClass::calc_batch"); }
@@ -67,22 +76,13 @@ class OFClass {
   fotg_ctx *handle() { return ctx; }
   PatGridClass *GetGrid(int scale) { return grid[scale - op.finest_scale]; }
   const img_params &GetImgParams(int scale) const { return iparams[scale - op.finest_scale]; }
+  const opt_params &GetOptParams() const { return op; }     // the opt_params every grid / VarRefClass of this object is built from
 
  private:
   opt_params op;
   std::vector<img_params> iparams;
   std::vector<PatGridClass *> grid;
   fotg_ctx *ctx = nullptr;
-};
-
-// src/refine_variational.h:35-57: the constructor does all the work, in place on flowout (device pointer)
-class VarRefClass {
- public:
-  VarRefClass(OFClass &ofc, const float *_I0, const float *_I1, const img_params *_i_params, const opt_params *_op, float *flowout)
-  {
-    const long stride = (long)_i_params->width_pad * _i_params->height_pad * _op->channels;
-    fotgCheck(fotg_varref(ofc.handle(), _i_params->curr_lvl, 1, _I0, _I1, stride, flowout, nullptr), "VarRefClass");
-  }
 };
 
 }  // namespace OFC

@@ -109,7 +109,7 @@ def test_depth_varref_golden_reference_vectors(noc):
             w0 = (-np.abs(wx) if camlr == 0 else np.abs(wx)).astype(np.float32)
             flow = dev(w0[..., None])[None].contiguous()
             ofc.grid[0].SetCamera(camlr)
-            VarRefClass(ofc, dev(padlvl(im1))[None], dev(padlvl(im2))[None], ofc.iparams[0], op, flow)
+            VarRefClass(dev(padlvl(im1))[None], dev(padlvl(im2))[None], ofc.iparams[0], ofc.op, flow)
             for nm in ("sh", "sv", "a11", "b1", "du"):
                 assert np.array_equal(plane(nm), z["%s/%s_de%d" % (name, nm, camlr)]), (name, nm, camlr)
             assert np.array_equal(flow[0, ..., 0].cpu().numpy(), z["%s/out_de%d" % (name, camlr)]), (name, camlr)
@@ -137,7 +137,7 @@ def test_depth_varref_sizes(w, h, solverit, path, monkeypatch):
     p = oracle_params(O, op)
     ref = O.varref_depth(pad(f0), pad(f1), w, h, lvl, p, wx[..., None], 0)
     flow = dev(np.stack([wx[..., None]] * n))
-    VarRefClass(ofc, dev(np.stack([pad(f0)] * n)), dev(np.stack([pad(f1)] * n)), ofc.iparams[0], op, flow)
+    VarRefClass(dev(np.stack([pad(f0)] * n)), dev(np.stack([pad(f1)] * n)), ofc.iparams[0], ofc.op, flow)
     got = flow.cpu().numpy()
     assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
     assert (ref != wx[..., None]).mean() > 0.5

@@ -153,7 +153,7 @@ def test_varref_golden_reference_vectors(noc, stage, monkeypatch):
         padlvl = lambda a: np.pad(a.transpose(1, 2, 0), ((ps, ps), (ps, ps), (0, 0)), mode="edge")
         flow = dev(np.stack([wx, wy], -1))[None].contiguous()
         F.lib().fotg_enable_taps(ofc._h, 1)     # solver planes of on-chip levels are only written back for taps
-        VarRefClass(ofc, dev(padlvl(im1))[None], dev(padlvl(im2))[None], ofc.iparams[0], op, flow)
+        VarRefClass(dev(padlvl(im1))[None], dev(padlvl(im2))[None], ofc.iparams[0], ofc.op, flow)
         out = flow[0].cpu().numpy()
         st = ((w + 3) // 4) * 4
 
@@ -801,3 +801,58 @@ def test_cpp_shim_run_dense_example(tmp_path):
         r = subprocess.run([exe, p0, p1, str(w), str(h), str(noc), out, "2"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         assert np.array_equal(read_flo(out), O.full_flow(f0, f1, op=2)), noc
+
+
+def test_cpp_shim_reference_scale_loop(tmp_path):
+    """examples/oflow_scale_loop.cpp: the reference's scale loop written with the shim classes, grids and VarRefClass constructed
+    with the reference's own constructor signatures (src/oflow.cpp:101, :332; the context comes from the registry), equals
+    OFClass::calc (exit code 0) and the oracle; with verbosity 2 the reference's TIME lines come out (src/oflow.cpp:343, :356)"""
+    import subprocess
+    from test_host import _build_example
+    F, OFClass, _, O = _mods()
+    exe = _build_example(tmp_path, "oflow_scale_loop")
+    h, w = 272, 480
+    f0, f1 = synth_pair(h, w, seed=78)
+    p0, p1, out = (str(tmp_path / n) for n in ("f0.raw", "f1.raw", "out.raw"))
+    f0.astype(np.float32).tofile(p0)
+    f1.astype(np.float32).tofile(p1)
+    r = subprocess.run([exe, p0, p1, str(w), str(h), "1", out, "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "scale loop by hand == OFClass::calc" in r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith("TIME (Sc:")]
+    assert len(lines) == 3 and "TIME (O.Flow Run-Time   ) (ms):" in r.stdout and "[optiTime]" in r.stdout, r.stdout
+    p = O.op_point(2, w, 1)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    got = np.fromfile(out, np.float32).reshape(ref.shape)
+    assert np.array_equal(got, ref)
+
+
+def test_verbosity_prints_the_reference_timing_lines(capfd):
+    """op.verbosity (src/oflow.cpp:246-365, kroeger/oflow.cpp:298-360): 1 -> "TIME (O.Flow Run-Time   ) (ms): ..", 2 -> also one
+    "TIME (Sc: l, #p: n, pconst, pinit, poptim, cflow, tvopt, total): .." line per scale, coarsest first, with GPU times of
+    the stages; PatGridClass.printTimings (src/patchgrid.cpp:334-345) prints the same numbers; the flow is unchanged"""
+    import re
+    F, OFClass, _, O = _mods()
+    f0, f1 = synth_pair(272, 480, seed=5)
+    op = F.operating_point(2, 480, 1)
+    quiet = OFClass(op, F.img_params(width=480, height=272, padding=8)).calc(dev(f0), dev(f1)).cpu().numpy()
+    capfd.readouterr()
+    op.verbosity = 2
+    ofc = OFClass(op, F.img_params(width=480, height=272, padding=8))
+    out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+    txt = capfd.readouterr().out
+    assert np.array_equal(out, quiet)
+    rows = re.findall(r"TIME \(Sc: (\d+), #p:\s*(\d+), pconst, pinit, poptim, cflow, tvopt, total\):\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+) ->\s+([\d.]+) ms\.", txt)
+    assert [int(r[0]) for r in rows] == list(range(ofc.op.coarsest_scale, ofc.op.finest_scale - 1, -1)), txt
+    assert [int(r[1]) for r in rows] == [g.GetNumPatches() for g in reversed(ofc.grid)]
+    for r in rows:
+        t = [float(x) for x in r[2:]]
+        assert t[0] == 0 and t[1] == 0 and t[2] > 0 and t[4] > 0 and abs(t[2] + t[3] + t[4] - t[5]) < 0.02
+    assert re.search(r"TIME \(O\.Flow Run-Time   \) \(ms\): [\d.e+-]+", txt)
+    tt = ofc.grid[0].printTimings()
+    assert "[optiTime]" in capfd.readouterr().out and tt[2] > 0
+    op.verbosity = 1
+    ofc1 = OFClass(op, F.img_params(width=480, height=272, padding=8))
+    ofc1.calc(dev(f0), dev(f1))
+    txt = capfd.readouterr().out
+    assert "TIME (O.Flow Run-Time" in txt and "TIME (Sc:" not in txt

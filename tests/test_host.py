@@ -119,13 +119,32 @@ def test_pfm_writer_matches_reference_file_layout(tmp_path):
         write_pfm(path, np.zeros((3, 3, 2), np.float32))
 
 
-def _build_example(tmpdir):
+def _build_example(tmpdir, name="run_dense_min"):
     import subprocess
-    exe = os.path.join(str(tmpdir), "run_dense_min")
+    exe = os.path.join(str(tmpdir), name)
     libdir = os.path.join(ROOT, "flowonthego_amd")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "run_dense_min.cpp"),
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".cpp"),
                            "-L" + libdir, "-lfotg", "-Wl,-rpath," + libdir, "-o", exe], stderr=subprocess.DEVNULL)
     return exe
+
+
+def test_cpp_shim_reference_constructor_signatures(tmp_path):
+    """a reference-side file that builds its own grids and refinement objects compiles against include/fotg/: the constructors
+    have the reference's signatures -- PatGridClass(const img_params*, const opt_params*) (src/patchgrid.h:16, called like
+    src/oflow.cpp:101), VarRefClass(const float*, const float*, const img_params*, const opt_params*, float*)
+    (src/refine_variational.h:38-39, called like src/oflow.cpp:332) -- and dev_patch_state has the fields of src/patch.h:15-36"""
+    import flowonthego_amd as F
+    F.lib()
+    exe = _build_example(tmp_path, "oflow_scale_loop")
+    assert os.path.exists(exe)
+    hdr = open(os.path.join(ROOT, "include", "fotg", "patchgrid.h")).read()
+    assert "PatGridClass(const img_params *_i_params, const opt_params *_op)" in hdr
+    hdr = open(os.path.join(ROOT, "include", "fotg", "refine_variational.h")).read()
+    assert "VarRefClass(const float *_I0, const float *_I1, const img_params *_i_params, const opt_params *_op, float *flowout)" in hdr
+    ref = open(os.path.join(ROOT, "include", "fotg", "patch.h")).read()
+    for field in ("has_converged", "has_opt_started", "H00, H01, H11", "p_orgx, p_orgy", "p_curx, p_cury", "delta_px, delta_py",
+                  "midpoint_curx, midpoint_cury", "midpoint_orgx, midpoint_orgy", "delta_p_sq_norm_init", "mares_old", "count", "invalid", "cost"):
+        assert field in ref, field
 
 
 def test_cpp_shim_example_builds(tmp_path):
