@@ -388,23 +388,23 @@ def main():
         print(json.dumps(res))
     if dist and a.scatter_gather:
         # end to end with the frames starting on rank 0 and the flows ending there (RCCL over xGMI: scatter + gather only)
-        from flowonthego_amd.shard import gather_flows, scatter_pairs
+        # chunked, double-buffered: chunk t+1 travels (grouped ncclSend/ncclRecv) while chunk t is computed; nothing is padded
+        from flowonthego_amd.shard import gather_flows_exact, pipelined_scatter_compute
         G0 = G1 = None
         if rank == 0:
             G0, G1 = I0.repeat((world,) + (1,) * (I0.dim() - 1)), I1.repeat((world,) + (1,) * (I1.dim() - 1))
+        chunk = max(1, a.batch // 4)
         barrier()
         t0 = time.perf_counter()
-        S0, S1, _ = scatter_pairs(G0, G1, td, src=0, device=dev)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ofc.calc_batch(S0.contiguous(), S1.contiguous(), None, out)
+        flows, _ = pipelined_scatter_compute(G0, G1, world * a.batch, tuple(I0.shape[1:]), I0.dtype, td,
+                                             lambda x, y: ofc.calc_batch(x.contiguous(), y.contiguous()), chunk, src=0, device=dev)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        full = gather_flows(out, world * a.batch, td, dst=0)
+        full = gather_flows_exact(flows, world * a.batch, td, dst=0)
         barrier()
         t3 = time.perf_counter()
         if rank == 0:
-            print(json.dumps({"scatter_gather": {"scatter_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3, "gather_ms": (t3 - t2) * 1e3,
+            print(json.dumps({"scatter_gather": {"scatter_plus_compute_ms": (t2 - t0) * 1e3, "gather_ms": (t3 - t2) * 1e3, "chunk_pairs": chunk,
                                                  "end_to_end_pairs_per_s": world * a.batch / (t3 - t0), "gathered_shape": list(full.shape)}}))
     if dist:
         td.barrier()

@@ -69,3 +69,100 @@ def gather_flows(flow, n_pairs: int, dist, dst: int = 0):
         b, e = shard_range(n_pairs, r, world)
         out.append(parts[r][: e - b])
     return torch.cat(out)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Pipelined scatter ("grouped send/recv scatter of input frames from rank 0, pipelined in chunks under compute"):
+# rank `src` holds the whole batch; every rank's contiguous shard (shard_range) is cut into chunks of at most `chunk` pairs;
+# in step t every peer receives chunk t of its shard (one grouped batch_isend_irecv: RCCL ncclSend/ncclRecv groups on GPUs,
+# gloo on CPU) into one of two buffers while it computes on chunk t-1 from the other.  Nothing is padded and rank `src` never
+# builds a second copy of the batch: it sends views of its tensors and computes on views of its own shard.
+# ----------------------------------------------------------------------------------------------------------------------
+def chunk_plan(n_pairs: int, world: int, chunk: int):
+    """steps[t][rank] = (begin, end) of the pairs rank `rank` receives (src: computes on) in step t, or None when its shard is
+    exhausted; every pair appears exactly once, in order within a rank, chunks of <= `chunk` pairs"""
+    if chunk < 1:
+        raise ValueError("chunk must be >= 1")
+    ranges = [shard_range(n_pairs, r, world) for r in range(world)]
+    nsteps = max(-(-(e - b) // chunk) for b, e in ranges) if n_pairs else 0
+    steps = []
+    for t in range(nsteps):
+        row = []
+        for b, e in ranges:
+            lo = b + t * chunk
+            row.append((lo, min(e, lo + chunk)) if lo < e else None)
+        steps.append(row)
+    return steps
+
+
+def pipelined_scatter_compute(I0, I1, n_pairs, frame_shape, dtype, dist, compute, chunk: int, src: int = 0, device=None):
+    """Runs `compute(I0_chunk, I1_chunk) -> flow_chunk` over this rank's shard while the NEXT chunk is in flight from rank
+    `src` (double buffered).  I0 / I1: the whole batch on rank `src`, None elsewhere.  Returns this rank's flows (shard order)
+    and its (begin, end).  `compute` must have finished reading its arguments when it returns a tensor that is later read
+    (stream order on GPUs: the receive buffer of step t is only overwritten in step t+2, after a wait on the transfer of t+2
+    was issued behind the compute of t on the same stream by the caller's synchronisation point below)."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    steps = chunk_plan(n_pairs, world, chunk)
+    b0, e0 = shard_range(n_pairs, rank, world)
+    bufs = None
+    if rank != src:
+        bufs = [torch.empty((2, chunk) + tuple(frame_shape), dtype=dtype, device=device) for _ in range(2)]
+    flows = []
+
+    def launch(t):
+        ops = []
+        if rank == src:
+            for r in range(world):
+                if r == src or steps[t][r] is None:
+                    continue
+                lo, hi = steps[t][r]
+                ops.append(dist.P2POp(dist.isend, I0[lo:hi], r))
+                ops.append(dist.P2POp(dist.isend, I1[lo:hi], r))
+        elif steps[t][rank] is not None:
+            lo, hi = steps[t][rank]
+            ops.append(dist.P2POp(dist.irecv, bufs[t % 2][0, : hi - lo], src))
+            ops.append(dist.P2POp(dist.irecv, bufs[t % 2][1, : hi - lo], src))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    pending = launch(0) if steps else []
+    for t in range(len(steps)):
+        for req in pending:                      # chunk t has arrived
+            req.wait()
+        pending = launch(t + 1) if t + 1 < len(steps) else []      # chunk t+1 travels while chunk t is computed
+        if steps[t][rank] is None:
+            continue
+        lo, hi = steps[t][rank]
+        if rank == src:
+            a, b = I0[lo:hi], I1[lo:hi]
+        else:
+            a, b = bufs[t % 2][0, : hi - lo], bufs[t % 2][1, : hi - lo]
+        flows.append(compute(a, b).clone())
+        if device is not None and str(device).startswith("cuda"):
+            torch.cuda.current_stream(device).synchronize()       # the buffer of step t is free again before step t+2 receives into it
+    out = torch.cat(flows) if flows else None
+    return out, (b0, e0)
+
+
+def gather_flows_exact(flow, n_pairs: int, dist, dst: int = 0):
+    """gather of the flows without padding: every rank sends exactly its shard (grouped send/recv), rank `dst` returns
+    (n_pairs, ...) in pair order"""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank != dst:
+        if flow is not None and flow.shape[0] > 0:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, flow.contiguous(), dst)]):
+                req.wait()
+        return None
+    tail = tuple(flow.shape[1:])
+    out = torch.empty((n_pairs,) + tail, dtype=flow.dtype, device=flow.device)
+    ops = []
+    for r in range(world):
+        b, e = shard_range(n_pairs, r, world)
+        if r == dst:
+            out[b:e] = flow
+        elif e > b:
+            ops.append(dist.P2POp(dist.irecv, out[b:e], r))
+    for req in (dist.batch_isend_irecv(ops) if ops else []):
+        req.wait()
+    return out

@@ -46,6 +46,13 @@ def alley():
 
 
 @pytest.fixture(scope="session")
+def natural_images():
+    """the reference's natural test images as 8-bit gray: road_HD (1080, 1920), yosemite_4k (2160, 3840)"""
+    z = np.load(os.path.join(GOLDEN, "natural_images.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
 def alley_golden_flow():
     return np.load(os.path.join(GOLDEN, "alley_0001_flo.npz"))["flow"]
 

@@ -11,6 +11,9 @@ plain data and travel to the GPU box.
   fdf_ref_rgb.npz       variational-refinement chain (kroeger/refine_variational.cpp:153-241):
                         every intermediate plane of the last inner iteration + the refined flow
   fdf_ref_depth_*.npz   the same inputs through the reference's stereo-depth chain (RefLevelDE, :243-330)
+  natural_images.npz    the reference's natural test images as 8-bit gray (same formula): images/road_HD.jpg (1920x1080) and
+                        images/yosemite_4k.jpg (3840x2160) -- the inputs SURVEY.md 8(d) names for C2-C4 (the second frame of
+                        a pair is a shifted copy, made by the test)
 """
 import os
 import sys
@@ -111,6 +114,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "fdf_ref_rgb.npz"), **fdf_cases(3))
     np.savez_compressed(os.path.join(OUT, "fdf_ref_depth_gray.npz"), **depth_cases(1))
     np.savez_compressed(os.path.join(OUT, "fdf_ref_depth_rgb.npz"), **depth_cases(3))
+    np.savez_compressed(os.path.join(OUT, "natural_images.npz"), road_HD=gray_cv(rgb(REF + "/images/road_HD.jpg")),
+                        yosemite_4k=gray_cv(rgb(REF + "/images/yosemite_4k.jpg")))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

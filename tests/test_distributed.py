@@ -9,7 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from flowonthego_amd.shard import gather_flows, max_over_ranks, scatter_pairs, shard_range
+from flowonthego_amd.shard import (chunk_plan, gather_flows, gather_flows_exact, max_over_ranks, pipelined_scatter_compute,
+                                   scatter_pairs, shard_range)
 
 
 def test_shard_ranges():
@@ -91,3 +92,68 @@ def test_two_rank_scatter_gather_gloo(n_pairs):
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def test_chunk_plan_covers_every_pair_once():
+    """the chunk scheduler of the pipelined scatter: every pair exactly once, in order within a rank, chunks <= chunk,
+    BASELINE configs[4] (512 pairs over 8 ranks in chunks of 16) takes 4 steps of 16 pairs per rank"""
+    for n in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            for chunk in (1, 3, 16, 64):
+                steps = chunk_plan(n, world, chunk)
+                for r in range(world):
+                    got = [k for row in steps if row[r] is not None for k in range(*row[r])]
+                    assert got == list(range(*shard_range(n, r, world)))
+                    assert all(row[r] is None or 0 < row[r][1] - row[r][0] <= chunk for row in steps)
+                    seen_none = False
+                    for row in steps:                     # a rank's chunks are contiguous steps from 0
+                        assert not (seen_none and row[r] is not None)
+                        seen_none |= row[r] is None
+    steps = chunk_plan(512, 8, 16)
+    assert len(steps) == 4 and steps[1][3] == (192 + 16, 192 + 32)
+    with pytest.raises(ValueError):
+        chunk_plan(8, 2, 0)
+
+
+def _pipe_worker(rank, world, port, n_pairs, chunk, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    I0 = I1 = None
+    if rank == 0:
+        I0 = torch.arange(n_pairs, dtype=torch.float32).view(-1, 1, 1).expand(n_pairs, 6, 8).contiguous()
+        I1 = I0 + 100
+    calls = []
+
+    def compute(a, b):                                    # stand-in engine: a "flow" that identifies its pair
+        calls.append(a.shape[0])
+        return torch.stack([a[:, :3, :4], b[:, :3, :4]], -1)
+
+    flow, (lo, hi) = pipelined_scatter_compute(I0, I1, n_pairs, (6, 8), torch.float32, dist, compute, chunk, src=0)
+    ok = (lo, hi) == shard_range(n_pairs, rank, world) and sum(calls) == hi - lo and max(calls, default=0) <= chunk
+    ok = ok and all(float(flow[k, 0, 0, 0]) == lo + k and float(flow[k, 0, 0, 1]) == 100 + lo + k for k in range(hi - lo))
+    full = gather_flows_exact(flow, n_pairs, dist, dst=0)
+    if rank == 0:
+        ok = ok and full.shape == (n_pairs, 3, 4, 2) and all(float(full[k, 0, 0, 0]) == k and float(full[k, 0, 0, 1]) == 100 + k for k in range(n_pairs))
+    else:
+        ok = ok and full is None
+    dist.barrier()
+    q.put((rank, bool(ok), calls))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs,chunk", [(8, 2), (7, 3), (9, 16)])
+def test_two_rank_pipelined_scatter_gloo(n_pairs, chunk):
+    """chunked, double-buffered scatter under compute (batch_isend_irecv; RCCL send/recv groups on GPUs) + unpadded gather:
+    every pair computed once, in order, in chunks of <= chunk, the flows arrive on rank 0 in pair order"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, n_pairs, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res

@@ -856,3 +856,82 @@ def test_verbosity_prints_the_reference_timing_lines(capfd):
     ofc1.calc(dev(f0), dev(f1))
     txt = capfd.readouterr().out
     assert "TIME (O.Flow Run-Time" in txt and "TIME (Sc:" not in txt
+
+
+def test_natural_images_1080p(natural_images):
+    """SURVEY 8(d) inputs for C2 / C3: the reference's images/road_HD.jpg (1920x1080) and a copy rolled by (2, 5) -- op-pt 2 with
+    and without refinement against the oracle bit for bit, the recovered flow is the shift; and a 1080p crop of
+    images/yosemite_4k.jpg with a sub-pixel warp"""
+    F, OFClass, _, O = _mods()
+    a = natural_images["road_HD"].astype(np.float32)
+    b = np.roll(a, (2, 5), axis=(0, 1))
+    for refine in (True, False):
+        op = F.operating_point(2, 1920, 1)
+        op.use_var_ref = refine
+        ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=8))
+        out = ofc.calc(dev(a), dev(b)).cpu().numpy()
+        p = oracle_params(O, op)
+        ref = O.flow(O.pad_frame(a, p.sc_f), O.pad_frame(b, p.sc_f), p, 0)
+        assert np.array_equal(out, ref), refine
+        full = ofc.upsample_crop(torch.from_numpy(out[None]).cuda())[0].cpu().numpy()
+        med = np.median(full[100:-100, 100:-100].reshape(-1, 2), axis=0)
+        assert abs(med[0] - 5) < 0.6 and abs(med[1] - 2) < 0.6, med
+        ofc.close()
+    y = natural_images["yosemite_4k"][540:1620, 960:2880].astype(np.float32)
+    y1 = np.round(0.5 * (np.roll(y, (1, 3), axis=(0, 1)) + np.roll(y, (1, 4), axis=(0, 1))))      # shift (3.5, 1), 8-bit grid
+    op = F.operating_point(2, 1920, 1)
+    ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=8))
+    out = ofc.calc(dev(y), dev(y1)).cpu().numpy()
+    p = oracle_params(O, op)
+    assert np.array_equal(out, O.flow(O.pad_frame(y, p.sc_f), O.pad_frame(y1, p.sc_f), p, 0))
+
+
+def test_natural_image_4k_quality_preset(natural_images):
+    """BASELINE configs[3] on its named input: images/yosemite_4k.jpg (3840x2160) and a shifted copy, op-pt 4
+    (ps 12, stride 3, scales 7..2, 128 LK iterations, refinement on 960x544) -- bit-identical to the oracle"""
+    F, OFClass, _, O = _mods()
+    a = natural_images["yosemite_4k"].astype(np.float32)
+    b = np.roll(a, (3, 7), axis=(0, 1))
+    op = F.operating_point(4, 3840, 1)
+    ofc = OFClass(op, F.img_params(width=3840, height=2160, padding=12))
+    got = ofc.calc(dev(a), dev(b)).cpu().numpy()
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(a, p.sc_f), O.pad_frame(b, p.sc_f), p, 0)
+    assert got.shape == (544, 960, 2) and np.array_equal(got, ref)
+    full = ofc.upsample_crop(torch.from_numpy(got[None]).cuda())[0].cpu().numpy()
+    med = np.median(full[200:-200, 200:-200].reshape(-1, 2), axis=0)
+    assert abs(med[0] - 7) < 0.6 and abs(med[1] - 3) < 0.6, med
+
+
+def test_golden_flo_on_the_coarse_grid(alley, alley_golden_flow):
+    """the reference's golden kroeger/flows/alley_0001.flo compared where the engine computes: on the 128x56 finest-scale grid.
+    The .flo is the coarse flow x 8, bilinearly upsampled (src coordinate (d + 0.5) / 8 - 0.5) and cropped by 6 rows
+    (kroeger/run_dense.cpp:407-414); along each axis the mean of the two full-resolution pixels around a coarse sample k is
+    c_k + (c_{k-1} - 2 c_k + c_{k+1}) / 32, a tridiagonal system that is solved for the coarse field (interior samples: the
+    crop removes the pixels around the first and last coarse row).  Reported in coarse-grid pixels (the unit the engine's
+    output has) and full-resolution pixels (x 8); the residual is the golden file's own (pin 2)."""
+    import scipy.linalg
+    F, OFClass, _, O = _mods()
+    f0, f1, _ = frames("alley", alley)
+    op = F.operating_point(2, 1024, 1)
+    ofc = OFClass(op, F.img_params(width=1024, height=436, padding=8))
+    coarse = ofc.calc(dev(f0), dev(f1)).cpu().numpy()                    # (56, 128, 2), rows of the padded 448-row frame
+    g = alley_golden_flow.astype(np.float64)                              # (436, 1024, 2), full-resolution px
+
+    def deinterp(m):                                                      # m[k] = c_k + (c_{k-1} - 2 c_k + c_{k+1}) / 32 along axis 0, replicate ends
+        n = m.shape[0]
+        ab = np.zeros((3, n)); ab[0, 1:] = 1 / 32; ab[1, :] = 1 - 2 / 32; ab[2, :-1] = 1 / 32
+        ab[1, 0] += 1 / 32; ab[1, -1] += 1 / 32
+        return scipy.linalg.solve_banded((1, 1), ab, m)
+    # columns: coarse sample k sits between full-resolution columns 8k+3 and 8k+4 (no horizontal crop)
+    cols = 0.5 * (g[:, 3::8] + g[:, 4::8])                                # (436, 128, 2)
+    cols = np.moveaxis(deinterp(np.moveaxis(cols, 1, 0)), 0, 1)
+    # rows: coarse row j sits between padded rows 8j+3, 8j+4 = cropped rows 8j-3, 8j-2: j = 1 .. 54
+    rows = 0.5 * (cols[5:429:8] + cols[6:430:8])                          # j = 1 .. 53 -> (53, 128, 2)
+    assert rows.shape[0] == 53
+    gold_coarse = deinterp(rows) / 8.0                                    # (edge rows of this system are approximate: dropped below)
+    ours = coarse[1:54].astype(np.float64)
+    e = np.sqrt(((ours - gold_coarse)[2:-2] ** 2).sum(-1))
+    print("coarse-grid EPE vs alley_0001.flo: mean %.5f px (coarse) = %.4f px full resolution, p99 %.4f, max %.4f (coarse px)"
+          % (e.mean(), 8 * e.mean(), np.percentile(e, 99), e.max()))
+    assert e.mean() < 0.03 / 8 * 1.5 and np.percentile(e, 99) < 0.2 / 8 * 1.5
