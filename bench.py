@@ -114,7 +114,7 @@ def roofline(ofc, I0, I1, lib, stream_ptr, batch):
     alg = batch * (2 * W * H * 4 + 2 * lw * lh * 4)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             k = json.load(f)["kernels"]
         key = [x for x in k if "pyr_base_kernel<float, 1, 4, true>" in x]
         if key and batch == 64:
@@ -125,6 +125,38 @@ def roofline(ofc, I0, I1, lib, stream_ptr, batch):
     return {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,1,4,true> (frames -> pyramid level 4, both frames of the batch in one launch)",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms}
+
+
+def roofline_dominant(ofc, lib, stream_ptr, batch, stage_ms):
+    """The kernel that holds most of the step's time: one sor_coupled call of the finest level (vr_sor_stream_kernel, launched
+    once per inner iteration: 5 x at level 4).  Algorithmic bytes per launch = batch x w x h x (32 B system cell read + 8 B (du,dv)
+    read + 8 B written); duration: HIP events around that launch alone on the launch stream.  It is a
+    dependency chain (w + h + 15 lock-stepped anti-diagonals), so the HBM roof is the nearest of the two the contract names,
+    not what bounds it -- `bound_by` says so."""
+    from flowonthego_amd._lib import check
+    ev = HipEvents()
+    lvl = ofc.op.finest_scale
+    lw, lh = ofc.width >> lvl, ofc.height >> lvl
+    ms = ev.time_ms(lambda: check(lib.fotg_bench_sor_call(ofc._h, lvl, batch, stream_ptr)), stream_ptr, 20)
+    alg = batch * lw * lh * 48
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+        key = [x for x in k if "vr_sor_stream_kernel" in x]
+        if key and batch == 64:
+            traffic = k[key[0]]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    inner = lvl + 1
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "fotg::vr_sor_stream_kernel<72,70,4,32> (one sor_coupled call = 3 lexicographic sweeps of the %dx%d level, "
+                                      "one workgroup per pair; %d launches per step)" % (lw, lh, inner),
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_per_step": inner,
+            "share_of_step": inner * ms / sum(stage_ms.values()),
+            "bound_by": "dependency-chain latency: %d anti-diagonal steps in lock step (~%.0f ns each), one workgroup = one CU per pair; "
+                        "the data it touches is L2 resident" % (lw + lh - 1 + 16, ms * 1e6 / (lw + lh - 1 + 16))}
 
 
 def cpu_baseline(I0, I1, budget_s=12.0):
@@ -297,6 +329,8 @@ def main():
             st = stage_breakdown(ofc, I0, I1, out, lib, stream_ptr)
             res["stage_ms"] = {k: round(v, 4) for k, v in st.items()}
             res["roofline"] = roofline(ofc, I0, I1, lib, stream_ptr, a.batch)
+            if op.use_var_ref and a.sor_mode == 0:
+                res["roofline_dominant"] = roofline_dominant(ofc, lib, stream_ptr, a.batch, st)
             # the whole path against the same roof: pairs/s x 16 654 080 B / 8 TB/s
             res["whole_path_hbm_frac"] = value / world * (2 * W * H * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS
             res["time_dominant_stage"] = max(st, key=st.get)

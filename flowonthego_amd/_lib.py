@@ -54,6 +54,7 @@ SYMBOLS = [
     ("fotg_grid_set_trace", C.c_int, [vp, C.c_int, vp]),
     ("fotg_varref", C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_long, vp, vp]),
     ("fotg_varref_plane", C.c_int, [vp, C.c_int, C.c_char_p, C.c_int, vp]),
+    ("fotg_bench_sor_call", C.c_int, [vp, C.c_int, C.c_int, vp]),
     ("fotg_strerror", C.c_char_p, [C.c_int]),
     ("fotg_last_hip_error", C.c_int, []),
     ("fotg_version", C.c_char_p, []),

@@ -1018,6 +1018,19 @@ static int varref_dispatch(fotg_ctx *c, int l, int n, const float *I0, const flo
 }
 
 extern "C" {
+/* measurement tap (bench.py's roofline of the time-dominant kernel): ONE sor_coupled call (tv_solverit sweeps) of level l on
+ * whatever system the last fotg_varref left in the workspace -- the launch the refinement issues once per inner iteration.
+ * It advances (du,dv) of the workspace by three more sweeps; no product entry point reads that state across calls. */
+int fotg_bench_sor_call(fotg_ctx *c, int l, int n, void *stream)
+{
+  int st = check_level(c, l, n); if (st) return st;
+  if (!c->vr || c->p.depth || !c->vrC[l] || c->p.tv_solverit < 1) return FOTG_ERR_UNSUPPORTED;
+  ON_DEVICE(c->device);
+  dispatch_sor(c, c->vra[l], n, c->p.tv_solverit, c->p.tv_sor, (hipStream_t)stream);
+  LAUNCHCHK();
+  return FOTG_OK;
+}
+
 int fotg_varref(fotg_ctx *c, int l, int n, const float *I0, const float *I1, long pair_stride, float *flow, void *stream)
 {
   if (!c || l < 0 || l >= FOTG_MAXLEV) return FOTG_ERR_ARG;

@@ -162,6 +162,9 @@ int fotg_varref(fotg_ctx *ctx, int level, int n, const float *I0, const float *I
  * depth mode: "wx","mask","du","uu","s","a11","b1","sh","sv" and the image planes (a11/b1: the scalar system of compute_data_DE) */
 int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, float *host_out);
 
+/* measurement tap: ONE sor_coupled call (the launch the refinement issues once per inner iteration) of `level` for n pairs on the
+ * system the last fotg_varref left in the workspace; bench.py times it for the roofline of the time-dominant kernel */
+int fotg_bench_sor_call(fotg_ctx *ctx, int level, int n, void *stream);
 /* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_wide", "vr_stage"); -1 for unknown names */
 long fotg_debug_counter(const char *name);
 /* test tap, per context (synchronises the device): "vr_stage_timeouts" = bounded waits of the stage-pipelined refinement that
