@@ -13,6 +13,7 @@
 #include "densify.hip.h"
 #include "varref.hip.h"
 #include "varref_stage.hip.h"
+#include "varref_tiles.hip.h"
 #include "varref_depth.hip.h"
 #include "upsample.hip.h"
 
@@ -62,6 +63,7 @@ struct FotgTune {
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
   int vr_wide;      // FOTG_VR_WIDE: 0 = single-wave kernel instead of the wide one
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
+  int vr_tiles;     // FOTG_VR_TILES: 0 = tall levels on one workgroup per pair (wide / single-wave kernels) instead of the tile pipeline
   int vr_stage;     // FOTG_VR_STAGE: 1 = stage-pipelined refinement of the levels it fits (varref_stage.hip.h); default 0
   int vr_stage_mins;// FOTG_VR_STAGE_MINS: fewest anti-diagonals of a level that takes the stage pipeline
 };
@@ -104,6 +106,10 @@ struct fotg_ctx {
   hipEvent_t tev[4 * FOTG_MAXLEV + 4];
   float tt[FOTG_MAXLEV][5];          // last measured ms per level: pconst, pinit, poptim, cflow, tvopt
   float tt_pyr, tt_total;
+  float2 *vrX[FOTG_MAXLEV];          // tile pipeline of tall levels (varref_tiles.hip.h): per-sweep skewed arrays
+  long x_pair_stride[FOTG_MAXLEV];
+  int x_rt[FOTG_MAXLEV];
+  int *tileSync;
   int *vrSync;
   int sync_block;                    // which block of vrSync this (view of the) context uses
   void *vrZero;
@@ -205,9 +211,9 @@ void fotg_destroy(fotg_ctx *c)
     (void)hipFree(c->dx1[l]); (void)hipFree(c->dy1[l]); (void)hipFree(c->p_iter_bw[l]); (void)hipFree(c->pweight_bw[l]); (void)hipFree(c->flow_bw[l]);
     (void)hipFree(c->tap_t[l]); (void)hipFree(c->tap_tx[l]); (void)hipFree(c->tap_ty[l]); (void)hipFree(c->tap_hes[l]); (void)hipFree(c->tap_cnt[l]);
     (void)hipFree(c->trace_dev[l]);
-    (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]);
+    (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]); (void)hipFree(c->vrX[l]);
   }
-  (void)hipFree(c->vr); (void)hipFree(c->vrQ); (void)hipFree(c->vrDS); (void)hipFree(c->vrSync); (void)hipFree(c->vrZero);
+  (void)hipFree(c->vr); (void)hipFree(c->vrQ); (void)hipFree(c->vrDS); (void)hipFree(c->vrSync); (void)hipFree(c->vrZero); (void)hipFree(c->tileSync);
   for (int i = 0; i < 8; ++i) {
     if (c->sub_stream[i]) (void)hipStreamDestroy(c->sub_stream[i]);
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -240,6 +246,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
   c->tune.vr_wide = env_int("FOTG_VR_WIDE", 1);
   c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
+  c->tune.vr_tiles = env_int("FOTG_VR_TILES", 1);
   c->tune.vr_stage = env_int("FOTG_VR_STAGE", 0);      // opt-in: measured slower than the per-iteration launches at batch 64
   c->tune.vr_stage_mins = env_int("FOTG_VR_STAGE_MINS", 80);
   fotg_padded_size(w_org, h_org, p->sc_f, &c->Wp, &c->Hp, &c->padw, &c->padh);
@@ -299,6 +306,19 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       ALLOC(c->vrD[l], B * a.d_pair_stride * sizeof(float2) + 4096);
       if (hipMemset(c->vrC[l], 0, cbytes) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       a.C = c->vrC[l]; a.D = c->vrD[l];
+      // tall levels (beyond the LDS solvers' 96 rows): per-sweep arrays of the tile pipeline, zero outside the image for good
+      if (c->tune.vr_tiles && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && gl.h > 96 && p->tv_solverit >= 1 && p->tv_solverit <= 4 &&
+          (gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS <= 32) {
+        c->x_rt[l] = ((gl.h + 2 + 15) / 16) * 16;
+        c->x_pair_stride[l] = (long)p->tv_solverit * (a.S + 2) * c->x_rt[l];
+        const size_t xb = B * c->x_pair_stride[l] * sizeof(float2);
+        ALLOC(c->vrX[l], xb);
+        if (hipMemset(c->vrX[l], 0, xb) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+        if (!c->tileSync) {
+          ALLOC(c->tileSync, 8 * (tile_sync_words((int)B) + 32) * sizeof(int));
+          if (hipMemset(c->tileSync, 0, 8 * (tile_sync_words((int)B) + 32) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+        }
+      }
     }
     // Levels that take the stage pipeline: lexicographic order, 1..3 sweeps (one solver wave each), 2..16 inner iterations
     // (one workgroup each), enough anti-diagonals to amortise the pipeline fill, a ring geometry that holds the rows.
@@ -706,6 +726,11 @@ static bool launch_sor_pipe(int n, float omega, hipStream_t s, const VrArgs &b)
 
 static long g_wide_launches = 0;        // fotg_debug_counter("sor_wide")
 static long g_stage_launches = 0;       // fotg_debug_counter("vr_stage")
+static long g_tile_launches = 0;        // fotg_debug_counter("sor_tiles")
+#ifndef FOTG_TILE_P
+#define FOTG_TILE_P 8                    // prefetch depth (diagonals) of the tile solver
+#endif
+static int a_level(const fotg_ctx *c, const VrArgs &a) { for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) if (c->vra[l].w == a.w && c->vra[l].h == a.h) return l; return c->p.sc_l; }
 static long g_stream_launches = 0;      // fotg_debug_counter("sor_stream"): tests assert the kernel really ran
 // streaming solver (vr_sor_stream_kernel): diagonals travel through LDS rings, two rows per lane.
 template <int RD, int RCW>
@@ -803,7 +828,24 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
 {
   const int path = c->tune.vr_path;    // 0 = automatic, 1 = single-wave global-memory solver only, 2 = no fused inner loop (tests)
   if (path != 1 && dispatch_sor_pipe(c, a, n, sweeps, omega, s)) return;
-  // levels too tall for the LDS solvers: a whole workgroup per pair on the global arrays (tune.vr_wide = 0: the single-wave kernel)
+  // levels too tall for the LDS solvers: tiles = (sweep, band of 128 rows), one single-wave workgroup each, pipelined through
+  // global memory (varref_tiles.hip.h); tune.vr_tiles = 0: one workgroup per pair (the kernels below; tests)
+  if (path != 1 && c->vrX[a_level(c, a)] && c->tileSync) {
+    const int l = a_level(c, a);
+    TileArgs g;
+    g.X = c->vrX[l] + (size_t)(a.C - c->vrC[l]) / a.c_pair_stride * c->x_pair_stride[l];      // (views: same pair offset as C)
+    g.x_pair_stride = c->x_pair_stride[l];
+    g.x_buf_stride = (long)(a.S + 2) * c->x_rt[l];
+    g.RT = c->x_rt[l];
+    g.NB = (a.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS;
+    g.npairs = n;
+    g.sync = c->tileSync + (size_t)c->sync_block * (tile_sync_words(c->max_batch) + 32);
+    g.timeouts = g.sync + tile_sync_words(c->max_batch);
+    (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n) * sizeof(int), s);
+    vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sweeps, 64, 0, s>>>(a, g, sweeps, omega);
+    ++g_tile_launches;
+    return;
+  }
   if (a.h > 1024 && sweeps >= 1) {
     // beyond the single-wave kernel's 16 rows per lane: four rows per lane, one sweep per launch (sweeps are sequential passes)
     const int lp = (((a.h + 3) / 4 + 63) / 64) * 64;
@@ -1364,6 +1406,7 @@ long fotg_debug_counter(const char *name)
   if (name && !strcmp(name, "sor_stream")) return g_stream_launches;
   if (name && !strcmp(name, "sor_wide")) return g_wide_launches;
   if (name && !strcmp(name, "vr_stage")) return g_stage_launches;
+  if (name && !strcmp(name, "sor_tiles")) return g_tile_launches;
   return -1;
 }
 
@@ -1385,6 +1428,18 @@ long fotg_ctx_counter(fotg_ctx *c, const char *name)
 {
   if (!c || !name) return -1;
   if (!strcmp(name, "stage_stamps_ptr")) return (long)(size_t)c->stamps;
+  if (!strcmp(name, "tile_timeouts")) {
+    if (!c->tileSync) return 0;
+    DevGuard dg(c->device);
+    long tot = 0;
+    if (!dg.ok || hipDeviceSynchronize() != hipSuccess) return -1;
+    for (int b = 0; b < 8; ++b) {
+      int v = 0;
+      if (hipMemcpy(&v, c->tileSync + (size_t)b * (tile_sync_words(c->max_batch) + 32) + tile_sync_words(c->max_batch), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      tot += v;
+    }
+    return tot;
+  }
   if (!strcmp(name, "vr_stage_timeouts")) {
     // bounded waits of the stage pipeline that gave up since the context was created (0 unless something is broken)
     if (!c->vrSync) return 0;

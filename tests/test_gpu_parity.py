@@ -312,6 +312,30 @@ def test_streaming_solver_kernel(mode, monkeypatch):
     assert F.lib().fotg_debug_counter(b"sor_stream") == before + expect
 
 
+def test_tile_solver_pipeline():
+    """levels of more than 96 rows are relaxed by the tile pipeline (varref_tiles.hip.h): one single-wave workgroup per (sweep,
+    band of 128 rows), (du,dv) handed from tile to tile through global memory behind progress words.  Sizes: op-pt 3 at 1080p
+    (levels 240x136: 2 bands, 480x272: 3 bands), a 132-row level (second band of 4 rows), op-pt 4 on a tall frame (544 rows:
+    5 bands), batches of two; 1, 2 and 4 sweeps.  Bit-identical to the oracle, no wait timed out."""
+    F, OFClass, _, O = _mods()
+    before = F.lib().fotg_debug_counter(b"sor_tiles")
+    for (w, h), op_point, width_for_op, sweeps in (((1920, 1080), 3, 1920, 3), ((640, 528), 3, 640, 3), ((480, 2176), 4, 3840, 3),
+                                                   ((640, 528), 3, 640, 1), ((640, 528), 3, 640, 2), ((640, 528), 3, 640, 4)):
+        f0, f1 = synth_pair(h, w, seed=4)
+        op = F.operating_point(op_point, width_for_op, 1)
+        op.var_ref_iter = sweeps
+        if op_point == 4:
+            op.grad_descent_iter = 8                           # keep the oracle quick; the solver is what is under test
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+        out = ofc.calc_batch(dev(np.stack([f0, f1])), dev(np.stack([f1, f0]))).cpu().numpy()
+        p = oracle_params(O, op)
+        a, b = O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f)
+        assert np.array_equal(out[0], O.flow(a, b, p, 0)) and np.array_equal(out[1], O.flow(b, a, p, 0)), (w, h, sweeps)
+        assert F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
+        ofc.close()
+    assert F.lib().fotg_debug_counter(b"sor_tiles") > before
+
+
 @pytest.mark.parametrize("wide", ["1", "0"])
 def test_wide_solver_kernel(wide, monkeypatch):
     """levels too tall for the LDS solvers (the fine levels of the quality presets) are relaxed by vr_sor_wide_kernel: a whole
@@ -320,6 +344,7 @@ def test_wide_solver_kernel(wide, monkeypatch):
     lane in the array padding: falls back), op-pt 4 on a tall frame (544-row level), and a batch of two"""
     F, OFClass, _, O = _mods()
     monkeypatch.setenv("FOTG_VR_WIDE", wide)
+    monkeypatch.setenv("FOTG_VR_TILES", "0")                 # (tall levels take the tile pipeline by default)
     before = F.lib().fotg_debug_counter(b"sor_wide")
     ran = 0
     for (w, h), op_point, width_for_op in (((1920, 1080), 3, 1920), ((640, 528), 3, 640), ((480, 2176), 4, 3840)):
@@ -337,21 +362,26 @@ def test_wide_solver_kernel(wide, monkeypatch):
     assert (ran > 0) if wide == "1" else (ran == 0)
 
 
-def test_levels_taller_than_1024_rows():
-    """a refined level of more than 1024 rows (beyond 16 rows per lane of the single-wave solver): the wide kernel, four rows
-    per lane, one sweep per launch.  op-pt 3 on a narrow tall frame refines the full-resolution level (1304 rows)"""
+@pytest.mark.parametrize("tiles", ["1", "0"])
+def test_levels_taller_than_1024_rows(tiles, monkeypatch):
+    """a refined level of more than 1024 rows (beyond 16 rows per lane of the single-wave solver): the tile pipeline (11 bands), or
+    with FOTG_VR_TILES=0 the wide kernel, four rows per lane, one sweep per launch.  op-pt 3 on a narrow tall frame refines the
+    full-resolution level (1304 rows)"""
     F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_TILES", tiles)
     w, h = 304, 1300
     f0, f1 = synth_pair(h, w, seed=8)
     op = F.operating_point(3, w, 1)
     assert op.finest_scale == 0
-    before = F.lib().fotg_debug_counter(b"sor_wide")
+    name = b"sor_tiles" if tiles == "1" else b"sor_wide"
+    before = F.lib().fotg_debug_counter(name)
     ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
     out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
     p = oracle_params(O, op)
     ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
     assert out.shape[0] > 1024 and np.array_equal(out, ref)
-    assert F.lib().fotg_debug_counter(b"sor_wide") > before
+    assert F.lib().fotg_debug_counter(name) > before
+    assert F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
 
 
 def test_plane_at_a_time_setup_stages(alley, monkeypatch):

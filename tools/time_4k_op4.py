@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE configs[3]: one 3840x2160 pair at operating point 4 (quality preset): python tools/time_4k_op4.py"""
 import sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from conftest import synth_pair
 import flowonthego_amd as F
