@@ -57,7 +57,6 @@ struct GridState {
 // Switches read ONCE from the environment at fotg_create (tests force the kernel variants through them; nothing under
 // fotg_calc_batch touches the environment).  Every variant computes the same bits.
 struct FotgTune {
-  int lk_np;        // FOTG_LK_NP: patches per LK wave (0 = by launch size)
   int vr_path;      // FOTG_VR_PATH: 0 automatic, 1 single-wave global-memory solver only, 2 no fused per-level kernel
   int vr_stream;    // FOTG_VR_STREAM: 0 = resident-D kernel instead of the streaming solver
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
@@ -240,7 +239,6 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   memset((void *)c, 0, sizeof(*c));
   c->p = *p; c->w_org = w_org; c->h_org = h_org; c->device = device; c->max_batch = max_batch;
   c->noc = p->noc; c->ps = p->ps; c->nch = p->depth ? 1 : 2;
-  c->tune.lk_np = env_int("FOTG_LK_NP", 0);
   c->tune.vr_path = env_int("FOTG_VR_PATH", 0);
   c->tune.vr_stream = env_int("FOTG_VR_STREAM", 1);
   c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
@@ -308,9 +306,9 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       a.C = c->vrC[l]; a.D = c->vrD[l];
       // tall levels (beyond the LDS solvers' 96 rows): per-sweep arrays of the tile pipeline, zero outside the image for good
       if (c->tune.vr_tiles && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && gl.h > 96 && p->tv_solverit >= 1 && p->tv_solverit <= 4 &&
-          (gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS <= 32) {
+          (gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS <= 64) {
         c->x_rt[l] = ((gl.h + 2 + 15) / 16) * 16;
-        c->x_pair_stride[l] = (long)p->tv_solverit * (a.S + 2) * c->x_rt[l];
+        c->x_pair_stride[l] = (long)p->tv_solverit * (a.S + 3) * c->x_rt[l];
         const size_t xb = B * c->x_pair_stride[l] * sizeof(float2);
         ALLOC(c->vrX[l], xb);
         if (hipMemset(c->vrX[l], 0, xb) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
@@ -581,35 +579,32 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   a.dp_thresh_sq = c->p.dp_thresh * c->p.dp_thresh;                 // kroeger/oflow.cpp:88
   a.dr_thresh = c->p.dr_thresh; a.res_thresh = c->p.res_thresh;
   a.outlier = (float)c->ps / 2;                                     // :82
-  // Patches per wave (packed scalar domain).  More patches per wave = fewer wave instructions per patch but a longer
-  // wave, so only when the launch is throughput bound (enough patches to fill the GPU several times over).
-  dim3 block(256);
-  // measured (MI355X, 64 x 1080p, packed reductions): 32.6k patches: NP 4 0.083 ms, NP 2 0.087; 8.6k: NP 2 0.034, NP 4 0.040;
-  // 2.5k: NP 1 0.018, NP 2 0.020
-  const long npatch = (long)n * g.nop;
-  int np = npatch >= 24576 ? 4 : npatch >= 4096 ? 2 : 1;
-  if (c->tune.lk_np > 0) np = c->tune.lk_np;
-#define LK(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
-#define LKD(PS_, NOC_, NP_) lk_kernel<PS_, NOC_, NP_, true><<<dim3((g.nop + 4 * NP_ - 1) / (4 * NP_), n), block, 0, s>>>(a)
-  if (c->ps == 4 || c->ps == 16) {                                  // custom patch sizes: one patch per wave
-    if (c->p.depth) {
-      if (c->ps == 4) { if (c->noc == 1) LKD(4, 1, 1); else LKD(4, 3, 1); }
-      else { if (c->noc == 1) LKD(16, 1, 1); else LKD(16, 3, 1); }
-    } else {
-      if (c->ps == 4) { if (c->noc == 1) LK(4, 1, 1); else LK(4, 3, 1); }
-      else { if (c->noc == 1) LK(16, 1, 1); else LK(16, 3, 1); }
+  {
+    // the largest float whose (correctly rounded) square root is <= outlier: sqrtf(s) > outlier  <=>  s > outlier_sq
+    float sq = a.outlier * a.outlier;
+    while (sqrtf(sq) > a.outlier) sq = nextafterf(sq, 0.0f);
+    while (sqrtf(nextafterf(sq, INFINITY)) <= a.outlier) sq = nextafterf(sq, INFINITY);
+    a.outlier_sq = sq;
+  }
+  // four patches per wave, one wave per workgroup (lk.hip.h)
+  dim3 block(64), grid((g.nop + FOTG_LK_PPW - 1) / FOTG_LK_PPW, n);
+#define LK(PS_, NOC_) lk_kernel<PS_, NOC_, false><<<grid, block, 0, s>>>(a)
+#define LKD(PS_, NOC_) lk_kernel<PS_, NOC_, true><<<grid, block, 0, s>>>(a)
+  if (c->p.depth) {
+    switch (c->ps * 10 + c->noc) {
+      case 41: LKD(4, 1); break;   case 43: LKD(4, 3); break;
+      case 81: LKD(8, 1); break;   case 83: LKD(8, 3); break;
+      case 121: LKD(12, 1); break; case 123: LKD(12, 3); break;
+      case 161: LKD(16, 1); break; default: LKD(16, 3); break;
+    }
+  } else {
+    switch (c->ps * 10 + c->noc) {
+      case 41: LK(4, 1); break;   case 43: LK(4, 3); break;
+      case 81: LK(8, 1); break;   case 83: LK(8, 3); break;
+      case 121: LK(12, 1); break; case 123: LK(12, 3); break;
+      case 161: LK(16, 1); break; default: LK(16, 3); break;
     }
   }
-  else if (c->p.depth) {
-    if (c->ps == 8 && c->noc == 1) { if (np >= 2) LKD(8, 1, 2); else LKD(8, 1, 1); }
-    else if (c->ps == 8) { if (np >= 2) LKD(8, 3, 2); else LKD(8, 3, 1); }
-    else if (c->noc == 1) { if (np >= 2) LKD(12, 1, 2); else LKD(12, 1, 1); }
-    else LKD(12, 3, 1);
-  }
-  else if (c->ps == 8 && c->noc == 1) { if (np >= 4) LK(8, 1, 4); else if (np == 2) LK(8, 1, 2); else LK(8, 1, 1); }
-  else if (c->ps == 8) { if (np >= 2) LK(8, 3, 2); else LK(8, 3, 1); }
-  else if (c->noc == 1) { if (np >= 2) LK(12, 1, 2); else LK(12, 1, 1); }
-  else LK(12, 3, 1);
 #undef LK
 #undef LKD
   LAUNCHCHK();
@@ -728,7 +723,7 @@ static long g_wide_launches = 0;        // fotg_debug_counter("sor_wide")
 static long g_stage_launches = 0;       // fotg_debug_counter("vr_stage")
 static long g_tile_launches = 0;        // fotg_debug_counter("sor_tiles")
 #ifndef FOTG_TILE_P
-#define FOTG_TILE_P 8                    // prefetch depth (diagonals) of the tile solver
+#define FOTG_TILE_P 16                   // prefetch depth (diagonals) of the tile solver
 #endif
 static int a_level(const fotg_ctx *c, const VrArgs &a) { for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) if (c->vra[l].w == a.w && c->vra[l].h == a.h) return l; return c->p.sc_l; }
 static long g_stream_launches = 0;      // fotg_debug_counter("sor_stream"): tests assert the kernel really ran
@@ -835,14 +830,14 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
     TileArgs g;
     g.X = c->vrX[l] + (size_t)(a.C - c->vrC[l]) / a.c_pair_stride * c->x_pair_stride[l];      // (views: same pair offset as C)
     g.x_pair_stride = c->x_pair_stride[l];
-    g.x_buf_stride = (long)(a.S + 2) * c->x_rt[l];
+    g.x_buf_stride = (long)(a.S + 3) * c->x_rt[l];
     g.RT = c->x_rt[l];
     g.NB = (a.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS;
     g.npairs = n;
     g.sync = c->tileSync + (size_t)c->sync_block * (tile_sync_words(c->max_batch) + 32);
     g.timeouts = g.sync + tile_sync_words(c->max_batch);
     (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n) * sizeof(int), s);
-    vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sweeps, 64, 0, s>>>(a, g, sweeps, omega);
+    vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sweeps, 128, 0, s>>>(a, g, sweeps, omega);
     ++g_tile_launches;
     return;
   }

@@ -4,7 +4,7 @@
 // solvers; round 1 relaxed them with one workgroup per pair (vr_sor_wide_kernel), i.e. on ONE CU, bound by that CU's L2 path
 // (three sweeps x 544 cells x 48 B per diagonal): 1.0 .. 1.5 ms per call, 57 % of a 4K operating-point-4 pair.
 //
-// Here the call is cut into TILES = (sweep n, band b of 128 rows), one single-wave workgroup each, all running at once:
+// Here the call is cut into TILES = (sweep n, band b of 64 rows), one single-wave workgroup each, all running at once:
 //   tile (b, n) relaxes the cells of its rows diagonal by diagonal (the anti-diagonal wavefront of the lexicographic order) and
 //   needs   the NEW values of the row above its band        from tile (b-1, n)    one diagonal back,
 //           the OLD values (= sweep n-1) of its own rows     from tile (b,   n-1)  one diagonal ahead,
@@ -16,10 +16,12 @@
 //
 // Hand-over through global memory (MI355X_MICROARCH.md, inter-workgroup visibility): sweep n writes the skewed array X[n]
 // (sweep 0 reads the level's D, the last sweep also stores its results there), every access of a handed-over cell is a relaxed agent-scope
-// 8-byte atomic (global_load / global_store ... sc1); a tile publishes "diagonals <= s - P - 1 are in memory" at step s -- its
-// vector-memory operations complete in order, and at step s it has consumed the loads it issued P steps ago, behind those stores;
-// X rows are a whole number of 128-byte lines, bands start on a line, a lane's two rows are r and r + 64 so that one store
-// instruction writes 64 consecutive cells = four whole lines.  Roles come from a ticket counter in the order of b + 2n: a tile
+// 8-byte atomic (global_load / global_store ... sc1).  A tile is TWO waves: the solver wave only loads (a wave's vector-memory
+// operations complete in order, so a load issued behind a write-through store is not back before that store is acknowledged --
+// microseconds), hands its results to the WRITER wave through a small LDS ring, one barrier per G diagonals; the writer
+// stores them, and publishes a chunk's progress two chunks later, when a counted vmcnt says those stores have completed;
+// X rows are a whole number of 128-byte lines, bands start on a line, one store instruction writes a band's 64 consecutive
+// cells = four whole lines.  Roles come from a ticket counter in the order of b + 2n: a tile
 // only waits for tiles holding lower tickets (running or finished by construction); every wait is bounded.
 #pragma once
 #include "varref.hip.h"
@@ -27,17 +29,23 @@
 namespace fotg {
 
 struct TileArgs {
-  float2 *X;                 // [pair][nsweeps][S+2][RT] float2, zero outside the image (never written there with non-zeros)
+  float2 *X;                 // [pair][nsweeps][S+3][RT] float2, zero outside the image (never written there with non-zeros)
   long x_pair_stride, x_buf_stride;
   int RT;                    // cells per row, multiple of 16
-  int NB;                    // bands of 128 rows
+  int NB;                    // bands of FOTG_TILE_ROWS rows
   int npairs;
-  int *sync;                 // [0] ticket, progress of tile (pair, n, b) at [32 * (1 + (pair * 4 + n) * 32 + b)]; zeroed before every launch
+  int *sync;                 // [0] ticket, progress of tile (pair, n, b) at [32 * (1 + (pair * 4 + n) * 64 + b)]; zeroed before every launch
   int *timeouts;             // timed-out waits since the context was created
 };
-__host__ __device__ inline long tile_sync_words(int npairs) { return 32L * (1 + (long)npairs * 4 * 32); }
-#define FOTG_TILE_ROWS 128
-#define FOTG_TILE_G 8          // progress is published / checked every G diagonals
+__host__ __device__ inline long tile_sync_words(int npairs) { return 32L * (1 + (long)npairs * 4 * 64); }
+#define FOTG_TILE_ROWS 64      // rows of a band = lanes of the solver wave (one row per lane)
+#define FOTG_TILE_G 4          // progress is published / checked every G diagonals
+#ifndef FOTG_TILE_W
+#define FOTG_TILE_W 4          // chunks of write-through stores the writer keeps in flight
+#endif
+#ifndef FOTG_TILE_U
+#define FOTG_TILE_U 32         // steps per loop trip
+#endif
 
 __device__ __forceinline__ float2 ld_sc1_f2(const float2 *p)
 {
@@ -55,14 +63,18 @@ __device__ __forceinline__ float dpp_wave_shl1(float v)
 }
 
 template <int P>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void vr_sor_tile_kernel(VrArgs a, TileArgs g, int nsweeps, float omega)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void vr_sor_tile_kernel(VrArgs a, TileArgs g, int nsweeps, float omega)
 {
-  constexpr int G = FOTG_TILE_G, BR = FOTG_TILE_ROWS;
-  const int lane = threadIdx.x;
+  constexpr int G = FOTG_TILE_G, BR = FOTG_TILE_ROWS, U = FOTG_TILE_U, RING = 4 * G, W = FOTG_TILE_W;
+  static_assert(U % P == 0 && P % G == 0 && U % G == 0 && U % RING == 0, "ring slots and barrier phase are compile-time");
+  __shared__ float2 res_ring[RING][BR];
+  __shared__ int role_s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int S = a.S, RP = a.RP, RPD = a.RPD, h = a.h;
   // ---- role: ticket -> (pair, tile), tiles in the order of b + 2n
-  int t = lane == 0 ? atomicAdd(&g.sync[0], 1) : 0;
-  t = __builtin_amdgcn_readfirstlane(t);
+  if (threadIdx.x == 0) role_s = atomicAdd(&g.sync[0], 1);
+  __syncthreads();
+  const int t = role_s;
   const int pair = t % g.npairs, idx = t / g.npairs;
   int n = -1, b = -1;
   {
@@ -76,29 +88,77 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
   }
   if (n < 0) return;
-  int *const prog = g.sync + 32 * (1 + (pair * 4 + n) * 32 + b);
-  const int *const prog_own = n > 0 ? g.sync + 32 * (1 + (pair * 4 + n - 1) * 32 + b) : nullptr;                      // (b, n-1)
-  const int *const prog_bel = (n > 0 && b + 1 < g.NB) ? g.sync + 32 * (1 + (pair * 4 + n - 1) * 32 + b + 1) : nullptr;  // (b+1, n-1)
-  const int *const prog_top = b > 0 ? g.sync + 32 * (1 + (pair * 4 + n) * 32 + b - 1) : nullptr;                       // (b-1, n)
+  int *const prog = g.sync + 32 * (1 + (pair * 4 + n) * 64 + b);
+  const int *const prog_own = n > 0 ? g.sync + 32 * (1 + (pair * 4 + n - 1) * 64 + b) : nullptr;                      // (b, n-1)
+  const int *const prog_bel = (n > 0 && b + 1 < g.NB) ? g.sync + 32 * (1 + (pair * 4 + n - 1) * 64 + b + 1) : nullptr;  // (b+1, n-1)
+  const int *const prog_top = b > 0 ? g.sync + 32 * (1 + (pair * 4 + n) * 64 + b - 1) : nullptr;                       // (b-1, n)
   // ---- arrays: input = values of sweep n-1, output = values of sweep n
   float2 *const Dlev = a.Dp(pair);
   float2 *const Xp = g.X + (size_t)pair * g.x_pair_stride;
   const float2 *const Xin = n == 0 ? Dlev : Xp + (size_t)(n - 1) * g.x_buf_stride;
   float2 *const Xout = Xp + (size_t)n * g.x_buf_stride;
   const int pin = n == 0 ? RPD : g.RT, pout = g.RT;
-  const bool in_plain = n == 0;                                   // the level's D was written by earlier launches: plain loads
   const bool to_level = n == nsweeps - 1;                         // the last sweep's results also go back to the level's D (plain stores:
                                                                   // nothing in this launch reads them there)
-  const int rb = b * BR, r1 = rb + lane, r2 = rb + 64 + lane;
-  // lanes whose row lies beyond the image relax padding cells with omega = 0 (they read zeros, write zeros); rows beyond the
-  // arrays' pitch are parked on the last padding cell
-  const int rmaxin = pin - 1, rmaxout = pout - 1, rmaxc = RP - 1;
-  const float om1 = r1 < h ? omega : 0.f, om2 = r2 < h ? omega : 0.f;
-  const int c1r = r1 < rmaxc ? r1 : rmaxc, c2r = r2 < rmaxc ? r2 : rmaxc;
-  const int i1r = r1 < rmaxin ? r1 : rmaxin, i2r = r2 < rmaxin ? r2 : rmaxin, ibel = rb + BR < rmaxin ? rb + BR : rmaxin;
-  const int o1r = r1 < rmaxout ? r1 : rmaxout, o2r = r2 < rmaxout ? r2 : rmaxout;
-  const bool st1 = r1 <= rmaxout && r1 < RP, st2 = r2 <= rmaxout && r2 < RP;   // rows that exist in the output array
-  const float4 *const C = a.Cp(pair);
+  const int rb = b * BR, r1 = rb + lane;
+  const int T = ((S + U - 1) / U) * U;                             // solver steps (those past S-1 run on the zero row with omega = 0)
+  const int NBAR = T / G + 1;                                     // barriers both waves execute
+
+  // ======================================== writer wave ========================================
+  if (wv == 1) {
+    // interval k (behind barrier #k): the results of chunk k-1 (diagonals (k-1) G .. k G - 1) are in the LDS ring.  Every row store
+    // is issued by every lane (lanes whose row does not exist in the array store into the spare row S+1 of X, which nobody
+    // reads), so a chunk is exactly NST instructions and "all but the newest NST + 1 have completed" = the chunk before the
+    // previous one is in memory: its progress is published now.
+    float2 *const dump = Xout + (size_t)(S + 1) * pout;
+    const bool x1 = r1 < pout, l1 = r1 < RPD;
+    for (int k = 0; k < NBAR; ++k) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // W chunks (+ their progress stores) may stay in flight: a write-through store is acknowledged after a memory round trip,
+      // longer than the solver needs for a chunk
+      if (to_level) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W * (2 * G + 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W * (G + 1)) : "memory");
+      {
+        const int kc = k - 2 - W;                                 // the newest chunk whose stores have completed
+        const int pub = kc < 0 ? -1 : (kc * G + G - 1 < S - 1 ? kc * G + G - 1 : S - 1);
+        __hip_atomic_store(prog, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (k == 0) continue;
+      const int d0 = (k - 1) * G;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int d = d0 + j;
+        const float2 v1 = res_ring[d % RING][lane];
+        const bool live = d < S;
+        float2 *row = Xout + (size_t)(live ? d : S + 1) * pout;
+        st_sc1_f2((live && x1) ? row + r1 : dump + lane, v1);
+        if (to_level) {
+          float2 *lrow = Dlev + (size_t)(live ? d : 0) * RPD;
+          *((live && l1) ? lrow + r1 : dump + lane) = v1;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(prog, 0x3ffffff0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+
+  // ======================================== solver wave ========================================
+  // One row per lane.  Lanes whose row lies beyond the image relax padding cells with omega = 0 (they read zeros, write zeros);
+  // rows beyond the arrays' pitch are parked on the last padding cell.  Every address is (wave-uniform running row pointer) +
+  // (lane-constant offset); every load is unconditional (what does not exist -- the row above band 0, diagonals < 0 or >= S -- is
+  // read from the all-zero row S), so a step is one straight-line block.
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const int rmaxin = pin - 1, rmaxc = RP - 1;
+  const float om1 = r1 < h ? omega : 0.f;
+  const unsigned c1o = (unsigned)(r1 < rmaxc ? r1 : rmaxc) * 32u;
+  const unsigned i1o = (unsigned)(r1 < rmaxin ? r1 : rmaxin) * 8u;
+  const unsigned ibo = (unsigned)(rb + BR < rmaxin ? rb + BR : rmaxin) * 8u;
+  const unsigned tpo = (unsigned)(b > 0 ? rb - 1 : 0) * 8u;
+  const char *const Cb = reinterpret_cast<const char *>(a.Cp(pair));
+  const char *const Ib = reinterpret_cast<const char *>(Xin);
+  const char *const Tb = reinterpret_cast<const char *>(Xout);
+  const size_t cpitch = (size_t)RP * 32, ipitch = (size_t)pin * 8, tpitch = (size_t)pout * 8;
 
   int seen_own = prog_own ? -1 : 0x3fffffff, seen_bel = prog_bel ? -1 : 0x3fffffff, seen_top = prog_top ? -1 : 0x3fffffff;
   auto wait_for = [&](const int *p, int &seen, int need) {
@@ -114,86 +174,84 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       seen = 0x3fffffff;
     }
   };
-  struct Stage { float4 c1[2], c2[2]; float2 right1, right2, below, top; };
-  auto load_in = [&](int row, int cell) {
-    const float2 *p = Xin + (size_t)row * pin + cell;
-    return in_plain ? *p : ld_sc1_f2(p);
-  };
-  // loads of diagonal step d: system cells of both rows, the (du,dv) of diagonal d+1 (right neighbours = next step's own values;
-  // the cell below the band), the new value above the band of diagonal d-1
+  struct Stage { float4 c1[2]; float2 right1, below, top; };
+  // loads of diagonal step d: the row's system cell, the (du,dv) of diagonal d+1 (right neighbour = next step's own value; the
+  // cell below the band), the new value above the band of diagonal d-1
   auto issue = [&](Stage &st, int d) {
     const int dc = d < S ? d : S;                                 // (row S of C and of the (du,dv) arrays is all zero)
     const int dn = d + 1 < S ? d + 1 : S;
-    const float4 *cp = C + ((size_t)dc * RP) * 2;
-    st.c1[0] = cp[(size_t)c1r * 2]; st.c1[1] = cp[(size_t)c1r * 2 + 1];
-    st.c2[0] = cp[(size_t)c2r * 2]; st.c2[1] = cp[(size_t)c2r * 2 + 1];
-    st.right1 = load_in(dn, i1r); st.right2 = load_in(dn, i2r); st.below = load_in(dn, ibel);
-    st.top = make_float2(0.f, 0.f);
-    if (prog_top && d >= 1 && d - 1 < S) st.top = ld_sc1_f2(Xout + (size_t)(d - 1) * pout + (rb - 1));
+    const int dt = (b > 0 && d >= 1 && d - 1 < S) ? d - 1 : S;
+    const char *crow = Cb + (size_t)dc * cpitch, *irow = Ib + (size_t)dn * ipitch, *trow = Tb + (size_t)dt * tpitch;
+    st.c1[0] = *reinterpret_cast<const float4 *>(crow + c1o); st.c1[1] = *reinterpret_cast<const float4 *>(crow + c1o + 16);
+    st.right1 = ld_sc1_f2(reinterpret_cast<const float2 *>(irow + i1o));
+    st.below = ld_sc1_f2(reinterpret_cast<const float2 *>(irow + ibo));
+    st.top = ld_sc1_f2(reinterpret_cast<const float2 *>(trow + tpo));
   };
-  // before the loads of diagonals d .. d + G - 1 are issued their producers must have published them
+  // Before the loads of diagonals d .. d + G - 1 are issued their producers must have published them.  The progress words are
+  // polled ASYNCHRONOUSLY: every check issues the loads whose values the next check (G steps later) consumes, so in the steady
+  // state -- a tile follows its producers at their pace -- nothing waits here; only a tile that has caught up polls in a loop.
+  int fut_own = seen_own, fut_bel = seen_bel, fut_top = seen_top;
   auto ensure = [&](int d) {
     const int dmax = d + G - 1;
     const int need_in = dmax + 1 < S - 1 ? dmax + 1 : S - 1, need_top = dmax - 1 < S - 1 ? dmax - 1 : S - 1;
-    if (prog_own) wait_for(prog_own, seen_own, need_in);
-    if (prog_bel) wait_for(prog_bel, seen_bel, need_in);
-    if (prog_top) wait_for(prog_top, seen_top, need_top);
+    if (prog_own) { seen_own = fut_own > seen_own ? fut_own : seen_own; wait_for(prog_own, seen_own, need_in); fut_own = __hip_atomic_load(prog_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (prog_bel) { seen_bel = fut_bel > seen_bel ? fut_bel : seen_bel; wait_for(prog_bel, seen_bel, need_in); fut_bel = __hip_atomic_load(prog_bel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (prog_top) { seen_top = fut_top > seen_top ? fut_top : seen_top; wait_for(prog_top, seen_top, need_top); fut_top = __hip_atomic_load(prog_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   };
-  static_assert(P % G == 0, "the prologue fills the ring in whole check intervals");
   Stage ring[P];
+#pragma unroll
   for (int d0 = 0; d0 < P; d0 += G) {
     ensure(d0);
 #pragma unroll
     for (int k = 0; k < G; ++k) issue(ring[(d0 + k) % P], d0 + k);
   }
-  // own values of diagonal 0
-  float2 own1 = load_in(0, i1r), own2 = load_in(0, i2r);
-  float2 prev1 = make_float2(0.f, 0.f), prev2 = prev1;            // results of the previous step (new left values; new top values by DPP)
-  float hl1 = 0.f, hl2 = 0.f;
-  const int T = ((S + P - 1) / P) * P;                             // steps past S-1 run on the zero row with omega = 0
-  for (int s0 = 0; s0 < T; s0 += P) {
+  // own value of diagonal 0
+  const float2 o1_ = ld_sc1_f2(reinterpret_cast<const float2 *>(Ib + i1o));
+  v2f own1 = {o1_.x, o1_.y};
+  v2f prev1 = {0.f, 0.f};                                         // result of the previous step (new left value; new top value by DPP)
+  float hl1 = 0.f;
+  // one cell update of sor_coupled in sor_update()'s expression order, the (du,dv) pair as packed f32 (each half rounded like the scalar op)
+  auto relax = [&](v2f own, float4 c0, float4 c1, float hl, v2f left, v2f top, v2f right, v2f bottom, float om) {
+    const v2f a1 = {c0.x, c0.y}, bb = {c0.z, c0.w};
+    const float a22 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
+    v2f sv = hr * right;
+    sv = sv + vt * top;
+    sv = sv + vb * bottom;
+    sv = sv + bb;
+    const v2f B = hl * left + sv;
+    const v2f pa = a1 * B;
+    v2f tt = {pa.x + pa.y, c0.y * B.x + a22 * B.y};
+    tt = tt - own;
+    return own + om * tt;
+  };
+  // U steps per loop trip: the compiler drains the outstanding loads at the loop's back edge, one exposed memory latency per trip
+  for (int s0 = 0; s0 < T; s0 += U) {
 #pragma unroll
-    for (int u = 0; u < P; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int s = s0 + u;
-      Stage &st = ring[u];
-      if (u % G == 0) ensure(s + P);                              // (wave-uniform)
-      const float o1 = s < S ? om1 : 0.f, o2 = s < S ? om2 : 0.f;
-      // new top values: the row above is the same slot of lane - 1 (first row of the band: from the band above; row 64: lane 63's first row)
-      float2 top1 = make_float2(dpp_wave_shr1(prev1.x), dpp_wave_shr1(prev1.y));
-      float2 top2 = make_float2(dpp_wave_shr1(prev2.x), dpp_wave_shr1(prev2.y));
-      const float2 p63 = make_float2(lane_get(prev1.x, 63), lane_get(prev1.y, 63));
-      if (lane == 0) { top1 = st.top; top2 = p63; }
-      // old bottom values: the row below is the same slot of lane + 1 (row 63: lane 0's second row; row 127: the band below)
-      float2 bot1 = make_float2(dpp_wave_shl1(st.right1.x), dpp_wave_shl1(st.right1.y));
-      float2 bot2 = make_float2(dpp_wave_shl1(st.right2.x), dpp_wave_shl1(st.right2.y));
-      const float2 q0 = make_float2(lane_get(st.right2.x, 0), lane_get(st.right2.y, 0));
-      if (lane == 63) { bot1 = q0; bot2 = st.below; }
-      const float2 res1 = sor_update(own1, st.c1[0], st.c1[1], hl1, prev1, top1, st.right1, bot1, o1);
-      const float2 res2 = sor_update(own2, st.c2[0], st.c2[1], hl2, prev2, top2, st.right2, bot2, o2);
-      if (s < S) {
-        float2 *row = Xout + (size_t)s * pout;
-        if (st1) st_sc1_f2(row + o1r, res1);
-        if (st2) st_sc1_f2(row + o2r, res2);
-        if (to_level) {
-          float2 *lrow = Dlev + (size_t)s * RPD;
-          if (r1 < RPD) lrow[r1] = res1;
-          if (r2 < RPD) lrow[r2] = res2;
-        }
+      Stage &st = ring[u % P];
+      if (u % G == 0) {                                           // (wave-uniform)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the writer may take the previous G diagonals
+        ensure(s + P);
       }
-      prev1 = res1; prev2 = res2; hl1 = st.c1[1].y; hl2 = st.c2[1].y;
-      own1 = st.right1; own2 = st.right2;
-      // this wave's vector-memory operations complete in order: the loads consumed above were issued behind the stores of steps
-      // <= s - P - 1, so those diagonals are in memory
-      if (u % G == G - 1 && s - P - 1 >= 0) {
-        int pv = s - P - 1;
-        asm volatile("" : "+v"(pv) : "v"(res1.x), "v"(res2.x));   // (issued behind the consumption of this step's loads)
-        __hip_atomic_store(prog, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      const float o1 = s < S ? om1 : 0.f;
+      // new top value: the row above is lane - 1 (first row of the band: from the band above)
+      v2f top1 = {dpp_wave_shr1(prev1.x), dpp_wave_shr1(prev1.y)};
+      const v2f tp = {st.top.x, st.top.y};
+      if (lane == 0) top1 = tp;
+      // old bottom value: the row below is lane + 1 (last row of the band: from the band below)
+      const v2f rg1 = {st.right1.x, st.right1.y};
+      v2f bot1 = {dpp_wave_shl1(rg1.x), dpp_wave_shl1(rg1.y)};
+      const v2f bl = {st.below.x, st.below.y};
+      if (lane == 63) bot1 = bl;
+      const v2f res1 = relax(own1, st.c1[0], st.c1[1], hl1, prev1, top1, rg1, bot1, o1);
+      res_ring[u % RING][lane] = make_float2(res1.x, res1.y);     // -> writer wave (U is a multiple of RING: s % RING == u % RING)
+      prev1 = res1; hl1 = st.c1[1].y;
+      own1 = rg1;
       issue(st, s + P);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __hip_atomic_store(prog, 0x3ffffff0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // barrier #T/G: the last chunk goes to the writer
 }
 
 }  // namespace fotg

@@ -154,15 +154,17 @@ void dis_pyramid_free(dis_pyramid *p)
 
 float dis_sum(const float *v, int n, int noc)
 {
-  float lane[64]; int used[64];
-  for (int i = 0; i < 64; ++i) { lane[i] = 0.0f; used[i] = 0; }
+  /* 16 partial sums: pixel q (element e / noc) goes to partial q % 16, elements in ascending order; then the balanced
+   * tree over the 16 partials (xor 8, 4, 2, 1).  Every supported patch has a multiple of 16 pixels. */
+  float lane[16]; int used[16];
+  for (int i = 0; i < 16; ++i) { lane[i] = 0.0f; used[i] = 0; }
   for (int e = 0; e < n; ++e) {
-    int l = (e / noc) & 63;
+    int l = (e / noc) & 15;
     if (!used[l]) { lane[l] = v[e]; used[l] = 1; } else lane[l] = lane[l] + v[e];
   }
-  for (int k = 32; k >= 1; k >>= 1) {
-    float t[64];
-    for (int i = 0; i < 64; ++i) t[i] = lane[i] + lane[i ^ k];
+  for (int k = 8; k >= 1; k >>= 1) {
+    float t[16];
+    for (int i = 0; i < 16; ++i) t[i] = lane[i] + lane[i ^ k];
     memcpy(lane, t, sizeof(t));
   }
   return lane[0];

@@ -416,12 +416,10 @@ def test_fused_level_system_in_global_memory(alley, monkeypatch):
         assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
 
 
-@pytest.mark.parametrize("np_per_wave", ["2", "4"])
-def test_lk_patches_per_wave(np_per_wave, alley, monkeypatch):
-    """the LK kernel packs the scalar state of 1, 2 or 4 patches into one wave (chosen by launch size); force 2 and 4 on
-    sizes whose patch count is not a multiple of it, incl. RGB and ps=12 (which cap at 2 / 1)"""
+def test_lk_partial_waves(alley):
+    """the LK kernel runs four patches per wave (one per row of 16 lanes): sizes whose patch count is not a multiple of four,
+    incl. RGB and ps=12"""
     F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_LK_NP", np_per_wave)
     for case, op_point in (("alley", 2), ("synth_odd", 2), ("synth_rgb", 2), ("synth_odd", 3)):
         f0, f1, noc = frames(case, alley)
         h, w = f0.shape[:2]
@@ -429,7 +427,7 @@ def test_lk_patches_per_wave(np_per_wave, alley, monkeypatch):
         ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
         out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
         p = oracle_params(O, op)
-        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (np_per_wave, case)
+        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
 
 
 @pytest.mark.parametrize("graph", ["0", "1"])

@@ -199,13 +199,20 @@ def test_redblack_is_not_reference(alley):
 
 
 def test_dis_sum_order():
-    v = (np.random.default_rng(3).standard_normal(64) * 100).astype(np.float32)
-    t = v.copy()
-    k = 32
-    while k >= 1:
-        t = t + t[np.arange(64) ^ k]
-        k >>= 1
-    assert O.lib().dis_sum(O.P(v), 64, 1) == t[0]
+    """definition D1: 16 partial sums (pixel q -> partial q % 16, ascending), then the balanced tree xor 8, 4, 2, 1"""
+    for n, noc in ((64, 1), (144, 1), (432, 3), (16, 1)):
+        v = (np.random.default_rng(3 + n).standard_normal(n) * 100).astype(np.float32)
+        part = np.zeros(16, np.float32)
+        used = np.zeros(16, bool)
+        for e in range(n):
+            l = (e // noc) % 16
+            part[l] = part[l] + v[e] if used[l] else v[e]
+            used[l] = True
+        k = 8
+        while k >= 1:
+            part = part + part[np.arange(16) ^ k]
+            k >>= 1
+        assert O.lib().dis_sum(O.P(v), n, noc) == part[0]
 
 
 # ---------------------------------------------------------------------------------------------------------------
