@@ -307,8 +307,12 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       // tall levels (beyond the LDS solvers' 96 rows): per-sweep arrays of the tile pipeline, zero outside the image for good
       if (c->tune.vr_tiles && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && gl.h > 96 && p->tv_solverit >= 1 && p->tv_solverit <= 4 &&
           (gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS <= 64) {
-        c->x_rt[l] = ((gl.h + 2 + 15) / 16) * 16;
-        c->x_pair_stride[l] = (long)p->tv_solverit * (a.S + 3) * c->x_rt[l];
+        {
+          // every lane of every band has a cell of its own in a row (no two lanes share a store target)
+          const int nbr = ((gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS) * FOTG_TILE_ROWS, need = ((gl.h + 2 + 15) / 16) * 16;
+          c->x_rt[l] = nbr > need ? nbr : need;
+        }
+        c->x_pair_stride[l] = (long)p->tv_solverit * (a.S + 1 + FOTG_TILE_DUMP) * c->x_rt[l];
         const size_t xb = B * c->x_pair_stride[l] * sizeof(float2);
         ALLOC(c->vrX[l], xb);
         if (hipMemset(c->vrX[l], 0, xb) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
@@ -723,7 +727,7 @@ static long g_wide_launches = 0;        // fotg_debug_counter("sor_wide")
 static long g_stage_launches = 0;       // fotg_debug_counter("vr_stage")
 static long g_tile_launches = 0;        // fotg_debug_counter("sor_tiles")
 #ifndef FOTG_TILE_P
-#define FOTG_TILE_P 16                   // prefetch depth (diagonals) of the tile solver
+#define FOTG_TILE_P 8                    // prefetch depth (diagonals) of the tile solver
 #endif
 static int a_level(const fotg_ctx *c, const VrArgs &a) { for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) if (c->vra[l].w == a.w && c->vra[l].h == a.h) return l; return c->p.sc_l; }
 static long g_stream_launches = 0;      // fotg_debug_counter("sor_stream"): tests assert the kernel really ran
@@ -830,12 +834,17 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
     TileArgs g;
     g.X = c->vrX[l] + (size_t)(a.C - c->vrC[l]) / a.c_pair_stride * c->x_pair_stride[l];      // (views: same pair offset as C)
     g.x_pair_stride = c->x_pair_stride[l];
-    g.x_buf_stride = (long)(a.S + 3) * c->x_rt[l];
+    g.x_buf_stride = (long)(a.S + 1 + FOTG_TILE_DUMP) * c->x_rt[l];
     g.RT = c->x_rt[l];
     g.NB = (a.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS;
     g.npairs = n;
     g.sync = c->tileSync + (size_t)c->sync_block * (tile_sync_words(c->max_batch) + 32);
     g.timeouts = g.sync + tile_sync_words(c->max_batch);
+#ifdef FOTG_TILE_STATS
+    if (!c->stamps) { if (hipMalloc((void **)&c->stamps, 4096 * 32 * 8) != hipSuccess) return; }
+    (void)hipMemsetAsync(c->stamps, 0, 4096 * 32 * 8, s);
+    g.stats = (long long *)c->stamps;
+#endif
     (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n) * sizeof(int), s);
     vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sweeps, 128, 0, s>>>(a, g, sweeps, omega);
     ++g_tile_launches;

@@ -212,6 +212,8 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
 #pragma unroll
       for (int e = 0; e < NE; ++e) q[e] -= m;
     }
+    // (the cost-function switch stays inside the element loop: with the switch hoisted around three loops hipcc 7.2 produced
+    // different bits for costfct 1 -- test_patch_cost_functions -- and the two scalar branches per element cost ~2%)
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       float d = q[e] - T[e];                               // :230-236 L2: the difference image itself

@@ -29,19 +29,28 @@
 namespace fotg {
 
 struct TileArgs {
-  float2 *X;                 // [pair][nsweeps][S+3][RT] float2, zero outside the image (never written there with non-zeros)
+  float2 *X;                 // [pair][nsweeps][S+1+FOTG_TILE_DUMP][RT] float2: rows 0..S-1 diagonals (zero outside the image), row S zeros, then the dump area
   long x_pair_stride, x_buf_stride;
   int RT;                    // cells per row, multiple of 16
   int NB;                    // bands of FOTG_TILE_ROWS rows
   int npairs;
   int *sync;                 // [0] ticket, progress of tile (pair, n, b) at [32 * (1 + (pair * 4 + n) * 64 + b)]; zeroed before every launch
   int *timeouts;             // timed-out waits since the context was created
+#ifdef FOTG_TILE_STATS
+  long long *stats;          // [ticket][16]: see the end of the solver / writer wave (diagnostic builds only)
+#endif
 };
 __host__ __device__ inline long tile_sync_words(int npairs) { return 32L * (1 + (long)npairs * 4 * 64); }
 #define FOTG_TILE_ROWS 64      // rows of a band = lanes of the solver wave (one row per lane)
+#define FOTG_TILE_DUMP 16      // rows of the dump area behind the zero row of every X buffer
+#ifndef FOTG_TILE_G
 #define FOTG_TILE_G 4          // progress is published / checked every G diagonals
+#endif
+#ifndef FOTG_TILE_EXP
+#define FOTG_TILE_EXP 0       // diagnostic builds only: 1-4 take one memory stream out (results are wrong)
+#endif
 #ifndef FOTG_TILE_W
-#define FOTG_TILE_W 4          // chunks of write-through stores the writer keeps in flight
+#define FOTG_TILE_W 1          // chunks of write-through stores the writer keeps in flight
 #endif
 #ifndef FOTG_TILE_U
 #define FOTG_TILE_U 32         // steps per loop trip
@@ -65,17 +74,28 @@ __device__ __forceinline__ float dpp_wave_shl1(float v)
 template <int P>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void vr_sor_tile_kernel(VrArgs a, TileArgs g, int nsweeps, float omega)
 {
-  constexpr int G = FOTG_TILE_G, BR = FOTG_TILE_ROWS, U = FOTG_TILE_U, RING = 4 * G, W = FOTG_TILE_W;
+  constexpr int G = FOTG_TILE_G, BR = FOTG_TILE_ROWS, U = FOTG_TILE_U, RING = 2 * G, W = FOTG_TILE_W;
   static_assert(U % P == 0 && P % G == 0 && U % G == 0 && U % RING == 0, "ring slots and barrier phase are compile-time");
   __shared__ float2 res_ring[RING][BR];
   __shared__ int role_s;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int S = a.S, RP = a.RP, RPD = a.RPD, h = a.h;
   // ---- role: ticket -> (pair, tile), tiles in the order of b + 2n
+#ifdef FOTG_TILE_SKIP_XCC
+  {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if ((xcc & 15) == FOTG_TILE_SKIP_XCC - 1) return;
+  }
+#endif
   if (threadIdx.x == 0) role_s = atomicAdd(&g.sync[0], 1);
   __syncthreads();
   const int t = role_s;
+#ifdef FOTG_TILE_REVERSE
+  const int pair = t % g.npairs, idx = g.NB * nsweeps - 1 - t / g.npairs;      // (experiment: needs all workgroups resident)
+#else
   const int pair = t % g.npairs, idx = t / g.npairs;
+#endif
   int n = -1, b = -1;
   {
     int cnt = 0;
@@ -110,14 +130,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     // is issued by every lane (lanes whose row does not exist in the array store into the spare row S+1 of X, which nobody
     // reads), so a chunk is exactly NST instructions and "all but the newest NST + 1 have completed" = the chunk before the
     // previous one is in memory: its progress is published now.
-    float2 *const dump = Xout + (size_t)(S + 1) * pout;
     const bool x1 = r1 < pout, l1 = r1 < RPD;
+#ifdef FOTG_TILE_STATS
+    long long wstall = 0;
+#endif
     for (int k = 0; k < NBAR; ++k) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       // W chunks (+ their progress stores) may stay in flight: a write-through store is acknowledged after a memory round trip,
       // longer than the solver needs for a chunk
+#ifdef FOTG_TILE_STATS
+      const long long tw0 = clock64();
+#endif
       if (to_level) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W * (2 * G + 1)) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W * (G + 1)) : "memory");
+#ifdef FOTG_TILE_STATS
+      wstall += clock64() - tw0;
+#endif
       {
         const int kc = k - 2 - W;                                 // the newest chunk whose stores have completed
         const int pub = kc < 0 ? -1 : (kc * G + G - 1 < S - 1 ? kc * G + G - 1 : S - 1);
@@ -131,15 +159,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const float2 v1 = res_ring[d % RING][lane];
         const bool live = d < S;
         float2 *row = Xout + (size_t)(live ? d : S + 1) * pout;
-        st_sc1_f2((live && x1) ? row + r1 : dump + lane, v1);
+        // (stores that have no cell to go to -- diagonals past the end, rows beyond the level's own array -- land in a dump
+        // area of FOTG_TILE_DUMP rows used round robin: write-through stores to one and the same line would queue up behind
+        // each other)
+        float2 *const dump = Xout + (size_t)(S + 1 + (d & (FOTG_TILE_DUMP - 1))) * pout + lane;
+        st_sc1_f2((live && x1) ? row + r1 : dump, v1);
         if (to_level) {
           float2 *lrow = Dlev + (size_t)(live ? d : 0) * RPD;
-          *((live && l1) ? lrow + r1 : dump + lane) = v1;
+          *((live && l1) ? lrow + r1 : dump) = v1;
         }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(prog, 0x3ffffff0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef FOTG_TILE_STATS
+    if (lane == 0) { g.stats[t * 32 + 8] = wstall; g.stats[t * 32 + 9] = wall_clock64(); }
+#endif
     return;
   }
 
@@ -161,6 +196,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   const size_t cpitch = (size_t)RP * 32, ipitch = (size_t)pin * 8, tpitch = (size_t)pout * 8;
 
   int seen_own = prog_own ? -1 : 0x3fffffff, seen_bel = prog_bel ? -1 : 0x3fffffff, seen_top = prog_top ? -1 : 0x3fffffff;
+#ifdef FOTG_TILE_STATS
+  long long st_spins[3] = {0, 0, 0}, st_bar = 0, st_vm = 0;
+  const long long st_t0 = wall_clock64();
+  int st_which = 0;
+#endif
   auto wait_for = [&](const int *p, int &seen, int need) {
     if (seen >= need) return;
     int spins = 0;
@@ -169,6 +209,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       if (seen >= need) break;
       __builtin_amdgcn_s_sleep(2);
     } while (++spins < (1 << 20));
+#ifdef FOTG_TILE_STATS
+    st_spins[st_which] += spins + 1;
+#endif
     if (seen < need) {                                            // bounded wait: report and go on (the result is wrong, nothing hangs)
       if (lane == 0) atomicAdd(g.timeouts, 1);
       seen = 0x3fffffff;
@@ -181,7 +224,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int dc = d < S ? d : S;                                 // (row S of C and of the (du,dv) arrays is all zero)
     const int dn = d + 1 < S ? d + 1 : S;
     const int dt = (b > 0 && d >= 1 && d - 1 < S) ? d - 1 : S;
+#if FOTG_TILE_EXP == 1
+    const char *crow = Cb + (size_t)(dc & 7) * cpitch, *irow = Ib + (size_t)dn * ipitch, *trow = Tb + (size_t)dt * tpitch;
+#elif FOTG_TILE_EXP == 2
+    const char *crow = Cb + (size_t)dc * cpitch, *irow = Ib + (size_t)(S + (dn & 0)) * ipitch, *trow = Tb + (size_t)dt * tpitch;
+#elif FOTG_TILE_EXP == 3
+    const char *crow = Cb + (size_t)dc * cpitch, *irow = Ib + (size_t)dn * ipitch, *trow = Tb + (size_t)(S + (dt & 0)) * tpitch;
+#else
     const char *crow = Cb + (size_t)dc * cpitch, *irow = Ib + (size_t)dn * ipitch, *trow = Tb + (size_t)dt * tpitch;
+#endif
     st.c1[0] = *reinterpret_cast<const float4 *>(crow + c1o); st.c1[1] = *reinterpret_cast<const float4 *>(crow + c1o + 16);
     st.right1 = ld_sc1_f2(reinterpret_cast<const float2 *>(irow + i1o));
     st.below = ld_sc1_f2(reinterpret_cast<const float2 *>(irow + ibo));
@@ -194,8 +245,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   auto ensure = [&](int d) {
     const int dmax = d + G - 1;
     const int need_in = dmax + 1 < S - 1 ? dmax + 1 : S - 1, need_top = dmax - 1 < S - 1 ? dmax - 1 : S - 1;
+#ifdef FOTG_TILE_STATS
+    st_which = 0;
+#endif
     if (prog_own) { seen_own = fut_own > seen_own ? fut_own : seen_own; wait_for(prog_own, seen_own, need_in); fut_own = __hip_atomic_load(prog_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifdef FOTG_TILE_STATS
+    st_which = 1;
+#endif
     if (prog_bel) { seen_bel = fut_bel > seen_bel ? fut_bel : seen_bel; wait_for(prog_bel, seen_bel, need_in); fut_bel = __hip_atomic_load(prog_bel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifdef FOTG_TILE_STATS
+    st_which = 2;
+#endif
     if (prog_top) { seen_top = fut_top > seen_top ? fut_top : seen_top; wait_for(prog_top, seen_top, need_top); fut_top = __hip_atomic_load(prog_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   };
   Stage ring[P];
@@ -226,12 +286,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   };
   // U steps per loop trip: the compiler drains the outstanding loads at the loop's back edge, one exposed memory latency per trip
   for (int s0 = 0; s0 < T; s0 += U) {
+#ifdef FOTG_TILE_STATS
+    if ((s0 & 127) == 0 && (s0 >> 7) < 16 && lane == 0) g.stats[t * 32 + 16 + (s0 >> 7)] = wall_clock64();
+#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int s = s0 + u;
       Stage &st = ring[u % P];
       if (u % G == 0) {                                           // (wave-uniform)
+#ifdef FOTG_TILE_STATS
+        const long long tb0 = clock64();
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the writer may take the previous G diagonals
+#ifdef FOTG_TILE_STATS
+        const long long tb1 = clock64();
+        st_bar += tb1 - tb0;
+#endif
         ensure(s + P);
       }
       const float o1 = s < S ? om1 : 0.f;
@@ -252,6 +322,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // barrier #T/G: the last chunk goes to the writer
+#ifdef FOTG_TILE_STATS
+  if (lane == 0) {
+    long long *o = g.stats + t * 32;
+    o[0] = st_t0; o[1] = wall_clock64(); o[2] = st_spins[0]; o[3] = st_spins[1]; o[4] = st_spins[2]; o[5] = st_bar; o[6] = st_vm;
+    o[7] = ((long long)pair << 32) | (n << 16) | b;
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    o[10] = hw; o[11] = xcc;
+  }
+#endif
 }
 
 }  // namespace fotg
