@@ -24,6 +24,7 @@
 // cells = four whole lines.  Roles come from a ticket counter in the order of b + 2n: a tile
 // only waits for tiles holding lower tickets (running or finished by construction); every wait is bounded.
 #pragma once
+#include <type_traits>
 #include "varref.hip.h"
 
 namespace fotg {
@@ -46,9 +47,6 @@ __host__ __device__ inline long tile_sync_words(int npairs) { return 32L * (1 + 
 #ifndef FOTG_TILE_G
 #define FOTG_TILE_G 4          // progress is published / checked every G diagonals
 #endif
-#ifndef FOTG_TILE_EXP
-#define FOTG_TILE_EXP 0       // diagnostic builds only: 1-4 take one memory stream out (results are wrong)
-#endif
 #ifndef FOTG_TILE_W
 #define FOTG_TILE_W 1          // chunks of write-through stores the writer keeps in flight
 #endif
@@ -69,6 +67,16 @@ __device__ __forceinline__ float dpp_wave_shl1(float v)
 {
   // lane L reads lane L+1 (wave_shl:1); lane 63 gets 0 (bound_ctrl)
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+// lane L reads src of lane L-1 / L+1; the lane without a source lane (0 / 63) gets `old`
+__device__ __forceinline__ float dpp_wave_shr1_old(float old, float src)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_wave_shl1_old(float old, float src)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x130, 0xF, 0xF, false));
 }
 
 template <int P>
@@ -186,14 +194,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   typedef float v2f __attribute__((ext_vector_type(2)));
   const int rmaxin = pin - 1, rmaxc = RP - 1;
   const float om1 = r1 < h ? omega : 0.f;
-  const unsigned c1o = (unsigned)(r1 < rmaxc ? r1 : rmaxc) * 32u;
+  // Loads go through buffer resources: address = resource base + per-lane byte offset (VGPR, constant) + row offset (one
+  // SGPR per array that advances by the pitch every step) -- no vector and no 64-bit scalar address arithmetic in the loop.
+  const unsigned c1o = (unsigned)(r1 < rmaxc ? r1 : rmaxc) * 32u, c1o16 = c1o + 16u;
   const unsigned i1o = (unsigned)(r1 < rmaxin ? r1 : rmaxin) * 8u;
-  const unsigned ibo = (unsigned)(rb + BR < rmaxin ? rb + BR : rmaxin) * 8u;
-  const unsigned tpo = (unsigned)(b > 0 ? rb - 1 : 0) * 8u;
-  const char *const Cb = reinterpret_cast<const char *>(a.Cp(pair));
-  const char *const Ib = reinterpret_cast<const char *>(Xin);
-  const char *const Tb = reinterpret_cast<const char *>(Xout);
-  const size_t cpitch = (size_t)RP * 32, ipitch = (size_t)pin * 8, tpitch = (size_t)pout * 8;
+  const unsigned ibo = (unsigned)(rb + BR < rmaxin ? rb + BR : rmaxin) * 8u + 0u * lane;      // (wave-uniform values, kept in VGPRs)
+  const unsigned tpo = (unsigned)(b > 0 ? rb - 1 : 0) * 8u + 0u * lane;
+  const unsigned cpitch = (unsigned)RP * 32u, ipitch = (unsigned)pin * 8u, tpitch = (unsigned)pout * 8u;
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)a.Cp(pair), 0, (S + 1) * cpitch, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc((void *)Xin, 0, (S + 1) * ipitch, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void *)Xout, 0, (S + 1) * tpitch, 0x00020000);
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  auto ld_c = [&](unsigned vo, unsigned so) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsC, vo, so, 0)); };
+  auto ld_x = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) {        // (aux 16 = sc1: agent-coherent like ld_sc1_f2)
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 16));
+  };
 
   int seen_own = prog_own ? -1 : 0x3fffffff, seen_bel = prog_bel ? -1 : 0x3fffffff, seen_top = prog_top ? -1 : 0x3fffffff;
 #ifdef FOTG_TILE_STATS
@@ -220,24 +236,23 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   struct Stage { float4 c1[2]; float2 right1, below, top; };
   // loads of diagonal step d: the row's system cell, the (du,dv) of diagonal d+1 (right neighbour = next step's own value; the
   // cell below the band), the new value above the band of diagonal d-1
+  auto load = [&](Stage &st, unsigned oc, unsigned oi, unsigned ot) {
+    st.c1[0] = ld_c(c1o, oc); st.c1[1] = ld_c(c1o16, oc);
+    st.right1 = ld_x(rsI, i1o, oi);
+    st.below = ld_x(rsI, ibo, oi);
+    st.top = ld_x(rsT, tpo, ot);
+  };
   auto issue = [&](Stage &st, int d) {
     const int dc = d < S ? d : S;                                 // (row S of C and of the (du,dv) arrays is all zero)
     const int dn = d + 1 < S ? d + 1 : S;
     const int dt = (b > 0 && d >= 1 && d - 1 < S) ? d - 1 : S;
-#if FOTG_TILE_EXP == 1
-    const char *crow = Cb + (size_t)(dc & 7) * cpitch, *irow = Ib + (size_t)dn * ipitch, *trow = Tb + (size_t)dt * tpitch;
-#elif FOTG_TILE_EXP == 2
-    const char *crow = Cb + (size_t)dc * cpitch, *irow = Ib + (size_t)(S + (dn & 0)) * ipitch, *trow = Tb + (size_t)dt * tpitch;
-#elif FOTG_TILE_EXP == 3
-    const char *crow = Cb + (size_t)dc * cpitch, *irow = Ib + (size_t)dn * ipitch, *trow = Tb + (size_t)(S + (dt & 0)) * tpitch;
-#else
-    const char *crow = Cb + (size_t)dc * cpitch, *irow = Ib + (size_t)dn * ipitch, *trow = Tb + (size_t)dt * tpitch;
-#endif
-    st.c1[0] = *reinterpret_cast<const float4 *>(crow + c1o); st.c1[1] = *reinterpret_cast<const float4 *>(crow + c1o + 16);
-    st.right1 = ld_sc1_f2(reinterpret_cast<const float2 *>(irow + i1o));
-    st.below = ld_sc1_f2(reinterpret_cast<const float2 *>(irow + ibo));
-    st.top = ld_sc1_f2(reinterpret_cast<const float2 *>(trow + tpo));
+    load(st, (unsigned)dc * cpitch, (unsigned)dn * ipitch, (unsigned)dt * tpitch);
   };
+  // The same rows as running offsets for the loop trips whose diagonals need no clamping (all but the last one or two):
+  // three scalar adds per step.
+  unsigned rc = (unsigned)P * cpitch, ri = (unsigned)(P + 1) * ipitch;           // rows of diagonal d = s + P at s = 0
+  unsigned rt = b > 0 ? (unsigned)(P - 1) * tpitch : (unsigned)S * tpitch;
+  const unsigned tstep = b > 0 ? tpitch : 0;
   // Before the loads of diagonals d .. d + G - 1 are issued their producers must have published them.  The progress words are
   // polled ASYNCHRONOUSLY: every check issues the loads whose values the next check (G steps later) consumes, so in the steady
   // state -- a tile follows its producers at their pace -- nothing waits here; only a tile that has caught up polls in a loop.
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     for (int k = 0; k < G; ++k) issue(ring[(d0 + k) % P], d0 + k);
   }
   // own value of diagonal 0
-  const float2 o1_ = ld_sc1_f2(reinterpret_cast<const float2 *>(Ib + i1o));
+  const float2 o1_ = ld_x(rsI, i1o, 0);
   v2f own1 = {o1_.x, o1_.y};
   v2f prev1 = {0.f, 0.f};                                         // result of the previous step (new left value; new top value by DPP)
   float hl1 = 0.f;
@@ -284,8 +299,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     tt = tt - own;
     return own + om * tt;
   };
-  // U steps per loop trip: the compiler drains the outstanding loads at the loop's back edge, one exposed memory latency per trip
-  for (int s0 = 0; s0 < T; s0 += U) {
+  auto trip = [&](int s0, auto fast_tag) {
+    constexpr bool fast = decltype(fast_tag)::value;
 #ifdef FOTG_TILE_STATS
     if ((s0 & 127) == 0 && (s0 >> 7) < 16 && lane == 0) g.stats[t * 32 + 16 + (s0 >> 7)] = wall_clock64();
 #endif
@@ -304,23 +319,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #endif
         ensure(s + P);
       }
-      const float o1 = s < S ? om1 : 0.f;
-      // new top value: the row above is lane - 1 (first row of the band: from the band above)
-      v2f top1 = {dpp_wave_shr1(prev1.x), dpp_wave_shr1(prev1.y)};
-      const v2f tp = {st.top.x, st.top.y};
-      if (lane == 0) top1 = tp;
-      // old bottom value: the row below is lane + 1 (last row of the band: from the band below)
+      const float o1 = (fast || s < S) ? om1 : 0.f;
+      // new top value: the row above is lane - 1; lane 0 has no source lane and keeps `old` = the value loaded from the band above
+      const v2f top1 = {dpp_wave_shr1_old(st.top.x, prev1.x), dpp_wave_shr1_old(st.top.y, prev1.y)};
+      // old bottom value: the row below is lane + 1; lane 63 keeps the value loaded from the band below
       const v2f rg1 = {st.right1.x, st.right1.y};
-      v2f bot1 = {dpp_wave_shl1(rg1.x), dpp_wave_shl1(rg1.y)};
-      const v2f bl = {st.below.x, st.below.y};
-      if (lane == 63) bot1 = bl;
+      const v2f bot1 = {dpp_wave_shl1_old(st.below.x, rg1.x), dpp_wave_shl1_old(st.below.y, rg1.y)};
       const v2f res1 = relax(own1, st.c1[0], st.c1[1], hl1, prev1, top1, rg1, bot1, o1);
       res_ring[u % RING][lane] = make_float2(res1.x, res1.y);     // -> writer wave (U is a multiple of RING: s % RING == u % RING)
       prev1 = res1; hl1 = st.c1[1].y;
       own1 = rg1;
-      issue(st, s + P);
+      if (fast) { load(st, rc, ri, rt); rc += cpitch; ri += ipitch; rt += tstep; }
+      else issue(st, s + P);
     }
-  }
+  };
+  // U steps per loop trip: the compiler drains the outstanding loads at the loop's back edge, one exposed memory latency per trip
+  int s0 = 0;
+  for (; s0 + U - 1 + P <= S - 2; s0 += U) trip(s0, std::true_type());
+  for (; s0 < T; s0 += U) trip(s0, std::false_type());
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // barrier #T/G: the last chunk goes to the writer
 #ifdef FOTG_TILE_STATS
   if (lane == 0) {
