@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns rocprofv3 outputs under gpurun_out/ into the committed summaries under profiles/.
-usage: tools/make_profiles.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <tag>"""
+usage: tools/make_profiles.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <tag> [<4k_stats_dir> <4k_log>]"""
 import collections, csv, glob, json, sys
 stats_dir, fdir, wdir, tag = sys.argv[1:5]
 f = (glob.glob(stats_dir + "/*_kernel_stats.csv") + glob.glob(stats_dir + "/*/*_kernel_stats.csv"))[0]
@@ -31,3 +31,17 @@ for r in rows[:12]:
     print(r["Name"][:70].ljust(70), r["Calls"].rjust(5), ("%.1f" % (float(r["AverageNs"]) / 1000)).rjust(8), "us avg", r["Percentage"])
 for k, d in out.items():
     if "pyr_base" in k: print(k, d)
+
+if len(sys.argv) > 6:
+    k4, log = sys.argv[5:7]
+    f = (glob.glob(k4 + "/*_kernel_stats.csv") + glob.glob(k4 + "/*/*_kernel_stats.csv"))[0]
+    rows = list(csv.DictReader(open(f)))
+    line = [l.strip() for l in open(log) if "per pair" in l]
+    with open("profiles/%s_4k_op4_kernel_stats.md" % tag, "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/time_4k_op4.py   (MI355X)\n")
+        o.write("# BASELINE configs[3]: one 3840x2160 gray f32 pair, operating point 4 (ps 12, 6 scales, 128 LK iterations, refinement); 7 calls\n")
+        o.write("# %s (under the profiler)\n\n| kernel | calls | total ns | avg ns | %% |\n|---|---|---|---|---|\n" % (line[-1] if line else ""))
+        for r in rows:
+            if "fotg" in r["Name"] or "rocclr" in r["Name"]:
+                o.write("| %s | %s | %s | %.0f | %s |\n" % (r["Name"][:110], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
+    print(line[-1] if line else "no 4K line")

@@ -10,6 +10,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-breakdown > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k4 -o k -- python3 $GRAFT_REPO_ROOT/tools/time_4k_op4.py > $OUT/k4.log 2>&1
 cd $GRAFT_REPO_ROOT
-python3 tools/make_profiles.py $OUT/stats $OUT/fetch $OUT/write $TAG > $OUT/summary.txt 2>&1
+python3 tools/make_profiles.py $OUT/stats $OUT/fetch $OUT/write $TAG $OUT/k4 $OUT/k4.log > $OUT/summary.txt 2>&1
+python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_err.log
+cp $OUT/bench_line.json profiles/${TAG}_bench_line.json
 cp profiles/${TAG}_* $OUT/ 2>/dev/null
 tail -20 $OUT/summary.txt; tail -2 $OUT/k4.log
