@@ -165,10 +165,10 @@ int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, floa
 /* measurement tap: ONE sor_coupled call (the launch the refinement issues once per inner iteration) of `level` for n pairs on the
  * system the last fotg_varref left in the workspace; bench.py times it for the roofline of the time-dominant kernel */
 int fotg_bench_sor_call(fotg_ctx *ctx, int level, int n, void *stream);
-/* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_wide", "vr_stage"); -1 for unknown names */
+/* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_wide", "sor_tiles", "vr_stage"); -1 for unknown names */
 long fotg_debug_counter(const char *name);
-/* test tap, per context (synchronises the device): "vr_stage_timeouts" = bounded waits of the stage-pipelined refinement that
- * gave up since the context was created -- 0 unless something is broken; -1 for unknown names */
+/* test tap, per context (synchronises the device): "vr_stage_timeouts" / "tile_timeouts" = bounded waits of the stage-pipelined
+ * refinement / of the tile solver that gave up since the context was created -- 0 unless something is broken; -1 for unknown names */
 long fotg_ctx_counter(fotg_ctx *ctx, const char *name);
 const char *fotg_strerror(int status);
 int fotg_last_hip_error(void);

@@ -5,7 +5,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flowonthego_amd as F
 from flowonthego_amd.oflow import OFClass
 from bench import synth_batch

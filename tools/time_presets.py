@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the four operating points at 1080p (gray f32, batch 16): python tools/time_presets.py [batch]"""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 import flowonthego_amd as F
