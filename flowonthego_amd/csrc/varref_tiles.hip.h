@@ -272,6 +272,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     st_which = 2;
 #endif
     if (prog_top) { seen_top = fut_top > seen_top ? fut_top : seen_top; wait_for(prog_top, seen_top, need_top); fut_top = __hip_atomic_load(prog_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    // the data loads below must stay behind the polls in program order (the hardware issues a wave's loads in order and the
+    // branch on the polled value is a control dependency; this keeps the COMPILER from moving them up)
+    asm volatile("" ::: "memory");
   };
   Stage ring[P];
 #pragma unroll

@@ -313,10 +313,10 @@ def test_streaming_solver_kernel(mode, monkeypatch):
 
 
 def test_tile_solver_pipeline():
-    """levels of more than 96 rows are relaxed by the tile pipeline (varref_tiles.hip.h): one single-wave workgroup per (sweep,
-    band of 128 rows), (du,dv) handed from tile to tile through global memory behind progress words.  Sizes: op-pt 3 at 1080p
-    (levels 240x136: 2 bands, 480x272: 3 bands), a 132-row level (second band of 4 rows), op-pt 4 on a tall frame (544 rows:
-    5 bands), batches of two; 1, 2 and 4 sweeps.  Bit-identical to the oracle, no wait timed out."""
+    """levels of more than 96 rows are relaxed by the tile pipeline (varref_tiles.hip.h): one workgroup (solver wave + writer wave)
+    per (sweep, band of 64 rows), (du,dv) handed from tile to tile through global memory behind progress words.  Sizes: op-pt 3 at
+    1080p (levels 240x136: 3 bands, 480x272: 5 bands), a 132-row level (third band of 4 rows), op-pt 4 on a tall frame (544 rows:
+    9 bands), batches of two; 1, 2 and 4 sweeps.  Bit-identical to the oracle, no wait timed out."""
     F, OFClass, _, O = _mods()
     before = F.lib().fotg_debug_counter(b"sor_tiles")
     for (w, h), op_point, width_for_op, sweeps in (((1920, 1080), 3, 1920, 3), ((640, 528), 3, 640, 3), ((480, 2176), 4, 3840, 3),
@@ -334,6 +334,25 @@ def test_tile_solver_pipeline():
         assert F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
         ofc.close()
     assert F.lib().fotg_debug_counter(b"sor_tiles") > before
+
+
+def test_tile_solver_more_tiles_than_cus():
+    """a launch with more tiles than the GPU has CUs (24 pairs x (3 + 5 bands) x 3 sweeps = 216 and 360 tiles on 256 CUs): roles are
+    dealt by ticket in dependency order, so the resident tiles never wait for one that has not started.  Every pair of the batch is
+    the same pair: 24 identical results, equal to the oracle's"""
+    F, OFClass, _, O = _mods()
+    n = 24
+    f0, f1 = synth_pair(1080, 1920, seed=6)
+    op = F.operating_point(3, 1920, 1)
+    ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=op.patch_size), max_batch=n)
+    a, b = dev(f0)[None].expand(n, -1, -1).contiguous(), dev(f1)[None].expand(n, -1, -1).contiguous()
+    out = ofc.calc_batch(a, b).cpu().numpy()
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    for k in range(n):
+        assert np.array_equal(out[k], ref), k
+    assert F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
+    ofc.close()
 
 
 @pytest.mark.parametrize("wide", ["1", "0"])
