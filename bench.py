@@ -9,6 +9,12 @@ over one batch of synthetic 1920x1080 frame pairs already resident in HBM (BASEL
 op-pt 2 + refinement on).  Frame pairs are independent, so N ranks each process their own batch (weak scaling, no
 data-path collective); value = pairs all ranks processed / max-over-ranks time.
 
+Batches in flight: the path is latency-bound at batch 64 (the refinement keeps a quarter of the CUs busy), so consecutive
+steps -- each a complete batch -- are submitted to --in-flight engine contexts on internal streams in turn
+(flowonthego_amd.FlowPipeline = fotg_pipe_* of include/fotg.h) and overlap on the GPU; every window still holds exactly K
+complete steps between its barriers (the window ends with a host wait for all contexts).  The same window with one batch at
+a time through a single context (fotg_calc_batch) is timed too and reported as `one_batch_at_a_time`.
+
 Extra objects in the JSON line:
   roofline      HBM roofline of the kernel that moves the path's algorithmic bytes (pyr_base_kernel: every input byte
                 exactly once), duration measured live with HIP events on the launch stream
@@ -23,6 +29,11 @@ import json
 import os
 import sys
 import time
+
+# HIP deals its streams to GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream included); two busy streams on one
+# queue run one after the other.  Four batches in flight need a queue each (measured: 134 k pairs/s with 4 queues, 165 k with 8).
+# Read by the runtime when it is loaded, i.e. before torch is imported; an explicit setting of the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
@@ -255,6 +266,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU per step (BASELINE configs[2]: 64)")
     ap.add_argument("--windows", type=int, default=25, help="repeats of the timed K-step window; the median window is reported")
+    ap.add_argument("--in-flight", type=int, default=4, help="batches in flight per GPU: consecutive steps go to this many engine "
+                    "contexts on internal streams in turn (flowonthego_amd.FlowPipeline / fotg_pipe_*); 1 = one batch at a time "
+                    "through a single context (fotg_calc_batch), which is also timed and reported beside `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time the video entry point fotg_calc_sequence (off by default: "
@@ -287,15 +301,32 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        ofc.calc_batch(I0, I1, None, out)
+    # The timed loop: every step is one full batch through the whole path.  With --in-flight D > 1 step i is submitted to engine
+    # context i % D (own internal stream, own frames and output buffer of that slot) and overlaps with the steps before it -- the
+    # path is latency-bound at this batch size, and a server keeps several batches in flight.  Every window ends with a host
+    # wait for all slots, so exactly K complete steps lie between the two barriers.
+    D = max(1, a.in_flight)
+    pipe = None
+    if D > 1:
+        from flowonthego_amd.pipeline import FlowPipeline
+        pipe = FlowPipeline(op, F.img_params(width=W, height=H, padding=op.patch_size), max_batch=a.batch, depth=D, device=local)
+        slots = [(I0, I1, out)] + [synth_batch(a.batch, 1234 + rank + 97 * k, dev) + (ofc.new_outflow(a.batch),) for k in range(1, D)]
 
-    def window():
+    def run_steps(n, pipelined):
+        if pipelined:
+            for i in range(n):
+                f0, f1, o = slots[i % D]
+                pipe.submit(f0, f1, None, o, after_current_stream=False)       # the frames are resident, nothing to wait for
+            pipe.synchronize()
+        else:
+            for _ in range(n):
+                ofc.calc_batch(I0, I1, None, out)
+
+    def window(pipelined):
         """EXACTLY a.steps steps between barrier + synchronize on both sides; max over ranks"""
         barrier()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            ofc.calc_batch(I0, I1, None, out)
+        run_steps(a.steps, pipelined)
         barrier()
         el = time.perf_counter() - t0
         if dist:
@@ -304,13 +335,20 @@ def main():
             el = float(t.item())
         return el
 
+    run_steps(a.warmup, False)
+    if pipe:
+        run_steps(max(a.warmup, D), True)
+        torch.cuda.synchronize()
+        same = all(torch.equal(ofc.calc_batch(f0, f1), o) for f0, f1, o in slots[:2])       # pipelined results = single-context results
     # One window of K steps at this batch is ~10 ms -- too short to be robust against clock ramp and launch jitter.  The
     # K-step window is therefore repeated (every repeat is again exactly K steps between barriers); `value` / `ms_per_step`
     # are those of the MEDIAN window, the spread is reported beside them.
-    els = sorted(window() for _ in range(max(1, a.windows)))
+    els = sorted(window(pipe is not None) for _ in range(max(1, a.windows)))
     el = els[len(els) // 2]
     ms_step = el / a.steps * 1e3
     value = world * a.batch * a.steps / el
+    els1 = sorted(window(False) for _ in range(max(1, min(a.windows, 9)))) if pipe else els
+    el1 = els1[len(els1) // 2]
 
     res = {"metric": "frame-pairs/sec @1080p DIS op-pt 2", "value": value, "unit": "frame-pairs/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
@@ -319,15 +357,24 @@ def main():
                                   "(ps=8, stride 4, scales 6-5-4, 12 LK iterations) + variational refinement on, "
                                   "%s SOR; inputs resident in HBM, output = finest-scale flow 120x68x2" %
                                   (a.batch, "lexicographic (reference order)" if a.sor_mode == 0 else "red-black"),
-                      "global_batch": world * a.batch, "parallelism": "frame-pair sharding x%d (no collective)" % world},
+                      "global_batch": world * a.batch,
+                      "parallelism": "frame-pair sharding x%d (no collective)%s" % (world, "; %d batches in flight per GPU (engine contexts on "
+                                     "internal streams, fotg_pipe_*): step i runs on context i %% %d" % (D, D) if pipe else "")},
            "timed_windows": {"n": len(els), "steps_each": a.steps, "ms_per_step_median": ms_step, "ms_per_step_min": els[0] / a.steps * 1e3,
-                             "ms_per_step_max": els[-1] / a.steps * 1e3}}
+                             "ms_per_step_max": els[-1] / a.steps * 1e3},
+           "batches_in_flight": D,
+           "one_batch_at_a_time": {"value": world * a.batch * a.steps / el1, "unit": "frame-pairs/s", "ms_per_step": el1 / a.steps * 1e3,
+                                   "note": "the same K-step window with every step through ONE context on one stream (fotg_calc_batch), "
+                                           "each step starting when the previous one has finished on the GPU"}}
+    if pipe:
+        res["pipeline_matches_single_context"] = bool(same)
 
     if rank == 0:
         stream_ptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if not a.no_breakdown:
             st = stage_breakdown(ofc, I0, I1, out, lib, stream_ptr)
             res["stage_ms"] = {k: round(v, 4) for k, v in st.items()}
+            res["stage_ms_note"] = "each stage alone on one stream: their sum is the time of ONE batch from start to end (one_batch_at_a_time); with batches in flight the stages of different batches overlap"
             res["roofline"] = roofline(ofc, I0, I1, lib, stream_ptr, a.batch)
             if op.use_var_ref and a.sor_mode == 0:
                 res["roofline_dominant"] = roofline_dominant(ofc, lib, stream_ptr, a.batch, st)

@@ -12,4 +12,7 @@ def __getattr__(name):
     if name in ("OFClass", "PatGridClass", "VarRefClass"):
         from . import oflow
         return getattr(oflow, name)
+    if name == "FlowPipeline":
+        from .pipeline import FlowPipeline
+        return FlowPipeline
     raise AttributeError(name)

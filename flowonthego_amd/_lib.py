@@ -35,6 +35,13 @@ SYMBOLS = [
     ("fotg_level_timings", C.c_int, [vp, C.c_int, f32p]),
     ("fotg_calc_sequence", C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     ("fotg_calc_sequence_u8", C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+    ("fotg_pipe_create", C.c_int, [C.POINTER(FotgParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    ("fotg_pipe_destroy", None, [vp]),
+    ("fotg_pipe_submit", C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_long)]),
+    ("fotg_pipe_submit_u8", C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_long)]),
+    ("fotg_pipe_wait", C.c_int, [vp, C.c_long, vp, C.c_int]),
+    ("fotg_pipe_sync", C.c_int, [vp]),
+    ("fotg_pipe_context", C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     ("fotg_calc", C.c_int, [vp, vp, vp, vp, vp]),
     ("fotg_upsample_crop", C.c_int, [vp, C.c_int, vp, vp, vp]),
     ("fotg_level_size", C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -370,8 +370,10 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
     if (c->nsub < 1) c->nsub = 1;
     if (c->nsub > 8) c->nsub = 8;
     c->use_graph = env_int("FOTG_GRAPH", 1);
-    if (hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
     if (c->nsub > 1) {
+      // (streams are only created where they are used: HIP deals its streams to a handful of hardware queues, and two busy
+      // streams on one queue run one after the other -- fotg_pipe_create relies on getting a queue per slot)
+      if (hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       for (int i = 0; i < c->nsub; ++i)
         if (hipStreamCreateWithFlags(&c->sub_stream[i], hipStreamNonBlocking) != hipSuccess ||
@@ -1387,6 +1389,117 @@ int fotg_calc_batch_u8(fotg_ctx *c, int n, const unsigned char *I0, const unsign
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
   ON_DEVICE(c->device);
   return calc_range<unsigned char>(c, n, I0, I1, initflow, outflow, (hipStream_t)stream);
+}
+
+/* ---- batches in flight ---------------------------------------------------------------------------------------------
+ * The path is latency-bound at batch 64 (the refinement keeps a quarter of the CUs busy), and consecutive batches are
+ * independent.  A pipe owns `depth` engine contexts, each with a non-blocking stream of its own; batch k goes to context
+ * k % depth and overlaps with the batches before it.  No host synchronisation anywhere: a slot's stream orders the reuse of
+ * its context, events order it against the caller's streams. */
+struct fotg_pipe {
+  int device, depth;
+  fotg_ctx *ctx[FOTG_PIPE_MAX_DEPTH];
+  hipStream_t stream[FOTG_PIPE_MAX_DEPTH];
+  hipEvent_t ready[FOTG_PIPE_MAX_DEPTH], done[FOTG_PIPE_MAX_DEPTH];
+  long submitted;
+};
+
+void fotg_pipe_destroy(fotg_pipe *q)
+{
+  if (!q) return;
+  DevGuard dg(q->device);
+  for (int k = 0; k < q->depth; ++k) {
+    if (q->stream[k]) (void)hipStreamSynchronize(q->stream[k]);
+    if (q->ctx[k]) fotg_destroy(q->ctx[k]);
+    if (q->ready[k]) (void)hipEventDestroy(q->ready[k]);
+    if (q->done[k]) (void)hipEventDestroy(q->done[k]);
+    if (q->stream[k]) (void)hipStreamDestroy(q->stream[k]);
+  }
+  delete q;
+}
+
+int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int max_batch, int depth, fotg_pipe **out)
+{
+  if (!out || depth < 1 || depth > FOTG_PIPE_MAX_DEPTH) return FOTG_ERR_ARG;
+  ON_DEVICE(device);
+  fotg_pipe *q = new (std::nothrow) fotg_pipe();
+  if (!q) return FOTG_ERR_ARG;
+  memset((void *)q, 0, sizeof(*q));
+  q->device = device; q->depth = depth;
+  // the slots' streams first and back to back, so that the runtime spreads them over its hardware queues
+  for (int k = 0; k < depth; ++k)
+    if (hipStreamCreateWithFlags(&q->stream[k], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&q->ready[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&q->done[k], hipEventDisableTiming) != hipSuccess) {
+      g_last_hip = (int)hipGetLastError();
+      fotg_pipe_destroy(q);
+      return FOTG_ERR_HIP;
+    }
+  for (int k = 0; k < depth; ++k) {
+    const int st = fotg_create(p, w_org, h_org, device, max_batch, &q->ctx[k]);
+    if (st != FOTG_OK) { fotg_pipe_destroy(q); return st; }
+  }
+  *out = q;
+  return FOTG_OK;
+}
+
+extern "C++" {
+template <typename T>
+static int pipe_submit(fotg_pipe *q, int n, const T *I0, const T *I1, const float *initflow, float *outflow, void *after_stream, long *ticket)
+{
+  if (!q || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
+  const int k = (int)(q->submitted % q->depth);
+  fotg_ctx *c = q->ctx[k];
+  if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  ON_DEVICE(q->device);
+  // the frames (and the reuse of outflow) are ordered behind what the caller has enqueued on `after_stream` so far
+  if (after_stream != FOTG_NO_STREAM) {
+    HIPCHK(hipEventRecord(q->ready[k], (hipStream_t)after_stream));
+    HIPCHK(hipStreamWaitEvent(q->stream[k], q->ready[k], 0));
+  }
+  const int st = calc_range<T>(c, n, I0, I1, initflow, outflow, q->stream[k]);
+  if (st != FOTG_OK) return st;
+  HIPCHK(hipEventRecord(q->done[k], q->stream[k]));
+  if (ticket) *ticket = q->submitted;
+  ++q->submitted;
+  return FOTG_OK;
+}
+}  // extern "C++"
+
+int fotg_pipe_submit(fotg_pipe *q, int n, const float *I0, const float *I1, const float *initflow, float *outflow, void *after_stream, long *ticket)
+{
+  return pipe_submit<float>(q, n, I0, I1, initflow, outflow, after_stream, ticket);
+}
+
+int fotg_pipe_submit_u8(fotg_pipe *q, int n, const unsigned char *I0, const unsigned char *I1, const float *initflow, float *outflow, void *after_stream, long *ticket)
+{
+  return pipe_submit<unsigned char>(q, n, I0, I1, initflow, outflow, after_stream, ticket);
+}
+
+int fotg_pipe_wait(fotg_pipe *q, long ticket, void *stream, int host_wait)
+{
+  if (!q || ticket < 0 || ticket >= q->submitted) return FOTG_ERR_ARG;
+  ON_DEVICE(q->device);
+  // (a slot that has been reused since carries a later batch of the same stream: waiting for that one covers the ticket)
+  const int k = (int)(ticket % q->depth);
+  if (host_wait) { HIPCHK(hipEventSynchronize(q->done[k])); }
+  else { HIPCHK(hipStreamWaitEvent((hipStream_t)stream, q->done[k], 0)); }
+  return FOTG_OK;
+}
+
+int fotg_pipe_sync(fotg_pipe *q)
+{
+  if (!q) return FOTG_ERR_ARG;
+  ON_DEVICE(q->device);
+  for (int k = 0; k < q->depth; ++k) HIPCHK(hipStreamSynchronize(q->stream[k]));
+  return FOTG_OK;
+}
+
+int fotg_pipe_context(fotg_pipe *q, int slot, fotg_ctx **ctx)
+{
+  if (!q || !ctx || slot < 0 || slot >= q->depth) return FOTG_ERR_ARG;
+  *ctx = q->ctx[slot];
+  return FOTG_OK;
 }
 
 /* sequence mode (SURVEY 8f "next" row 2): n_frames consecutive frames -> n_frames - 1 flows (frame k -> k+1) */

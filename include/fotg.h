@@ -95,6 +95,30 @@ int fotg_calc_batch_u8(fotg_ctx *ctx, int n, const unsigned char *I0, const unsi
 int fotg_calc_sequence(fotg_ctx *ctx, int n_frames, const float *frames, const float *initflow, float *outflow, void *stream);
 int fotg_calc_sequence_u8(fotg_ctx *ctx, int n_frames, const unsigned char *frames, const float *initflow, float *outflow,
                           void *stream);
+/* ---- batches in flight (no reference equivalent: the reference's calc() is synchronous, one pair at a time) -------------
+ * A pipe owns `depth` engine contexts, each on an internal non-blocking stream.  fotg_pipe_submit enqueues one batch exactly
+ * like fotg_calc_batch (same arguments, same bits) on the next context in turn and returns at once; up to `depth` batches
+ * overlap on the GPU.  The work starts behind everything enqueued so far on `after_stream` (the stream that produced the
+ * frames; NULL = default stream), or at once with after_stream = FOTG_NO_STREAM (frames already in place; note that an event
+ * on a busy stream is only reached when that stream's queue has drained).  The caller keeps I0 / I1 / outflow alive and
+ * untouched until the ticket has been waited for. */
+#define FOTG_PIPE_MAX_DEPTH 8
+#define FOTG_NO_STREAM ((void *)(-1))
+typedef struct fotg_pipe fotg_pipe;
+int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int max_batch, int depth, fotg_pipe **out);
+void fotg_pipe_destroy(fotg_pipe *pipe);
+int fotg_pipe_submit(fotg_pipe *pipe, int n, const float *I0, const float *I1, const float *initflow, float *outflow,
+                     void *after_stream, long *ticket);
+int fotg_pipe_submit_u8(fotg_pipe *pipe, int n, const unsigned char *I0, const unsigned char *I1, const float *initflow,
+                        float *outflow, void *after_stream, long *ticket);
+/* host_wait = 0: `stream` (NULL = default stream) waits for batch `ticket` on the device, the call returns at once;
+ * host_wait != 0: the calling thread waits */
+int fotg_pipe_wait(fotg_pipe *pipe, long ticket, void *stream, int host_wait);
+/* the calling thread waits for everything submitted so far */
+int fotg_pipe_sync(fotg_pipe *pipe);
+/* the engine context of a slot (geometry queries, taps, counters) */
+int fotg_pipe_context(fotg_pipe *pipe, int slot, fotg_ctx **ctx);
+
 /* Single pair, outflow in HOST memory, synchronous -- the exact shape of the reference call. */
 int fotg_calc(fotg_ctx *ctx, const float *I0, const float *I1, const float *initflow, float *outflow_host);
 

@@ -336,6 +336,42 @@ def test_tile_solver_pipeline():
     assert F.lib().fotg_debug_counter(b"sor_tiles") > before
 
 
+def test_flow_pipeline_batches_in_flight():
+    """FlowPipeline (fotg_pipe_*): consecutive batches go to `depth` engine contexts on internal streams in turn and overlap;
+    every batch has the bits of OFClass.calc_batch -- different inputs and batch sizes per submit, more submits than slots,
+    float and 8-bit frames, waits on the device and on the host, results of a reused slot"""
+    F, OFClass, _, O = _mods()
+    from flowonthego_amd.pipeline import FlowPipeline
+    w, h, nb = 640, 360, 3
+    op = F.operating_point(2, w, 1)
+    ip = F.img_params(width=w, height=h, padding=op.patch_size)
+    ofc = OFClass(op, ip, max_batch=nb)
+    pipe = FlowPipeline(op, ip, max_batch=nb, depth=3)
+    assert pipe.out_size() == ofc.out_size()
+    batches = []
+    for k in range(8):
+        n = 1 + k % nb
+        fr = [synth_pair(h, w, seed=40 + 3 * k + j) for j in range(n)]
+        a, b = dev(np.stack([f[0] for f in fr])), dev(np.stack([f[1] for f in fr]))
+        if k % 4 == 3:                                                    # 8-bit frames
+            a, b = a.round().clamp(0, 255).to(torch.uint8), b.round().clamp(0, 255).to(torch.uint8)
+        batches.append((a, b))
+    tickets = [pipe.submit(a, b) for a, b in batches]
+    assert [t for t, _ in tickets] == list(range(8))
+    pipe.wait(tickets[2][0], host=True)
+    pipe.wait(tickets[7][0])                                              # the current stream waits on the device
+    torch.cuda.synchronize()
+    pipe.synchronize()
+    for (a, b), (_, out) in zip(batches, tickets):
+        ref = ofc.calc_batch_u8(a, b) if a.dtype == torch.uint8 else ofc.calc_batch(a, b)
+        assert torch.equal(out, ref)
+    with pytest.raises(F.FotgError):
+        pipe.submit(batches[0][0][:, :-1], batches[0][1][:, :-1])
+    with pytest.raises(F.FotgError):
+        pipe.wait(99)
+    pipe.close(); ofc.close()
+
+
 def test_tile_solver_more_tiles_than_cus():
     """a launch with more tiles than the GPU has CUs (24 pairs x (3 + 5 bands) x 3 sweeps = 216 and 360 tiles on 256 CUs): roles are
     dealt by ticket in dependency order, so the resident tiles never wait for one that has not started.  Every pair of the batch is
