@@ -19,3 +19,17 @@ for _ in range(5):
     ofc.calc(a, b)
 torch.cuda.synchronize()
 print("4K op-pt 4 (scales %d..%d): %.2f ms per pair" % (op.coarsest_scale, op.finest_scale, (time.perf_counter() - t) / 5 * 1e3))
+# consecutive pairs of a 4K video through a FlowPipeline (one pair per submit, several in flight)
+from flowonthego_amd.pipeline import FlowPipeline
+for depth in (2, 4):
+    pipe = FlowPipeline(op, F.img_params(width=3840, height=2160, padding=op.patch_size), max_batch=1, depth=depth)
+    outs = [pipe.new_outflow(1) for _ in range(depth)]
+    for k in range(2 * depth):
+        pipe.submit(a[None], b[None], None, outs[k % depth], after_current_stream=False)
+    pipe.synchronize(); t = time.perf_counter()
+    n = 6 * depth
+    for k in range(n):
+        pipe.submit(a[None], b[None], None, outs[k % depth], after_current_stream=False)
+    pipe.synchronize()
+    print("4K op-pt 4, %d pairs in flight: %.2f ms per pair (throughput), same bits: %s" % (depth, (time.perf_counter() - t) / n * 1e3, bool(torch.equal(outs[0][0], ofc.calc(a, b)))))
+    pipe.close()
