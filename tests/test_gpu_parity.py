@@ -886,6 +886,27 @@ def test_cpp_shim_run_dense_example(tmp_path):
         assert np.array_equal(read_flo(out), O.full_flow(f0, f1, op=2)), noc
 
 
+def test_cpp_video_pipeline_example(tmp_path):
+    """examples/video_pipeline.cpp: consecutive frame pairs of a clip submitted to OFC::FlowPipeline (include/fotg/pipeline.h)
+    behind their uploads, three pairs in flight -- every flow equals the oracle's for that pair"""
+    import subprocess
+    from test_host import _build_example
+    F, OFClass, _, O = _mods()
+    exe = _build_example(tmp_path, "video_pipeline")
+    h, w, n = 272, 480, 6
+    fr = [synth_pair(h, w, seed=90 + k)[0] for k in range(n)]
+    src, out = str(tmp_path / "frames.raw"), str(tmp_path / "flows.raw")
+    np.stack(fr).astype(np.float32).tofile(src)
+    r = subprocess.run([exe, src, str(w), str(h), str(n), out, "3", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    op = F.operating_point(2, w, 1)
+    p = oracle_params(O, op)
+    ow, oh = O.padded_size(w, h, p.sc_f)[0] >> p.sc_l, O.padded_size(w, h, p.sc_f)[1] >> p.sc_l
+    flows = np.fromfile(out, np.float32).reshape(n - 1, oh, ow, 2)
+    for k in range(n - 1):
+        assert np.array_equal(flows[k], O.flow(O.pad_frame(fr[k], p.sc_f), O.pad_frame(fr[k + 1], p.sc_f), p, 0)), k
+
+
 def test_cpp_shim_reference_scale_loop(tmp_path):
     """examples/oflow_scale_loop.cpp: the reference's scale loop written with the shim classes, grids and VarRefClass constructed
     with the reference's own constructor signatures (src/oflow.cpp:101, :332; the context comes from the registry), equals

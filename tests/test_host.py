@@ -156,6 +156,12 @@ def test_cpp_shim_example_builds(tmp_path):
     assert os.path.exists(exe)
 
 
+def test_cpp_pipeline_example_builds(tmp_path):
+    """include/fotg/pipeline.h (several batches in flight, fotg_pipe_*) compiles and links as a video-loop program"""
+    exe = _build_example(tmp_path, "video_pipeline")
+    assert os.path.exists(exe)
+
+
 def test_no_kernel_uses_scratch_memory():
     """the build keeps the compiler's per-kernel resource table (flowonthego_amd/libfotg.resusage.txt, written by the
     Makefile with -Rpass-analysis=kernel-resource-usage): no kernel of the product may have a private-memory segment --
