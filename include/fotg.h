@@ -101,7 +101,8 @@ int fotg_calc_sequence_u8(fotg_ctx *ctx, int n_frames, const unsigned char *fram
  * overlap on the GPU.  The work starts behind everything enqueued so far on `after_stream` (the stream that produced the
  * frames; NULL = default stream), or at once with after_stream = FOTG_NO_STREAM (frames already in place; note that an event
  * on a busy stream is only reached when that stream's queue has drained).  The caller keeps I0 / I1 / outflow alive and
- * untouched until the ticket has been waited for. */
+ * untouched until the ticket has been waited for.  A pipe is used from one thread at a time (like a context); batches complete
+ * in submission order per slot, and waiting for a ticket whose slot has been reused waits for the later batch in that slot. */
 #define FOTG_PIPE_MAX_DEPTH 8
 #define FOTG_NO_STREAM ((void *)(-1))
 typedef struct fotg_pipe fotg_pipe;
