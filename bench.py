@@ -262,7 +262,7 @@ def cpu_baseline(I0, I1, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100, help="steps per timed window (with batches in flight a window starts with an empty pipeline and ends with a drain: short windows under-report)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU per step (BASELINE configs[2]: 64)")
     ap.add_argument("--windows", type=int, default=25, help="repeats of the timed K-step window; the median window is reported")
