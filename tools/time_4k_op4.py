@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""BASELINE configs[3]: one 3840x2160 pair at operating point 4 (quality preset): python tools/time_4k_op4.py"""
+"""BASELINE configs[3]: one 3840x2160 pair at operating point 4 (quality preset): python tools/time_4k_op4.py [--in-flight]
+(--in-flight: also the throughput of consecutive pairs through a FlowPipeline, 2 and 4 pairs in flight)"""
 import sys, time
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # (a hardware queue per pipeline slot, see bench.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
@@ -21,7 +23,7 @@ torch.cuda.synchronize()
 print("4K op-pt 4 (scales %d..%d): %.2f ms per pair" % (op.coarsest_scale, op.finest_scale, (time.perf_counter() - t) / 5 * 1e3))
 # consecutive pairs of a 4K video through a FlowPipeline (one pair per submit, several in flight)
 from flowonthego_amd.pipeline import FlowPipeline
-for depth in (2, 4):
+for depth in ((2, 4) if "--in-flight" in sys.argv else ()):
     pipe = FlowPipeline(op, F.img_params(width=3840, height=2160, padding=op.patch_size), max_batch=1, depth=depth)
     outs = [pipe.new_outflow(1) for _ in range(depth)]
     for k in range(2 * depth):
