@@ -40,7 +40,7 @@ if len(sys.argv) > 6:
     with open("profiles/%s_4k_op4_kernel_stats.md" % tag, "w") as o:
         o.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/time_4k_op4.py   (MI355X)\n")
         o.write("# BASELINE configs[3]: one 3840x2160 gray f32 pair, operating point 4 (ps 12, 6 scales, 128 LK iterations, refinement); 7 calls\n")
-        o.write("".join("# %s (under the profiler)\n" % l for l in line) + "\n| kernel | calls | total ns | avg ns | %% |\n|---|---|---|---|---|\n")
+        o.write("".join("# %s (under the profiler)\n" % l for l in line) + "\n| kernel | calls | total ns | avg ns | % |\n|---|---|---|---|---|\n")
         for r in rows:
             if "fotg" in r["Name"] or "rocclr" in r["Name"]:
                 o.write("| %s | %s | %s | %.0f | %s |\n" % (r["Name"][:110], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
