@@ -337,6 +337,7 @@ def main():
 
     run_steps(a.warmup, False)
     if pipe:
+        torch.cuda.synchronize()      # the pipe's streams do not wait for torch's: slot 0 shares its buffers with the warm-up above
         run_steps(max(a.warmup, D), True)
         torch.cuda.synchronize()
         same = all(torch.equal(ofc.calc_batch(f0, f1), o) for f0, f1, o in slots[:2])       # pipelined results = single-context results

@@ -68,7 +68,24 @@ struct FotgTune {
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
+#ifdef FOTG_DEBUG
+#include <map>
+#include <mutex>
+static std::map<void *, void *> g_dbg_base;      // user pointer -> allocation base (FOTG_DEBUG_GUARD)
+static std::mutex g_dbg_mu;
+static hipError_t fotg_dbg_free(void *p)
+{
+  void *base = p;
+  { std::lock_guard<std::mutex> g(g_dbg_mu); auto it = g_dbg_base.find(p); if (it != g_dbg_base.end()) { base = it->second; g_dbg_base.erase(it); } }
+  return (hipFree)(base);
+}
+#define hipFree(p) fotg_dbg_free((void *)(p))
+#endif
 struct fotg_ctx {
+#ifdef FOTG_DEBUG
+  struct Guard { const char *name; char *begin, *end; size_t size; } guards[256];      // FOTG_DEBUG_GUARD: a 64 KiB pattern behind every allocation
+  int nguards;
+#endif
   fotg_params p;
   FotgTune tune;
   int w_org, h_org, Wp, Hp, padw, padh, device, max_batch, noc, ps;
@@ -256,7 +273,22 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
     if (g.w < 1 || g.h < 1) { fotg_destroy(c); return FOTG_ERR_ARG; }
     c->lev_stride[l] = (long)g.tw * g.th * c->noc;
     const size_t bytes = B * c->lev_stride[l] * sizeof(float);
+#ifdef FOTG_DEBUG
+    // FOTG_DEBUG builds: FOTG_DEBUG_POISON=1 fills every allocation with 0xFF bytes (float NaN) so that a read of memory the engine
+    // never wrote shows up as a wrong result in the parity tests instead of depending on what the allocator hands out;
+    // FOTG_DEBUG_GUARD=1 puts 64 KiB of 0xA5 behind every allocation, fotg_ctx_counter("guard_violations") counts the guards
+    // that no longer hold the pattern (writes past the end of a buffer) and prints which
+#define FOTG_GUARD_BYTES 65536
+#define ALLOC(ptr, nbytes) do { const bool gd_ = getenv("FOTG_DEBUG_GUARD") != nullptr; const size_t nb_ = ((nbytes) + 255) & ~(size_t)255; char *base_ = nullptr; \
+    if (hipMalloc((void **)&base_, nb_ + (gd_ ? 2 * FOTG_GUARD_BYTES : 0)) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; } \
+    *(void **)&(ptr) = gd_ ? base_ + FOTG_GUARD_BYTES : base_; \
+    if (getenv("FOTG_DEBUG_POISON")) (void)hipMemset((ptr), getenv("FOTG_DEBUG_POISON")[0] == '2' ? 0x4B : 0xFF, nb_); \
+    if (gd_ && c->nguards < 256) { (void)hipMemset(base_, 0xA5, FOTG_GUARD_BYTES); (void)hipMemset(base_ + FOTG_GUARD_BYTES + nb_, 0xA5, FOTG_GUARD_BYTES); \
+      { std::lock_guard<std::mutex> g_(g_dbg_mu); g_dbg_base[(void *)(ptr)] = base_; } \
+      c->guards[c->nguards].name = #ptr; c->guards[c->nguards].begin = base_; c->guards[c->nguards].end = base_ + FOTG_GUARD_BYTES + nb_; c->guards[c->nguards++].size = nb_; } } while (0)
+#else
 #define ALLOC(ptr, nbytes) do { if (hipMalloc((void **)&(ptr), (nbytes)) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; } } while (0)
+#endif
     const size_t bytes1 = (B + 1) * c->lev_stride[l] * sizeof(float);       // sequence mode: max_batch pairs = max_batch + 1 frames
     ALLOC(c->im[0][l], bytes1);
     ALLOC(c->im[1][l], bytes);
@@ -1545,6 +1577,27 @@ long fotg_ctx_counter(fotg_ctx *c, const char *name)
 {
   if (!c || !name) return -1;
   if (!strcmp(name, "stage_stamps_ptr")) return (long)(size_t)c->stamps;
+#ifdef FOTG_DEBUG
+  if (!strcmp(name, "guard_violations")) {
+    DevGuard dg(c->device);
+    if (!dg.ok || hipDeviceSynchronize() != hipSuccess) return -1;
+    long bad = 0;
+    static unsigned char host[FOTG_GUARD_BYTES];
+    for (int k = 0; k < c->nguards; ++k)
+      for (int side = 0; side < 2; ++side) {
+        if (hipMemcpy(host, side ? c->guards[k].end : c->guards[k].begin, FOTG_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        int first = -1, last = -1;
+        for (int b = 0; b < FOTG_GUARD_BYTES; ++b) if (host[b] != 0xA5) { if (first < 0) first = b; last = b; }
+        if (first >= 0) {
+          ++bad;
+          if (side) printf("guard violated behind %s (%zu bytes): bytes %d..%d past the end\n", c->guards[k].name, c->guards[k].size, first, last);
+          else printf("guard violated in front of %s (%zu bytes): bytes %d..%d before the start\n", c->guards[k].name, c->guards[k].size, FOTG_GUARD_BYTES - last, FOTG_GUARD_BYTES - first);
+        }
+      }
+    fflush(stdout);
+    return bad;
+  }
+#endif
   if (!strcmp(name, "tile_timeouts")) {
     if (!c->tileSync) return 0;
     DevGuard dg(c->device);

@@ -35,9 +35,12 @@ class FlowPipeline:
         return torch.empty((n, h, w, self.nch), dtype=torch.float32, device=self.device)
 
     def submit(self, I0, I1, initflow=None, outflow=None, after_current_stream=True):
-        """enqueue one batch (n, h, w[, channels]) float32 or uint8 behind the current torch stream's work (or at once:
-        after_current_stream=False, the frames are already in place); returns (ticket, outflow).  I0, I1 and outflow must
-        stay alive and untouched until wait(ticket) / synchronize()."""
+        """enqueue one batch (n, h, w[, channels]) float32 or uint8 behind the current torch stream's work; returns
+        (ticket, outflow).  I0, I1 and outflow must stay alive and untouched until wait(ticket) / synchronize().
+        after_current_stream=False starts at once: the caller then guarantees that nothing still enqueued on a torch stream
+        writes the frames or touches `outflow` -- including earlier users of memory that torch's caching allocator has
+        recycled into these tensors (the pipe's streams are not torch's; synchronize once after allocating the buffers).
+        An outflow allocated here (outflow=None) always waits for the current stream for that reason."""
         u8 = I0.dtype == torch.uint8
         for t, nm in ((I0, "I0"), (I1, "I1")):
             _dev_f32(t, nm, self.device, dtype=torch.uint8 if u8 else torch.float32)
@@ -50,6 +53,7 @@ class FlowPipeline:
         w, h = self.out_size()
         if outflow is None:
             outflow = torch.empty((n, h, w, self.nch), dtype=torch.float32, device=self.device)
+            after_current_stream = True
         _dev_f32(outflow, "outflow", self.device, (n, h, w, self.nch))
         if initflow is not None:
             sc = self.op.coarsest_scale + 1

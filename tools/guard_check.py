@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""FOTG_DEBUG builds with FOTG_DEBUG_GUARD=1: run the headline batch (and a few other shapes) and count buffers that were written
+past their end: python tools/guard_check.py"""
+import os, sys
+os.environ["FOTG_DEBUG_GUARD"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+import bench
+import flowonthego_amd as F
+from flowonthego_amd.oflow import OFClass
+from flowonthego_amd._lib import lib
+from conftest import synth_pair
+dev = torch.device("cuda", 0)
+def run(w, h, opp, B, frames):
+    op = F.operating_point(opp, w, 1)
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=B)
+    for _ in range(3): ofc.calc_batch(*frames)
+    torch.cuda.synchronize()
+    print("%dx%d op-pt %d batch %d: guard violations %d" % (w, h, opp, B, lib().fotg_ctx_counter(ofc._h, b"guard_violations")), flush=True)
+    ofc.close()
+run(1920, 1080, 2, 64, bench.synth_batch(64, 1, dev))
+f0, f1 = synth_pair(1080, 1920, seed=3)
+a, b = torch.from_numpy(f0).cuda()[None], torch.from_numpy(f1).cuda()[None]
+run(1920, 1080, 2, 1, (a, b))
+run(1920, 1080, 3, 1, (a, b))
+f0, f1 = synth_pair(436, 1024, seed=3)
+run(1024, 436, 2, 1, (torch.from_numpy(f0).cuda()[None], torch.from_numpy(f1).cuda()[None]))
