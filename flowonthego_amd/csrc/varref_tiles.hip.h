@@ -4,14 +4,15 @@
 // solvers; round 1 relaxed them with one workgroup per pair (vr_sor_wide_kernel), i.e. on ONE CU, bound by that CU's L2 path
 // (three sweeps x 544 cells x 48 B per diagonal): 1.0 .. 1.5 ms per call, 57 % of a 4K operating-point-4 pair.
 //
-// Here the call is cut into TILES = (sweep n, band b of 64 rows), one single-wave workgroup each, all running at once:
+// Here the call is cut into TILES = (sweep n, band b of 64 rows), one workgroup (solver wave + writer wave) each, all running at once:
 //   tile (b, n) relaxes the cells of its rows diagonal by diagonal (the anti-diagonal wavefront of the lexicographic order) and
 //   needs   the NEW values of the row above its band        from tile (b-1, n)    one diagonal back,
 //           the OLD values (= sweep n-1) of its own rows     from tile (b,   n-1)  one diagonal ahead,
 //           the OLD value of the row below its band          from tile (b+1, n-1)  one diagonal ahead.
 // Every dependency points to a smaller b + 2n, so the tiles form a pipeline: each follows its producers at the distance the
-// hand-over needs (prefetch depth + publication granularity + latency, ~50 diagonals) and a call takes
-// (w + h) + ~50 (bands - 1 + 2 (sweeps - 1)) single-wave steps of ~0.12 us instead of (w + h + 12) steps of 0.7 .. 1 us.
+// hand-over needs (prefetch depth + publication granularity + latency, ~22 diagonals) and a call takes
+// (w + h) + ~22 (bands - 1 + 2 (sweeps - 1)) single-wave steps of ~0.13 us instead of (w + h + 12) steps of 0.7 .. 1 us
+// (measured: 75 / 135 / 238 us per call at 240x136 / 480x272 / 960x544; DESIGN.md section 5, "Tile pipeline").
 // Same cell updates in the same order as the row-major loop, hence the same bits.
 //
 // Hand-over through global memory (MI355X_MICROARCH.md, inter-workgroup visibility): sweep n writes the skewed array X[n]
@@ -19,7 +20,8 @@
 // 8-byte atomic (global_load / global_store ... sc1).  A tile is TWO waves: the solver wave only loads (a wave's vector-memory
 // operations complete in order, so a load issued behind a write-through store is not back before that store is acknowledged --
 // microseconds), hands its results to the WRITER wave through a small LDS ring, one barrier per G diagonals; the writer
-// stores them, and publishes a chunk's progress two chunks later, when a counted vmcnt says those stores have completed;
+// stores them, and publishes a chunk's progress two chunks later, when a counted vmcnt says those stores have completed
+// (stores that have no cell to go to land in a dump area used round robin: write-through stores to ONE line queue up);
 // X rows are a whole number of 128-byte lines, bands start on a line, one store instruction writes a band's 64 consecutive
 // cells = four whole lines.  Roles come from a ticket counter in the order of b + 2n: a tile
 // only waits for tiles holding lower tickets (running or finished by construction); every wait is bounded.
@@ -89,21 +91,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int S = a.S, RP = a.RP, RPD = a.RPD, h = a.h;
   // ---- role: ticket -> (pair, tile), tiles in the order of b + 2n
-#ifdef FOTG_TILE_SKIP_XCC
-  {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    if ((xcc & 15) == FOTG_TILE_SKIP_XCC - 1) return;
-  }
-#endif
   if (threadIdx.x == 0) role_s = atomicAdd(&g.sync[0], 1);
   __syncthreads();
   const int t = role_s;
-#ifdef FOTG_TILE_REVERSE
-  const int pair = t % g.npairs, idx = g.NB * nsweeps - 1 - t / g.npairs;      // (experiment: needs all workgroups resident)
-#else
   const int pair = t % g.npairs, idx = t / g.npairs;
-#endif
   int n = -1, b = -1;
   {
     int cnt = 0;
