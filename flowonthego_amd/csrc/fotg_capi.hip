@@ -221,6 +221,9 @@ int fotg_padded_size(int w, int h, int sc_f, int *wp, int *hp, int *padw, int *p
 void fotg_destroy(fotg_ctx *c)
 {
   if (!c) return;
+#ifdef FOTG_DEBUG
+  if (c->nguards > 0) (void)fotg_ctx_counter(c, "guard_violations");      // (prints what it finds)
+#endif
   for (int l = 0; l < FOTG_MAXLEV; ++l) {
     (void)hipFree(c->im[0][l]); (void)hipFree(c->im[1][l]); (void)hipFree(c->dx0[l]); (void)hipFree(c->dy0[l]);
     (void)hipFree(c->flow[l]); (void)hipFree(c->p_iter[l]); (void)hipFree(c->pweight[l]);
