@@ -262,6 +262,71 @@ def test_depth_varref_vs_live_reference(noc, w, h, camlr):
     assert np.array_equal(out[..., 0], ox)
 
 
+def _d1_sum(v, noc=1):
+    """definition D1 in numpy: 16 partial sums (pixel q -> partial q % 16, ascending), then the tree xor 8, 4, 2, 1"""
+    v = np.asarray(v, np.float32)
+    part = np.zeros(16, np.float32)
+    used = np.zeros(16, bool)
+    for e in range(len(v)):
+        l = (e // noc) % 16
+        part[l] = part[l] + v[e] if used[l] else v[e]
+        used[l] = True
+    k = 8
+    while k >= 1:
+        part = part + part[np.arange(16) ^ k]
+        k >>= 1
+    return part[0]
+
+
+@pytest.mark.parametrize("camlr", [0, 1])
+def test_depth_lk_numpy_restatement(camlr):
+    """the depth-specific pieces of the patch optimisation (kroeger/patch.cpp, SELECTMODE 2), written again in numpy from
+    the reference text and compared with the oracle bit for bit after ONE iteration from an integer start position:
+    scalar Hessian sum(Tx^2) with the 1e-10 guard (:83-87), one projection sum(Tx * pdiff) (:181), the 1x1 LLT solve
+    (L = sqrt(H), y = d / L, x = y / L, :184), p -= x (:186), the sign clamp by camera side (:188-193), y untouched
+    (:218-220), reset to p_in when the patch leaves the valid region or moves more than ps/2 (:199-208).  The template,
+    its gradient and the query patch at an integer position are plain pixel reads (shared with the flow mode, pinned
+    through the golden .flo)"""
+    h, w, ps = 136, 240, 8
+    f0, f1 = synth_pair(h, w, seed=21)
+    f1 = np.roll(f0, -1 if camlr == 0 else 1, axis=1)              # a one-pixel disparity of the admissible sign
+    p = depth_params(2, w)
+    p.sc_f = p.sc_l = 0
+    p.max_iter = p.min_iter = 1
+    P0, P1 = O.Pyramid(O.pad_frame(f0, 0), 0, ps), O.Pyramid(O.pad_frame(f1, 0), 0, ps)
+    g = O.Grid(*P0.level_wh(0), 0, p, camlr=camlr)
+    g.init(P0.im[0], P0.dx[0], P0.dy[0])
+    tr = g.optimize(P1.im[0], trace=True)
+    I1 = P1.im[0][..., 0]
+    lb, ubw, ubh = -ps / 2.0, float(w + ps // 2 - 2), float(h + ps // 2 - 2)
+    T, Tx, ref = g.tmpl, g.tdx, g.pt_ref
+    nv = ps * ps
+    checked = moved = 0
+    for ip in range(0, g.nop, 7):
+        rx, ry = float(ref[ip, 0]), float(ref[ip, 1])
+        if rx < lb or ry < lb or rx > ubw or ry > ubh:
+            continue                                                 # never started (oracle definition D2)
+        H = _d1_sum(Tx[ip] * Tx[ip])
+        if H == 0:
+            H = np.float32(np.float64(H) + 1e-10)
+        x0, y0 = int(rx) + ps - ps // 2, int(ry) + ps - ps // 2     # padded coordinates of the patch's first pixel
+        q = I1[y0:y0 + ps, x0:x0 + ps].reshape(-1).astype(np.float32)
+        q = q - np.float32(_d1_sum(q) / np.float32(nv))             # mean normalisation (patch.cpp:330-331 / :397-398)
+        pdiff = q - T[ip]
+        d = _d1_sum(Tx[ip] * pdiff)
+        L = np.sqrt(np.float32(H))
+        x = np.float32(np.float32(d / L) / L)
+        pn = np.float32(0.0) - x
+        pn = min(pn, np.float32(0.0)) if camlr == 0 else max(pn, np.float32(0.0))
+        px = np.float32(rx) + pn
+        if abs(float(np.float32(rx) - px)) > ps / 2 or px < lb or px > ubw:
+            pn = np.float32(0.0)                                     # reset to p_in
+        assert tr[ip, 1, 0] == pn and tr[ip, 1, 1] == 0 and g.p_iter[ip, 0] == pn, ip
+        checked += 1
+        moved += pn != 0
+    assert checked > 50 and moved > 20
+
+
 def test_depth_recovers_disparity():
     """whole depth pipeline on a synthetic rectified pair: the second view is the first shifted left, so the disparity is
     negative (left camera, camlr 0) and the clamp p <= 0 never binds at the solution"""
