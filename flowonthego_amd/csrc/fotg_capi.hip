@@ -127,6 +127,10 @@ struct fotg_ctx {
   int x_rt[FOTG_MAXLEV];
   int *tileSync;
   int *vrSync;
+  // a bounded inter-workgroup wait that gave up (tile / resident pipelines) sets this word of pinned host memory from the device;
+  // fotg_calc, fotg_pipe_wait(host_wait) and fotg_pipe_sync read it after their synchronisation and return FOTG_ERR_STALL
+  int *stall_host, *stall_dev;
+  long stalls;                       // host-side count of the times the word was found set
   int sync_block;                    // which block of vrSync this (view of the) context uses
   void *vrZero;
   unsigned long long *stamps;        // -DFOTG_STAGE_STAMPS builds only
@@ -178,6 +182,7 @@ const char *fotg_strerror(int s)
     case FOTG_ERR_HIP: return "HIP runtime error";
     case FOTG_ERR_BATCH: return "batch larger than max_batch";
     case FOTG_ERR_UNSUPPORTED: return "unsupported configuration";
+    case FOTG_ERR_STALL: return "a bounded inter-workgroup wait timed out: the flow of this call is not valid";
     default: return "unknown status";
   }
 }
@@ -232,6 +237,7 @@ void fotg_destroy(fotg_ctx *c)
     (void)hipFree(c->trace_dev[l]);
     (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]); (void)hipFree(c->vrX[l]);
   }
+  if (c->stall_host) (void)hipHostFree(c->stall_host);
   (void)hipFree(c->vr); (void)hipFree(c->vrQ); (void)hipFree(c->vrDS); (void)hipFree(c->vrSync); (void)hipFree(c->vrZero); (void)hipFree(c->tileSync);
   for (int i = 0; i < 8; ++i) {
     if (c->sub_stream[i]) (void)hipStreamDestroy(c->sub_stream[i]);
@@ -267,6 +273,9 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_tiles = env_int("FOTG_VR_TILES", 1);
   c->tune.vr_stage = env_int("FOTG_VR_STAGE", 0);      // opt-in: measured slower than the per-iteration launches at batch 64
   c->tune.vr_stage_mins = env_int("FOTG_VR_STAGE_MINS", 80);
+  if (hipHostMalloc((void **)&c->stall_host, 64, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&c->stall_dev, c->stall_host, 0) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; }
+  memset(c->stall_host, 0, 64);
   fotg_padded_size(w_org, h_org, p->sc_f, &c->Wp, &c->Hp, &c->padw, &c->padh);
   c->base_lv = p->sc_l < 4 ? p->sc_l : 4;
   const size_t B = (size_t)max_batch;
@@ -702,6 +711,7 @@ int fotg_grid_read(fotg_ctx *c, int l, int pair, float *p_iter, float *pweight, 
 {
   int st = check_level(c, l, 1); if (st) return st;
   if (pair < 0 || pair >= c->max_batch) return FOTG_ERR_ARG;
+  ON_DEVICE(c->device);
   HIPCHK(hipDeviceSynchronize());
   const size_t nop = c->geom[l].nop, nv = (size_t)c->ps * c->ps * c->noc, pb = (size_t)pair * nop;
   if (p_iter) HIPCHK(hipMemcpy(p_iter, c->p_iter[l] + pb * 2, nop * 2 * 4, hipMemcpyDeviceToHost));
@@ -877,6 +887,7 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
     g.npairs = n;
     g.sync = c->tileSync + (size_t)c->sync_block * (tile_sync_words(c->max_batch) + 32);
     g.timeouts = g.sync + tile_sync_words(c->max_batch);
+    g.stall_flag = c->stall_dev;
 #ifdef FOTG_TILE_STATS
     if (!c->stamps) { if (hipMalloc((void **)&c->stamps, 4096 * 32 * 8) != hipSuccess) return; }
     (void)hipMemsetAsync(c->stamps, 0, 4096 * 32 * 8, s);
@@ -1138,6 +1149,7 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
   const LevelGeom &g = c->geom[l];
   const VrArgs &a = c->vra[l];
   const size_t pl = (size_t)g.st * g.h;
+  ON_DEVICE(c->device);
   HIPCHK(hipDeviceSynchronize());
   if (c->p.depth) {
     static const char *de[] = {"du", "uu", "s", "a11", "b1", "sh", "sv"};        // VrDePlane order
@@ -1431,6 +1443,18 @@ int fotg_calc_batch_u8(fotg_ctx *c, int n, const unsigned char *I0, const unsign
  * independent.  A pipe owns `depth` engine contexts, each with a non-blocking stream of its own; batch k goes to context
  * k % depth and overlaps with the batches before it.  No host synchronisation anywhere: a slot's stream orders the reuse of
  * its context, events order it against the caller's streams. */
+// Host sync points of the product API call this AFTER they have synchronised with the context's work: a time-out of a bounded
+// inter-workgroup wait (a stalled producer: preemption, a debugger, a starved queue) means the flow of that call is wrong.
+static int stall_status(fotg_ctx *c)
+{
+  if (!c->stall_host) return FOTG_OK;
+  volatile int *f = c->stall_host;
+  if (*f == 0) return FOTG_OK;
+  *f = 0;
+  ++c->stalls;
+  return FOTG_ERR_STALL;
+}
+
 struct fotg_pipe {
   int device, depth;
   fotg_ctx *ctx[FOTG_PIPE_MAX_DEPTH];
@@ -1517,8 +1541,8 @@ int fotg_pipe_wait(fotg_pipe *q, long ticket, void *stream, int host_wait)
   ON_DEVICE(q->device);
   // (a slot that has been reused since carries a later batch of the same stream: waiting for that one covers the ticket)
   const int k = (int)(ticket % q->depth);
-  if (host_wait) { HIPCHK(hipEventSynchronize(q->done[k])); }
-  else { HIPCHK(hipStreamWaitEvent((hipStream_t)stream, q->done[k], 0)); }
+  if (host_wait) { HIPCHK(hipEventSynchronize(q->done[k])); return stall_status(q->ctx[k]); }
+  HIPCHK(hipStreamWaitEvent((hipStream_t)stream, q->done[k], 0));
   return FOTG_OK;
 }
 
@@ -1527,7 +1551,9 @@ int fotg_pipe_sync(fotg_pipe *q)
   if (!q) return FOTG_ERR_ARG;
   ON_DEVICE(q->device);
   for (int k = 0; k < q->depth; ++k) HIPCHK(hipStreamSynchronize(q->stream[k]));
-  return FOTG_OK;
+  int st = FOTG_OK;
+  for (int k = 0; k < q->depth; ++k) if (stall_status(q->ctx[k]) != FOTG_OK) st = FOTG_ERR_STALL;
+  return st;
 }
 
 int fotg_pipe_context(fotg_pipe *q, int slot, fotg_ctx **ctx)
@@ -1601,6 +1627,10 @@ long fotg_ctx_counter(fotg_ctx *c, const char *name)
     return bad;
   }
 #endif
+  // non-synchronising: host-side count of stalls reported so far + whether the device has flagged one since (meaningful once
+  // the caller has synchronised with the context's stream); "inject_stall" sets the word like a timed-out wait would (tests)
+  if (!strcmp(name, "stalls")) return c->stalls + (c->stall_host && *(volatile int *)c->stall_host ? 1 : 0);
+  if (!strcmp(name, "inject_stall")) { if (c->stall_host) *(volatile int *)c->stall_host = 1; return 0; }
   if (!strcmp(name, "tile_timeouts")) {
     if (!c->tileSync) return 0;
     DevGuard dg(c->device);
@@ -1635,8 +1665,10 @@ int fotg_calc(fotg_ctx *c, const float *I0, const float *I1, const float *initfl
   const LevelGeom &g = c->geom[c->p.sc_l];
   int st = fotg_calc_batch(c, 1, I0, I1, initflow, c->flow[c->p.sc_l], nullptr);
   if (st) return st;
+  ON_DEVICE(c->device);
+  HIPCHK(hipStreamSynchronize(nullptr));
   HIPCHK(hipMemcpy(outflow_host, c->flow[c->p.sc_l], (size_t)g.w * g.h * c->nch * sizeof(float), hipMemcpyDeviceToHost));
-  return FOTG_OK;
+  return stall_status(c);
 }
 
 int fotg_upsample_crop(fotg_ctx *c, int n, const float *flow, float *out, void *stream)

@@ -39,6 +39,7 @@ struct TileArgs {
   int npairs;
   int *sync;                 // [0] ticket, progress of tile (pair, n, b) at [32 * (1 + (pair * 4 + n) * 64 + b)]; zeroed before every launch
   int *timeouts;             // timed-out waits since the context was created
+  int *stall_flag;           // host-visible word (pinned host memory): set on a time-out, read by the product API's host sync points
 #ifdef FOTG_TILE_STATS
   long long *stats;          // [ticket][16]: see the end of the solver / writer wave (diagnostic builds only)
 #endif
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     st_spins[st_which] += spins + 1;
 #endif
     if (seen < need) {                                            // bounded wait: report and go on (the result is wrong, nothing hangs)
-      if (lane == 0) atomicAdd(g.timeouts, 1);
+      if (lane == 0) { atomicAdd(g.timeouts, 1); __hip_atomic_store(g.stall_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
       seen = 0x3fffffff;
     }
   };

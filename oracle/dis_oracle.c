@@ -22,7 +22,59 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdint.h>
+#include <pthread.h>
+#include <time.h>
 #include "dis_oracle.h"
+
+/* ------------------------------------------------------------------------------------------- */
+/* allocation: every buffer of the port goes through dis_alloc / dis_release.  Outside          */
+/* dis_flow_many() they are malloc / free.  Inside it every worker thread keeps the blocks it    */
+/* releases in a thread-private cache keyed by size: a pair asks for the same sequence of sizes   */
+/* as the pair before it, so from a thread's second pair on nothing reaches the C library (no    */
+/* mmap / munmap / page faults per pair, which is what bound the all-cores leg of round 2).      */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct dis_blk { size_t size; struct dis_blk *next; } dis_blk;      /* 16-byte header */
+typedef struct { size_t size[96]; dis_blk *head[96]; int n; } dis_pool;
+static __thread dis_pool *tl_pool = NULL;
+
+static void *dis_alloc(size_t n, int zero)
+{
+  dis_blk *b = NULL;
+  if (tl_pool) {
+    for (int i = 0; i < tl_pool->n; ++i)
+      if (tl_pool->size[i] == n && tl_pool->head[i]) { b = tl_pool->head[i]; tl_pool->head[i] = b->next; break; }
+  }
+  if (!b) { b = (dis_blk *)malloc(sizeof(dis_blk) + n); if (!b) return NULL; b->size = n; }
+  if (zero) memset(b + 1, 0, n);
+  return b + 1;
+}
+static void dis_release(void *p)
+{
+  if (!p) return;
+  dis_blk *b = (dis_blk *)p - 1;
+  if (tl_pool) {
+    int i = 0;
+    for (; i < tl_pool->n; ++i) if (tl_pool->size[i] == b->size) break;
+    if (i == tl_pool->n && tl_pool->n < 96) { tl_pool->size[i] = b->size; tl_pool->head[i] = NULL; tl_pool->n++; }
+    if (i < tl_pool->n) { b->next = tl_pool->head[i]; tl_pool->head[i] = b; return; }
+  }
+  free(b);
+}
+static void dis_pool_drain(dis_pool *pl)
+{
+  for (int i = 0; i < pl->n; ++i) while (pl->head[i]) { dis_blk *b = pl->head[i]; pl->head[i] = b->next; free(b); }
+  pl->n = 0;
+}
+#define malloc(n) dis_alloc((n), 0)
+#define calloc(a, b) dis_alloc((size_t)(a) * (size_t)(b), 1)
+#define free(p) dis_release(p)
+
+/* order switches of the parity-sensitivity test (tests/test_oracle.py): what the reference leaves to Eigen / OpenCV */
+static int g_sum_order = 0;     /* D1: 0 = 16 partials + xor tree (default), 1 sequential, 2 Eigen-style 4-lane packets, 3 pairwise */
+static int g_mean_order = 0;    /* D4: 0 = ((a+c)+(b+d))/4 (default), 1 ((a+b)+(c+d))/4, 2 (((a+b)+c)+d)/4, 3 a/4+b/4+c/4+d/4 */
+void dis_set_sum_order(int o) { g_sum_order = o; }
+void dis_set_mean_order(int o) { g_mean_order = o; }
 
 /* ------------------------------------------------------------------------------------------- */
 /* parameters / operating points                                                               */
@@ -112,7 +164,14 @@ dis_pyramid *dis_pyramid_build(const float *img, int wp, int hp, int noc, int sc
         const float b = prev[((size_t)(2 * y) * pw + 2 * x + 1) * noc + c];
         const float cc = prev[((size_t)(2 * y + 1) * pw + 2 * x) * noc + c];
         const float d = prev[((size_t)(2 * y + 1) * pw + 2 * x + 1) * noc + c];
-        cur[((size_t)y * w + x) * noc + c] = ((a + cc) + (b + d)) * 0.25f;
+        float m;
+        switch (g_mean_order) {
+          case 1: m = ((a + b) + (cc + d)) * 0.25f; break;
+          case 2: m = (((a + b) + cc) + d) * 0.25f; break;
+          case 3: m = a * 0.25f + b * 0.25f + cc * 0.25f + d * 0.25f; break;
+          default: m = ((a + cc) + (b + d)) * 0.25f; break;             /* definition D4 */
+        }
+        cur[((size_t)y * w + x) * noc + c] = m;
       }
     }
     /* :156-157 Sobel ksize=1 -> [-1 0 1], BORDER_DEFAULT = REFLECT_101; :166-175 pad */
@@ -152,8 +211,35 @@ void dis_pyramid_free(dis_pyramid *p)
 /* reductions (definition D1)                                                                  */
 /* ------------------------------------------------------------------------------------------- */
 
+static float dis_sum_pairwise(const float *v, int n)
+{
+  if (n <= 2) return n == 2 ? v[0] + v[1] : v[0];
+  const int h = n / 2;
+  return dis_sum_pairwise(v, h) + dis_sum_pairwise(v + h, n - h);
+}
+
 float dis_sum(const float *v, int n, int noc)
 {
+  if (g_sum_order == 1) {                       /* sequential, the order of a scalar loop */
+    float acc = v[0];
+    for (int e = 1; e < n; ++e) acc = acc + v[e];
+    return acc;
+  }
+  if (g_sum_order == 2) {
+    /* Eigen-style vectorised redux with 4-float packets (SSE, the reference's -msse4 build): two packet accumulators over
+     * alternating packets, added, then the horizontal sum (a0 + a2) + (a1 + a3) (movehl / shuffle form of predux) */
+    float p0[4], p1[4];
+    for (int k = 0; k < 4; ++k) { p0[k] = v[k]; p1[k] = n >= 8 ? v[4 + k] : 0.0f; }
+    int e = 8;
+    for (; e + 8 <= n; e += 8) for (int k = 0; k < 4; ++k) { p0[k] = p0[k] + v[e + k]; p1[k] = p1[k] + v[e + 4 + k]; }
+    if (e + 4 <= n) { for (int k = 0; k < 4; ++k) p0[k] = p0[k] + v[e + k]; e += 4; }
+    float q[4];
+    for (int k = 0; k < 4; ++k) q[k] = n >= 8 ? p0[k] + p1[k] : p0[k];
+    float r = (q[0] + q[2]) + (q[1] + q[3]);
+    for (; e < n; ++e) r = r + v[e];
+    return r;
+  }
+  if (g_sum_order == 3) return dis_sum_pairwise(v, n);
   /* 16 partial sums: pixel q (element e / noc) goes to partial q % 16, elements in ascending order; then the balanced
    * tree over the 16 partials (xor 8, 4, 2, 1).  Every supported patch has a multiple of 16 pixels. */
   float lane[16]; int used[16];
@@ -995,6 +1081,98 @@ void dis_flow(const float *I0, const float *I1, int wp, int hp, const dis_params
   dis_pyramid *P1 = dis_pyramid_build(I1, wp, hp, p->noc, p->sc_f, p->ps);
   dis_flow_pyr(P0, P1, p, NULL, outflow, sor_mode, NULL);
   dis_pyramid_free(P0); dis_pyramid_free(P1);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* all-cores leg of bench.py's cpu_baseline: frame-parallel over `nthreads` pthreads, one pair per */
+/* thread at a time (the CPU analogue of frame-pair sharding).  Every thread first     */
+/* runs ONE untimed pair (which also fills its block cache, see dis_alloc), all threads meet at a  */
+/* barrier, then they draw pair indices from a shared counter until n_total pairs are done.       */
+/* frames: nsrc unpadded w x h x noc pairs (pair k of the run is source pair k % nsrc).           */
+/* with_pyramid = 1: padding + both pyramids + flow per pair (what a reference driver does per     */
+/* pair); 0: every thread builds the pyramids of its first pair once and times dis_flow_pyr only  */
+/* (what the reference prints as O.Flow Run-Time, kroeger/oflow.cpp:355-360).                     */
+/* out (optional): flows of the first min(n_total, nsrc) pairs.  Returns the timed seconds.       */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *I0, *I1; long pair_stride; int nsrc, w, h, wp, hp; const dis_params *p; int n_total, with_pyramid;
+  float *out; long out_stride; long next; pthread_barrier_t bar; pthread_mutex_t mu; struct timespec t0, t1; int tid_seq;
+} dis_many;
+
+static void dis_many_pair(dis_many *m, int k, int tid, float *pad0, float *pad1, float *flow, const dis_pyramid *P0, const dis_pyramid *P1)
+{
+  const dis_params *p = m->p;
+  /* source pair: k % nsrc with the pyramid in the loop; without it every thread keeps the pyramids of pair tid % nsrc */
+  const int src = m->with_pyramid ? ((k % m->nsrc) + m->nsrc) % m->nsrc : tid % m->nsrc;
+  if (m->with_pyramid) {
+    dis_pad_frame(m->I0 + (size_t)src * m->pair_stride, m->w, m->h, p->noc, p->sc_f, pad0);
+    dis_pad_frame(m->I1 + (size_t)src * m->pair_stride, m->w, m->h, p->noc, p->sc_f, pad1);
+    dis_flow(pad0, pad1, m->wp, m->hp, p, flow, 0);
+  } else {
+    dis_flow_pyr(P0, P1, p, NULL, flow, 0, NULL);
+  }
+  if (m->out && k >= 0 && src < m->n_total) memcpy(m->out + (size_t)src * m->out_stride, flow, sizeof(float) * (size_t)m->out_stride);
+}
+
+static void *dis_many_worker(void *arg)
+{
+  dis_many *m = (dis_many *)arg;
+  dis_pool pool; memset(&pool, 0, sizeof(pool));
+  tl_pool = &pool;
+  const dis_params *p = m->p;
+  pthread_mutex_lock(&m->mu); const int tid = m->tid_seq++; pthread_mutex_unlock(&m->mu);
+  float *pad0 = (float *)malloc(sizeof(float) * (size_t)m->wp * m->hp * p->noc);
+  float *pad1 = (float *)malloc(sizeof(float) * (size_t)m->wp * m->hp * p->noc);
+  float *flow = (float *)malloc(sizeof(float) * (size_t)m->out_stride);
+  dis_pyramid *P0 = NULL, *P1 = NULL;
+  if (!m->with_pyramid) {
+    const int src = tid % m->nsrc;
+    dis_pad_frame(m->I0 + (size_t)src * m->pair_stride, m->w, m->h, p->noc, p->sc_f, pad0);
+    dis_pad_frame(m->I1 + (size_t)src * m->pair_stride, m->w, m->h, p->noc, p->sc_f, pad1);
+    P0 = dis_pyramid_build(pad0, m->wp, m->hp, p->noc, p->sc_f, p->ps);
+    P1 = dis_pyramid_build(pad1, m->wp, m->hp, p->noc, p->sc_f, p->ps);
+  }
+  dis_many_pair(m, -1 - tid, tid, pad0, pad1, flow, P0, P1);              /* warm-up pair (source pair |k| % nsrc), not stored */
+  if (pthread_barrier_wait(&m->bar) == PTHREAD_BARRIER_SERIAL_THREAD) clock_gettime(CLOCK_MONOTONIC, &m->t0);
+  pthread_barrier_wait(&m->bar);
+  for (;;) {
+    const long k = __atomic_fetch_add(&m->next, 1, __ATOMIC_RELAXED);
+    if (k >= m->n_total) break;
+    dis_many_pair(m, (int)k, tid, pad0, pad1, flow, P0, P1);
+  }
+  if (pthread_barrier_wait(&m->bar) == PTHREAD_BARRIER_SERIAL_THREAD) clock_gettime(CLOCK_MONOTONIC, &m->t1);
+  pthread_barrier_wait(&m->bar);
+  if (P0) dis_pyramid_free(P0);
+  if (P1) dis_pyramid_free(P1);
+  free(pad0); free(pad1); free(flow);
+  tl_pool = NULL;
+  dis_pool_drain(&pool);
+  return NULL;
+}
+
+double dis_flow_many(const float *I0, const float *I1, long pair_stride, int nsrc, int w, int h, const dis_params *p,
+                     int n_total, int nthreads, int with_pyramid, float *out)
+{
+  if (nsrc < 1 || nthreads < 1 || n_total < 0) return -1.0;
+  dis_many m; memset(&m, 0, sizeof(m));
+  int padw, padh;
+  dis_padded_size(w, h, p->sc_f, &m.wp, &m.hp, &padw, &padh);
+  m.I0 = I0; m.I1 = I1; m.pair_stride = pair_stride; m.nsrc = nsrc; m.w = w; m.h = h; m.p = p;
+  m.n_total = n_total; m.with_pyramid = with_pyramid; m.out = out;
+  m.out_stride = (long)(m.wp >> p->sc_l) * (m.hp >> p->sc_l) * (p->depth ? 1 : 2);
+  pthread_barrier_init(&m.bar, NULL, (unsigned)nthreads);
+  pthread_mutex_init(&m.mu, NULL);
+  pthread_t *th = (pthread_t *)(malloc)(sizeof(pthread_t) * (size_t)nthreads);
+  int started = 0;
+  for (; started < nthreads; ++started) if (pthread_create(&th[started], NULL, dis_many_worker, &m) != 0) break;
+  if (started < nthreads) {                                            /* cannot meet the barrier with fewer threads: give up loudly */
+    fprintf(stderr, "dis_flow_many: only %d of %d threads could be created\n", started, nthreads);
+    abort();
+  }
+  for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
+  (free)(th);
+  pthread_barrier_destroy(&m.bar); pthread_mutex_destroy(&m.mu);
+  return (double)(m.t1.tv_sec - m.t0.tv_sec) + 1e-9 * (double)(m.t1.tv_nsec - m.t0.tv_nsec);
 }
 
 /* kroeger/run_dense.cpp:407-414.  cv::resize(INTER_LINEAR) upscaling: source coordinate

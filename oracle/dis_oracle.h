@@ -148,6 +148,15 @@ void dis_flow_pyr(const dis_pyramid *P0, const dis_pyramid *P1, const dis_params
 /* convenience: padded frames in -> finest-scale flow out (pyramid + flow) */
 void dis_flow(const float *I0, const float *I1, int wp, int hp, const dis_params *p,
               float *outflow, int sor_mode);
+/* bench.py's cpu_baseline, all-cores leg: n_total pairs (pair k = source pair k % nsrc of the unpadded w x h x noc frames)
+ * frame-parallel on nthreads pthreads with thread-private block caches (no allocation per pair after a thread's first);
+ * with_pyramid 1: padding + pyramids + flow per pair, 0: flow on pyramids built once per thread.  out (optional): the flows
+ * of pairs 0 .. min(n_total, nsrc)-1.  Returns the seconds the n_total pairs took (every thread runs one untimed pair first). */
+double dis_flow_many(const float *I0, const float *I1, long pair_stride, int nsrc, int w, int h, const dis_params *p,
+                     int n_total, int nthreads, int with_pyramid, float *out);
+/* parity-sensitivity switches (tests only): order of the per-patch reductions (definition D1) and of the 2x2 mean (D4) */
+void dis_set_sum_order(int order);
+void dis_set_mean_order(int order);
 /* kroeger/run_dense.cpp:407-414: *2^sc_l, bilinear x2^sc_l (cv::resize INTER_LINEAR), crop */
 void dis_upsample_crop(const float *flow, int wl, int hl, int sc_l, int padw, int padh,
                        int w_org, int h_org, float *out);

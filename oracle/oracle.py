@@ -259,6 +259,34 @@ def flow(I0p, I1p, params, sor_mode=0):
     return out
 
 
+def flow_many(I0, I1, params, n_total, nthreads, with_pyramid=True, want_out=False):
+    """bench.py's cpu_baseline, all-cores leg (dis_flow_many): I0, I1 = (nsrc, h, w[, noc]) unpadded float32 frames; n_total pairs
+    (pair k = source pair k % nsrc) frame-parallel on nthreads pthreads.  Returns (seconds, flows of the first
+    min(n_total, nsrc) pairs or None)."""
+    I0, I1 = f32(I0), f32(I1)
+    nsrc, h, w = I0.shape[:3]
+    wp, hp, _, _ = padded_size(w, h, params.sc_f)
+    out = None
+    if want_out:
+        out = np.zeros((min(n_total, nsrc), hp >> params.sc_l, wp >> params.sc_l, 1 if params.depth else 2), np.float32)
+    L = lib()
+    L.dis_flow_many.restype = C.c_double
+    L.dis_flow_many.argtypes = [f32p, f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(DisParams), C.c_int, C.c_int, C.c_int, f32p]
+    sec = L.dis_flow_many(P(I0), P(I1), int(I0[0].size), nsrc, w, h, C.byref(params), int(n_total), int(nthreads),
+                          1 if with_pyramid else 0, P(out) if out is not None else None)
+    return sec, out
+
+
+def set_sum_order(order):
+    """parity-sensitivity switch (tests): 0 = definition D1, 1 sequential, 2 Eigen-style 4-lane packets, 3 pairwise"""
+    lib().dis_set_sum_order(int(order))
+
+
+def set_mean_order(order):
+    """parity-sensitivity switch (tests): order of the 2x2 mean's additions, 0 = definition D4"""
+    lib().dis_set_mean_order(int(order))
+
+
 def upsample_crop(fl, sc_l, padw, padh, w_org, h_org):
     fl = f32(fl)
     hl, wl, nch = fl.shape

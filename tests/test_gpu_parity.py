@@ -788,6 +788,56 @@ def test_batch_1080p_parity_and_independence():
     assert np.median(epe(full, gt)) < 0.5
 
 
+def test_batch64_default_path_and_depth4_pipeline():
+    """BASELINE configs[2] at its real size: 64 DISTINCT 1080p pairs, op-pt 2 + refinement, the default path.  One
+    calc_batch of 64; every pair == its own single-pair call, 8 of them == the oracle; the same 64 pairs through
+    FlowPipeline(depth=4) as 8 submits of 8 pairs and as 4 submits of the whole batch (the configuration bench.py times):
+    every submit == calc_batch."""
+    F, OFClass, _, O = _mods()
+    from flowonthego_amd.pipeline import FlowPipeline
+    n = 64
+    base = [synth_pair(1080, 1920, seed=4321 + k) for k in range(8)]
+
+    def variant(f, t):                                                    # 8 bases x 8 rigid transforms = 64 distinct pairs
+        if t & 1: f = f[:, ::-1]
+        if t & 2: f = f[::-1]
+        if t & 4: f = np.roll(f, (37, 101), (0, 1))
+        return np.ascontiguousarray(f)
+    pairs = [(variant(base[k % 8][0], k // 8), variant(base[k % 8][1], k // 8)) for k in range(n)]
+    assert len({p[0].tobytes()[:4096] + p[0].tobytes()[-4096:] for p in pairs}) == n
+    I0 = dev(np.stack([p[0] for p in pairs])); I1 = dev(np.stack([p[1] for p in pairs]))
+    op = F.operating_point(2, 1920, 1)
+    ip = F.img_params(width=1920, height=1080, padding=8)
+    ofc = OFClass(op, ip, max_batch=n)
+    out = ofc.calc_batch(I0, I1)
+    torch.cuda.synchronize()
+    assert out.shape == (n, 68, 120, 2)
+    single = OFClass(op, ip, max_batch=1)
+    for k in range(n):
+        assert torch.equal(single.calc(I0[k], I1[k]), out[k]), k
+    p = oracle_params(O, op)
+    outh = out.cpu().numpy()
+    for k in range(0, n, 8):                                              # one pair of every transform
+        kk = k + (k // 8) % 8
+        ref = O.flow(O.pad_frame(pairs[kk][0], p.sc_f), O.pad_frame(pairs[kk][1], p.sc_f), p, 0)
+        assert np.array_equal(outh[kk], ref), kk
+    pipe = FlowPipeline(op, ip, max_batch=8, depth=4)
+    tickets = [pipe.submit(I0[8 * j:8 * j + 8], I1[8 * j:8 * j + 8]) for j in range(8)]
+    pipe.synchronize()
+    for j, (_, o) in enumerate(tickets):
+        assert torch.equal(o, out[8 * j:8 * j + 8]), j
+    pipe.close()
+    pipe = FlowPipeline(op, ip, max_batch=n, depth=4)
+    perm = torch.arange(n - 1, -1, -1, device=I0.device)
+    I0r, I1r = I0[perm].contiguous(), I1[perm].contiguous()               # a second, different batch in flight beside the first
+    torch.cuda.synchronize()
+    tickets = [pipe.submit(a, b) for a, b in ((I0, I1), (I0r, I1r), (I0, I1), (I0r, I1r))]
+    pipe.synchronize()
+    for j, (_, o) in enumerate(tickets):
+        assert torch.equal(o, out if j % 2 == 0 else out[perm]), j
+    pipe.close(); ofc.close(); single.close()
+
+
 def test_single_1080p_pair_no_refinement():
     """BASELINE configs[1] exactly: ONE 1920x1080 pair, patch_size 8, stride 4 (overlap 0.4), 3 pyramid levels (6-5-4), no
     variational refinement -- finest-scale flow, full-resolution flow and the patch state of every scale against the oracle"""
@@ -866,6 +916,43 @@ def test_errors():
     bad.patch_size = 10
     with pytest.raises(F.FotgError):
         OFClass(bad, F.img_params(width=512, height=256, padding=10))
+
+
+def test_stalled_wait_is_reported_by_the_product_api():
+    """a bounded inter-workgroup wait that times out raises a word in pinned host memory; the entry points that synchronise
+    with the host return FOTG_ERR_STALL once (the flow of that call is not valid), then the context is usable again"""
+    import ctypes as C
+    F, OFClass, _, O = _mods()
+    from flowonthego_amd.pipeline import FlowPipeline
+    L = F.lib()
+    w, h = 512, 256
+    op = F.operating_point(2, w, 1)
+    ip = F.img_params(width=w, height=h, padding=8)
+    ofc = OFClass(op, ip, max_batch=1)
+    a, b = synth_pair(h, w, seed=5)
+    A, B = dev(a), dev(b)
+    ow, oh = ofc.out_size()
+    host = np.zeros((oh, ow, 2), np.float32)
+    args = (ofc._h, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), None, host.ctypes.data_as(C.c_void_p))
+    assert L.fotg_calc(*args) == 0 and L.fotg_ctx_counter(ofc._h, b"stalls") == 0
+    good = host.copy()
+    L.fotg_ctx_counter(ofc._h, b"inject_stall")
+    assert L.fotg_ctx_counter(ofc._h, b"stalls") == 1                     # (non-synchronising query)
+    assert L.fotg_calc(*args) == 5                                        # FOTG_ERR_STALL
+    assert b"timed out" in L.fotg_strerror(5)
+    assert L.fotg_calc(*args) == 0 and np.array_equal(host, good)
+    assert L.fotg_ctx_counter(ofc._h, b"stalls") == 1
+    pipe = FlowPipeline(op, ip, max_batch=1, depth=2)
+    t, _ = pipe.submit(A[None], B[None])
+    L.fotg_ctx_counter(pipe.context(0), b"inject_stall")
+    with pytest.raises(F.FotgError):
+        pipe.wait(t, host=True)
+    pipe.wait(t, host=True)                                               # reported once
+    L.fotg_ctx_counter(pipe.context(1), b"inject_stall")
+    with pytest.raises(F.FotgError):
+        pipe.synchronize()
+    pipe.synchronize()
+    pipe.close(); ofc.close()
 
 
 def test_cpp_shim_run_dense_example(tmp_path):
