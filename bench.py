@@ -378,7 +378,10 @@ def main():
             res["stage_ms_note"] = "each stage alone on one stream: their sum is the time of ONE batch from start to end (one_batch_at_a_time); with batches in flight the stages of different batches overlap"
             res["roofline"] = roofline(ofc, I0, I1, lib, stream_ptr, a.batch)
             if op.use_var_ref and a.sor_mode == 0:
-                res["roofline_dominant"] = roofline_dominant(ofc, lib, stream_ptr, a.batch, st)
+                try:
+                    res["roofline_dominant"] = roofline_dominant(ofc, lib, stream_ptr, a.batch, st)
+                except Exception as e:          # (levels of the resident pipeline have no stand-alone sor_coupled launch)
+                    res["roofline_dominant"] = {"unavailable": str(e)}
             # the whole path against the same roof: pairs/s x 16 654 080 B / 8 TB/s
             res["whole_path_hbm_frac"] = value / world * (2 * W * H * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS
             res["time_dominant_stage"] = max(st, key=st.get)

@@ -12,7 +12,7 @@
 #include "lk.hip.h"
 #include "densify.hip.h"
 #include "varref.hip.h"
-#include "varref_stage.hip.h"
+#include "varref_resident.hip.h"
 #include "varref_tiles.hip.h"
 #include "varref_depth.hip.h"
 #include "upsample.hip.h"
@@ -63,8 +63,7 @@ struct FotgTune {
   int vr_wide;      // FOTG_VR_WIDE: 0 = single-wave kernel instead of the wide one
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
   int vr_tiles;     // FOTG_VR_TILES: 0 = tall levels on one workgroup per pair (wide / single-wave kernels) instead of the tile pipeline
-  int vr_stage;     // FOTG_VR_STAGE: 1 = stage-pipelined refinement of the levels it fits (varref_stage.hip.h); default 0
-  int vr_stage_mins;// FOTG_VR_STAGE_MINS: fewest anti-diagonals of a level that takes the stage pipeline
+  int vr_resident;  // FOTG_VR_RESIDENT: 0 = launch-per-iteration refinement instead of the resident pipeline (varref_resident.hip.h)
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
@@ -109,13 +108,11 @@ struct fotg_ctx {
   float4 *vrC[FOTG_MAXLEV];          // skewed system per level (cells outside the image stay zero forever)
   float2 *vrD[FOTG_MAXLEV];          // skewed (du,dv) per level
   VrArgs vra[FOTG_MAXLEV];
-  // stage-pipelined refinement (varref_stage.hip.h): skewed constant planes, hand-over buffers, ticket / progress words
-  int stage_geo[FOTG_MAXLEV];        // 0: level not eligible; 1, 2, 3: ring geometry (RD, RCW) = (48, 38), (80, 70), (112, 98)
-  int stage_used[FOTG_MAXLEV];       // the last fotg_varref of the level took the pipeline (fotg_varref_plane de-skews)
+  // resident refinement pipeline (varref_resident.hip.h): skewed constant planes, ticket / progress words
+  int res_geo[FOTG_MAXLEV];          // 0: level not eligible; 1, 2: ring geometry (RD, RCW) = (72, 70), (100, 98)
+  int skew_used[FOTG_MAXLEV];        // the last fotg_varref of the level took the pipeline (fotg_varref_plane de-skews)
   VrArgs vraq[FOTG_MAXLEV];          // the level's arguments with the planes in the skewed workspace
   float *vrQ;
-  float2 *vrDS;
-  long ds_pair_stride, ds_stage_stride[FOTG_MAXLEV];
   // verbosity (the reference's op.verbosity, src/oflow.cpp:246-365 / kroeger/oflow.cpp:298-360): > 0 makes the flow calls
   // synchronous and prints the reference's timing lines from HIP-event times of the stages
   int verbosity;
@@ -131,25 +128,32 @@ struct fotg_ctx {
   // fotg_calc, fotg_pipe_wait(host_wait) and fotg_pipe_sync read it after their synchronisation and return FOTG_ERR_STALL
   int *stall_host, *stall_dev;
   long stalls;                       // host-side count of the times the word was found set
-  int sync_block;                    // which block of vrSync this (view of the) context uses
   void *vrZero;
-  unsigned long long *stamps;        // -DFOTG_STAGE_STAMPS builds only
+  unsigned long long *stamps;        // -DFOTG_TILE_STATS builds only
   GridState gs[FOTG_MAXLEV];
-  // sub-batch pipelining (fotg_calc_batch): the solver's dependent chain has a latency that does not depend on the
-  // batch size while every other stage is throughput bound, so a batch is cut into sub-batches on internal streams
-  // and one sub-batch's solver latency hides behind the others' throughput work
-  int nsub;
-  hipStream_t sub_stream[8];
-  hipEvent_t ev_fork, ev_join[8];
-  // The sub-batched launch sequence (a few hundred launches on several streams) is host-bound when issued eagerly,
-  // so it is captured once into a hipGraph and replayed while the call's arguments stay the same.
-  int use_graph;
-  hipStream_t cap_stream;
-  hipGraphExec_t gexec;
-  int g_n, g_seen;
-  const float *g_I0, *g_I1, *g_init;
-  float *g_out;
 };
+
+// resident pipeline: float4 / float2 units between the arrays of consecutive inner iterations of a pair
+// (every array has exactly E rows -- the diagonals of a solver round -- so the arrays of a pair are one contiguous run of rows)
+static long res_c_it_stride(const VrArgs &a, int nsweeps) { return (long)res_geom(a.w, a.h, nsweeps).E * a.RP * 2; }
+static long res_d_it_stride(const VrArgs &a, int nsweeps) { return (long)res_geom(a.w, a.h, nsweeps).E * a.RPD; }
+// ring geometry of a level that takes the resident pipeline (0: not eligible): lexicographic order, 1..3 sweeps (one solver wave
+// each), 65..96 rows (two rows per lane of one solver wave, two direct loads per system plane and diagonal), enough diagonals for
+// the unrolled loop; 1, 2: (RD, RCW) = (72, 70), (100, 98)
+static int res_level_geo(const fotg_ctx *c, int l)
+{
+  const fotg_params *p = &c->p;
+  const VrArgs &a = c->vra[l];
+  if (c->noc != 1) return 0;                   // (gray only: the RGB data term does not fit the 128 registers of a 1024-thread workgroup)
+  if (p->depth || p->sor_mode != FOTG_SOR_LEXICOGRAPHIC || !c->tune.vr_resident || c->tune.vr_path != 0 || p->tv_solverit < 1 || p->tv_solverit > 3) return 0;
+  const int inner = p->tv_innerit * (l + 1);
+  if (inner < 1 || a.K != 2 || a.RP < 64 || (a.RPD & 1) || a.h + 2 > a.RPD || a.S < 64) return 0;
+  const ResGeom q = res_geom(a.w, a.h, p->tv_solverit);
+  if (q.nww < 1) return 0;
+  if (a.RP + 1 <= 70 && a.h + 2 <= 72 && res_lds_bytes<72, 70>(q) <= 160 * 1024) return 1;
+  if (a.RP + 1 <= 98 && a.h + 2 <= 100 && res_lds_bytes<100, 98>(q) <= 160 * 1024) return 2;
+  return 0;
+}
 
 static void fill_geom(const fotg_params &p, int Wp, int Hp, int l, LevelGeom &g)
 {
@@ -238,15 +242,8 @@ void fotg_destroy(fotg_ctx *c)
     (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]); (void)hipFree(c->vrX[l]);
   }
   if (c->stall_host) (void)hipHostFree(c->stall_host);
-  (void)hipFree(c->vr); (void)hipFree(c->vrQ); (void)hipFree(c->vrDS); (void)hipFree(c->vrSync); (void)hipFree(c->vrZero); (void)hipFree(c->tileSync);
-  for (int i = 0; i < 8; ++i) {
-    if (c->sub_stream[i]) (void)hipStreamDestroy(c->sub_stream[i]);
-    if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
-  }
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  (void)hipFree(c->vr); (void)hipFree(c->vrQ); (void)hipFree(c->vrSync); (void)hipFree(c->vrZero); (void)hipFree(c->tileSync);
   for (auto &e : c->tev) if (e) (void)hipEventDestroy(e);
-  if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
-  if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   delete c;
 }
 
@@ -271,8 +268,9 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_wide = env_int("FOTG_VR_WIDE", 1);
   c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
   c->tune.vr_tiles = env_int("FOTG_VR_TILES", 1);
-  c->tune.vr_stage = env_int("FOTG_VR_STAGE", 0);      // opt-in: measured slower than the per-iteration launches at batch 64
-  c->tune.vr_stage_mins = env_int("FOTG_VR_STAGE_MINS", 80);
+  // opt-in: measured at batch 64 it is no faster than the per-iteration launches (0.255 vs 0.249 ms at level 4) and, with several
+  // batches in flight, its polling workgroups hold whole CUs (120 k vs 168 k pairs/s) -- docs/EXPERIMENTS.md
+  c->tune.vr_resident = env_int("FOTG_VR_RESIDENT", 0);
   if (hipHostMalloc((void **)&c->stall_host, 64, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void **)&c->stall_dev, c->stall_host, 0) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; }
   memset(c->stall_host, 0, 64);
@@ -340,12 +338,21 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       a.S = gl.w + gl.h - 1; a.SC = a.S + 1;        // one spare (zero) row: idle lanes read past the last row
       a.c_pair_stride = (long)a.SC * a.RP * 2;
       a.d_pair_stride = (long)(a.S + 1) * a.RPD;
-      if (p->depth) continue;                        // depth mode solves on plain planes of the workspace (varref_depth.hip.h)
+      if (p->depth) continue;
+      // resident pipeline (varref_resident.hip.h): one system array and one (du,dv) array PER INNER ITERATION (write once);
+      // the launch-per-iteration kernels of such a level use the first one
+      if (const int geo = res_level_geo(c, l)) {
+        const int inner = p->tv_innerit * (l + 1);
+        a.RPD = geo == 1 ? 72 : 100;                   // = the kernel's ring geometry RD: one pitch for planes, arrays, rings and slabs
+        a.c_pair_stride = (long)inner * res_c_it_stride(a, p->tv_solverit);
+        a.d_pair_stride = (long)(inner + 1) * res_d_it_stride(a, p->tv_solverit) + 2 * a.RPD;      // array 0: zeros; + the writer's spare rows
+      }                        // depth mode solves on plain planes of the workspace (varref_depth.hip.h)
       // + slack: idle lanes of the solver read K cells past the row they are parked on, i.e. past the last pair's
       // last (spare) row
       const size_t cbytes = B * a.c_pair_stride * sizeof(float4) + 64 * 16 * 2 * sizeof(float4);
       ALLOC(c->vrC[l], cbytes);
       ALLOC(c->vrD[l], B * a.d_pair_stride * sizeof(float2) + 4096);
+      if (res_level_geo(c, l) && hipMemset(c->vrD[l], 0, B * a.d_pair_stride * sizeof(float2) + 4096) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       if (hipMemset(c->vrC[l], 0, cbytes) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       a.C = c->vrC[l]; a.D = c->vrD[l];
       // tall levels (beyond the LDS solvers' 96 rows): per-sweep arrays of the tile pipeline, zero outside the image for good
@@ -361,46 +368,30 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
         ALLOC(c->vrX[l], xb);
         if (hipMemset(c->vrX[l], 0, xb) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
         if (!c->tileSync) {
-          ALLOC(c->tileSync, 8 * (tile_sync_words((int)B) + 32) * sizeof(int));
-          if (hipMemset(c->tileSync, 0, 8 * (tile_sync_words((int)B) + 32) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+          ALLOC(c->tileSync, (tile_sync_words((int)B) + 32) * sizeof(int));
+          if (hipMemset(c->tileSync, 0, (tile_sync_words((int)B) + 32) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
         }
       }
     }
-    // Levels that take the stage pipeline: lexicographic order, 1..3 sweeps (one solver wave each), 2..16 inner iterations
-    // (one workgroup each), enough anti-diagonals to amortise the pipeline fill, a ring geometry that holds the rows.
-    if (!p->depth && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->tune.vr_stage && c->tune.vr_path == 0 && p->tv_solverit >= 1 && p->tv_solverit <= 3) {
-      long qmax = 0, ds_total = 0;
+    // Levels that take the resident pipeline (res_level_geo): skewed constant planes, ticket / progress words
+    {
+      long qmax = 0;
       for (int l = p->sc_l; l <= p->sc_f; ++l) {
         const VrArgs &a = c->vra[l];
-        const int inner = p->tv_innerit * (l + 1);
-        if (inner < 2 || inner > FOTG_STAGE_MAXINNER || a.S < c->tune.vr_stage_mins || a.K > 2) continue;
-        const StageGeom q = stage_geom(a.w, a.h, p->tv_solverit);
-        if (q.NBW > FOTG_STAGE_NDW) continue;
-        int geo = 0, rd = 0;
-        int lds = 0;
-        if (a.h + 2 <= 48 && q.HR <= 38) { geo = 1; rd = 48; lds = stage_lds_bytes<48, 38>(q); }
-        else if (a.h + 2 <= 80 && q.HR <= 70) { geo = 2; rd = 80; lds = stage_lds_bytes<80, 70>(q); }
-        else if (a.h + 2 <= 112 && q.HR <= 98) { geo = 3; rd = 112; lds = stage_lds_bytes<112, 98>(q); }
-        if (!geo || lds > 160 * 1024) continue;
-        c->stage_geo[l] = geo;
+        c->res_geo[l] = res_level_geo(c, l);
+        if (!c->res_geo[l]) continue;
         const long pl = (long)(a.S + 1) * a.RPD;
-        const long need = pl * (P_NSINGLE + C_NCOLOR * c->noc + FOTG_VR_NEXTRA) + 1024;      // (+ slack: the row loads of the stage loader run up to 2 rows past a plane)
+        const long need = pl * (P_NSINGLE + C_NCOLOR * c->noc + FOTG_VR_NEXTRA) + 1024;
         if (need > qmax) qmax = need;
-        c->ds_stage_stride[l] = (long)(a.S + FOTG_STAGE_M + 1) * rd;
-        const long t = c->ds_stage_stride[l] * (inner - 1);
-        if (t > ds_total) ds_total = t;
       }
       if (qmax) {
         ALLOC(c->vrQ, B * qmax * sizeof(float));
-        ALLOC(c->vrDS, B * ds_total * sizeof(float2) + 4096);
         ALLOC(c->vrZero, 4096);
         if (hipMemset(c->vrZero, 0, 4096) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
-        // one block of ticket / progress words per sub-batch stream (their stage launches run concurrently)
-        ALLOC(c->vrSync, 8 * stage_sync_words((int)B) * sizeof(int));
-        if (hipMemset(c->vrSync, 0, 8 * stage_sync_words((int)B) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
-        c->ds_pair_stride = ds_total;
+        ALLOC(c->vrSync, res_sync_words((int)B) * sizeof(int));
+        if (hipMemset(c->vrSync, 0, res_sync_words((int)B) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
         for (int l = p->sc_l; l <= p->sc_f; ++l) {
-          if (!c->stage_geo[l]) continue;
+          if (!c->res_geo[l]) continue;
           VrArgs &aq = c->vraq[l];
           aq = c->vra[l];
           aq.skew = 1; aq.base = c->vrQ; aq.pair_stride = qmax; aq.pl = (long)(aq.S + 1) * aq.RPD;
@@ -409,21 +400,6 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
     }
   }
 #undef ALLOC
-  {
-    c->nsub = env_int("FOTG_SUBBATCH", 1);     // measured on MI355X, 64 x 1080p: no gain (the host launch path is the wall), so off by default
-    if (c->nsub < 1) c->nsub = 1;
-    if (c->nsub > 8) c->nsub = 8;
-    c->use_graph = env_int("FOTG_GRAPH", 1);
-    if (c->nsub > 1) {
-      // (streams are only created where they are used: HIP deals its streams to a handful of hardware queues, and two busy
-      // streams on one queue run one after the other -- fotg_pipe_create relies on getting a queue per slot)
-      if (hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
-      if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
-      for (int i = 0; i < c->nsub; ++i)
-        if (hipStreamCreateWithFlags(&c->sub_stream[i], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
-    }
-  }
   *out = c;
   return FOTG_OK;
 }
@@ -771,7 +747,7 @@ static bool launch_sor_pipe(int n, float omega, hipStream_t s, const VrArgs &b)
 }
 
 static long g_wide_launches = 0;        // fotg_debug_counter("sor_wide")
-static long g_stage_launches = 0;       // fotg_debug_counter("vr_stage")
+static long g_res_launches = 0;         // fotg_debug_counter("vr_resident")
 static long g_tile_launches = 0;        // fotg_debug_counter("sor_tiles")
 #ifndef FOTG_TILE_P
 #define FOTG_TILE_P 8                    // prefetch depth (diagonals) of the tile solver
@@ -885,7 +861,7 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
     g.RT = c->x_rt[l];
     g.NB = (a.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS;
     g.npairs = n;
-    g.sync = c->tileSync + (size_t)c->sync_block * (tile_sync_words(c->max_batch) + 32);
+    g.sync = c->tileSync;
     g.timeouts = g.sync + tile_sync_words(c->max_batch);
     g.stall_flag = c->stall_dev;
 #ifdef FOTG_TILE_STATS
@@ -948,42 +924,40 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   const float half_gamma_over3 = c->p.tv_gamma * 0.5f / 3.0f;
   const float half_delta_over3 = c->p.tv_delta * 0.5f / 3.0f;
   const int inner = c->p.tv_innerit * (l + 1);
-  if (c->stage_geo[l] && c->tune.vr_path == 0) {
-    // stage pipeline: set-up launch into the skewed planes (it also zeroes the ticket / progress words), then ONE launch of
-    // inner x n workgroups, workgroup = one inner iteration of one pair
-    c->stage_used[l] = 1;
+  if constexpr (NOC == 1)
+  if (c->res_geo[l] && c->tune.vr_path == 0) {
+    // resident pipeline: set-up launch into the skewed planes (it also zeroes the ticket / progress words), then ONE launch of
+    // (1 + NDW) n workgroups: per pair a solver workgroup that stays resident over the inner iterations and NDW data workgroups
+    c->skew_used[l] = 1;
     VrArgs aq = c->vraq[l];
     aq.taps = c->taps ? 1 : 0;
     aq.nsweeps = c->p.tv_solverit;
-    int *sync = c->vrSync + (size_t)c->sync_block * stage_sync_words(c->max_batch);
-    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(aq, I0, I1, img_stride, g.tw, c->ps, flow, fs, 2, sync, stage_sync_words(n));
+    int *sync = c->vrSync;
+    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(aq, I0, I1, img_stride, g.tw, c->ps, flow, fs, 2, sync, res_sync_words(n));
     LAUNCHCHK();
-    StageArgs sa;
-    sa.inner = inner; sa.npairs = n; sa.qa = quarter_alpha; sa.hd = half_delta_over3; sa.hg = half_gamma_over3; sa.omega = c->p.tv_sor;
-    sa.flow = flow; sa.flow_stride = fs; sa.DS = c->vrDS; sa.ds_pair_stride = c->ds_pair_stride; sa.ds_stage_stride = c->ds_stage_stride[l];
-    sa.sync = sync;
-    sa.zero = c->vrZero;
-    sa.stamps = nullptr;
-#ifdef FOTG_STAGE_STAMPS
-    if (!c->stamps) { if (hipMalloc((void **)&c->stamps, (size_t)FOTG_STAGE_MAXINNER * c->max_batch * 16 * 8 * 8) != hipSuccess) return FOTG_ERR_HIP; }
-    (void)hipMemsetAsync(c->stamps, 0, (size_t)FOTG_STAGE_MAXINNER * c->max_batch * 16 * 8 * 8, s);
-    sa.stamps = c->stamps;
+    const ResGeom q = res_geom(g.w, g.h, c->p.tv_solverit);
+    ResArgs ra;
+    ra.inner = inner; ra.npairs = n; ra.nww = q.nww; ra.c_it_stride = res_c_it_stride(aq, c->p.tv_solverit); ra.d_it_stride = res_d_it_stride(aq, c->p.tv_solverit); ra.qa = quarter_alpha; ra.hd = half_delta_over3; ra.hg = half_gamma_over3; ra.omega = c->p.tv_sor;
+    ra.flow = flow; ra.flow_stride = fs; ra.zero = c->vrZero; ra.sync = sync; ra.stall_flag = c->stall_dev;
+    ra.stats = nullptr;
+#ifdef FOTG_RES_STATS
+    if (!c->stamps) { if (hipMalloc((void **)&c->stamps, 4 * 16 * 4 * 8) != hipSuccess) return FOTG_ERR_HIP; }
+    (void)hipMemsetAsync(c->stamps, 0, 4 * 16 * 4 * 8, s);
+    ra.stats = (long long *)c->stamps;
 #endif
-    const StageGeom q = stage_geom(g.w, g.h, c->p.tv_solverit);
-    static int lds_set[3][32];
-#define STAGE(GEO, RD_, RCW_) \
-    { const int lds = stage_lds_bytes<RD_, RCW_>(q); \
-      if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_stage_kernel<NOC, RD_, RCW_>), lds, lds_set[GEO - 1])) return FOTG_ERR_HIP; \
-      vr_stage_kernel<NOC, RD_, RCW_><<<inner * n, 1024, lds, s>>>(aq, sa); }
-    if (c->stage_geo[l] == 1) STAGE(1, 48, 38)
-    else if (c->stage_geo[l] == 2) STAGE(2, 80, 70)
-    else STAGE(3, 112, 98)
-#undef STAGE
-    ++g_stage_launches;
+    static int lds_set[2][32];
+#define RESIDENT(GEO, RD_, RCW_) \
+    { const int lds = res_lds_bytes<RD_, RCW_>(q); \
+      if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_resident_kernel<NOC, RD_, RCW_>), lds, lds_set[GEO - 1])) return FOTG_ERR_HIP; \
+      vr_resident_kernel<NOC, RD_, RCW_><<<(1 + FOTG_RES_NDW) * n, 1024, lds, s>>>(aq, ra); }
+    if (c->res_geo[l] == 1) RESIDENT(1, 72, 70)
+    else RESIDENT(2, 100, 98)
+#undef RESIDENT
+    ++g_res_launches;
     LAUNCHCHK();
     return FOTG_OK;
   }
-  c->stage_used[l] = 0;
+  c->skew_used[l] = 0;
   // small levels: the whole level (set-up stages, fixed-point loop, final w + d) in one launch, one workgroup per pair
   if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && c->tune.vr_path == 0 &&
       dispatch_inner_fused<NOC>(c, a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s,
@@ -1118,7 +1092,7 @@ extern "C" {
 int fotg_bench_sor_call(fotg_ctx *c, int l, int n, void *stream)
 {
   int st = check_level(c, l, n); if (st) return st;
-  if (!c->vr || c->p.depth || !c->vrC[l] || c->p.tv_solverit < 1) return FOTG_ERR_UNSUPPORTED;
+  if (!c->vr || c->p.depth || !c->vrC[l] || c->p.tv_solverit < 1 || c->res_geo[l]) return FOTG_ERR_UNSUPPORTED;   // (resident levels: (du,dv) array 0 must stay zero)
   ON_DEVICE(c->device);
   dispatch_sor(c, c->vra[l], n, c->p.tv_solverit, c->p.tv_sor, (hipStream_t)stream);
   LAUNCHCHK();
@@ -1159,8 +1133,8 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
         return FOTG_OK;
       }
   }
-  if (c->stage_used[l]) {
-    // the level took the stage pipeline: its planes live in the skewed workspace (pixel (i,j) at [(i+j) * RPD + j]); de-skew on the host
+  if (c->skew_used[l]) {
+    // the level took the resident pipeline: its planes live in the skewed workspace (pixel (i,j) at [(i+j) * RPD + j]); de-skew on the host
     const VrArgs &aq = c->vraq[l];
     int first = -1, cnt = 1;
     for (int i = 0; i < P_NSINGLE; ++i) if (!strcmp(name, singles[i])) first = i;
@@ -1192,9 +1166,12 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
   // planes that live in the skewed solver arrays: copy and de-skew on the host
   for (int k = 0; k < 8; ++k)
     if (!strcmp(name, sys[k])) {
-      float *tmp = (float *)malloc((size_t)a.c_pair_stride * sizeof(float4));
+      // (a level of the resident pipeline has one array per inner iteration: the last system is in the last one)
+      const size_t c_len = c->res_geo[l] ? (size_t)res_c_it_stride(a, c->p.tv_solverit) : (size_t)a.c_pair_stride;
+      const size_t c_off = c->skew_used[l] ? (size_t)(c->p.tv_innerit * (l + 1) - 1) * c_len : 0;
+      float *tmp = (float *)malloc(c_len * sizeof(float4));
       if (!tmp) return FOTG_ERR_ARG;
-      hipError_t e = hipMemcpy(tmp, a.C + (size_t)pair * a.c_pair_stride, (size_t)a.c_pair_stride * sizeof(float4), hipMemcpyDeviceToHost);
+      hipError_t e = hipMemcpy(tmp, a.C + (size_t)pair * a.c_pair_stride + c_off, c_len * sizeof(float4), hipMemcpyDeviceToHost);
       if (e != hipSuccess) { free(tmp); g_last_hip = (int)e; return FOTG_ERR_HIP; }
       memset(host_out, 0, pl * 4);
       for (int j = 0; j < g.h; ++j) for (int i = 0; i < g.w; ++i) host_out[(size_t)j * g.st + i] = tmp[a.cidx(i, j) * 4 + k];
@@ -1202,9 +1179,12 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
       return FOTG_OK;
     }
   if (!strcmp(name, "du") || !strcmp(name, "dv")) {
-    float *tmp = (float *)malloc((size_t)a.d_pair_stride * sizeof(float2));
+    // (resident pipeline: array 0 is the zero state, iteration it writes array it + 1)
+    const size_t d_len = c->res_geo[l] ? (size_t)res_d_it_stride(a, c->p.tv_solverit) : (size_t)a.d_pair_stride;
+    const size_t d_off = c->skew_used[l] ? (size_t)(c->p.tv_innerit * (l + 1)) * d_len : 0;
+    float *tmp = (float *)malloc(d_len * sizeof(float2));
     if (!tmp) return FOTG_ERR_ARG;
-    hipError_t e = hipMemcpy(tmp, a.D + (size_t)pair * a.d_pair_stride, (size_t)a.d_pair_stride * sizeof(float2), hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpy(tmp, a.D + (size_t)pair * a.d_pair_stride + d_off, d_len * sizeof(float2), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { free(tmp); g_last_hip = (int)e; return FOTG_ERR_HIP; }
     memset(host_out, 0, pl * 4);
     const int comp = name[1] == 'v';
@@ -1328,104 +1308,12 @@ static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float 
 }
 
 extern "C" {
-// a copy of the context whose per-pair arenas start at pair `p0` (nothing is owned by the copy)
-static void make_view(const fotg_ctx *c, int p0, fotg_ctx *v)
-{
-  *v = *c;
-  const size_t nv = (size_t)c->ps * c->ps * c->noc;
-  for (int l = c->base_lv; l <= c->p.sc_f; ++l) {
-    const size_t ls = (size_t)c->lev_stride[l] * p0;
-    v->im[0][l] += ls; v->im[1][l] += ls;
-    if (l < c->p.sc_l) continue;
-    const LevelGeom &g = c->geom[l];
-    v->dx0[l] += ls; v->dy0[l] += ls;
-    v->flow[l] += (size_t)p0 * g.w * g.h * 2;
-    v->p_iter[l] += (size_t)p0 * g.nop * 2;
-    v->pweight[l] += (size_t)p0 * g.nop * nv;
-    if (c->taps) {
-      v->tap_t[l] += (size_t)p0 * g.nop * nv; v->tap_tx[l] += (size_t)p0 * g.nop * nv; v->tap_ty[l] += (size_t)p0 * g.nop * nv;
-      v->tap_hes[l] += (size_t)p0 * g.nop * 3; v->tap_cnt[l] += (size_t)p0 * g.nop;
-    }
-    if (c->vr) {
-      VrArgs &a = v->vra[l];
-      a.base += (size_t)p0 * a.pair_stride; a.C += (size_t)p0 * a.c_pair_stride; a.D += (size_t)p0 * a.d_pair_stride;
-      if (c->stage_geo[l]) {
-        VrArgs &aq = v->vraq[l];
-        aq.base += (size_t)p0 * aq.pair_stride; aq.C += (size_t)p0 * aq.c_pair_stride; aq.D += (size_t)p0 * aq.d_pair_stride;
-      }
-    }
-    if (p0 != 0) v->gs[l].trace_host = nullptr;
-  }
-  if (c->vr) v->vr += (size_t)p0 * c->vr_pair_stride;
-  if (c->vrDS) v->vrDS += (size_t)p0 * c->ds_pair_stride;
-}
-
-// enqueue the whole batch on stream s (forking to the internal sub-batch streams and joining back)
-static int calc_enqueue(fotg_ctx *c, int n, const float *I0, const float *I1, const float *initflow, float *outflow, hipStream_t s)
-{
-  const int nsub = (c->nsub > 1 && n >= 4 * c->nsub && !c->p.usefbcon) ? c->nsub : 1;    // >= 4 pairs per sub-batch
-  if (nsub == 1) return calc_range(c, n, I0, I1, initflow, outflow, s);
-  const LevelGeom &gf = c->geom[c->p.sc_l], &gc = c->geom[c->p.sc_f];
-  const size_t frame = (size_t)c->w_org * c->h_org * c->noc, oflow = (size_t)gf.w * gf.h * c->nch;
-  const size_t iflow = (size_t)(gc.w / 2) * (gc.h / 2) * c->nch;
-  HIPCHK(hipEventRecord(c->ev_fork, s));
-  int status = FOTG_OK;
-  for (int k = 0; k < nsub; ++k) {
-    const int p0 = (int)((long)n * k / nsub), p1 = (int)((long)n * (k + 1) / nsub);
-    HIPCHK(hipStreamWaitEvent(c->sub_stream[k], c->ev_fork, 0));
-    fotg_ctx v;
-    make_view(c, p0, &v);
-    v.sync_block = k;
-    const int st = calc_range(&v, p1 - p0, I0 + frame * p0, I1 + frame * p0, initflow ? initflow + iflow * p0 : nullptr,
-                              outflow + oflow * p0, c->sub_stream[k]);
-    if (st && !status) status = st;
-    for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) { c->gs[l] = v.gs[l]; c->stage_used[l] = v.stage_used[l]; }      // keep the last grid state observable (taps)
-    HIPCHK(hipEventRecord(c->ev_join[k], c->sub_stream[k]));
-    HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
-  }
-  return status;
-}
-
 int fotg_calc_batch(fotg_ctx *c, int n, const float *I0, const float *I1, const float *initflow, float *outflow, void *stream)
 {
   if (!c || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
   ON_DEVICE(c->device);
-  hipStream_t s = (hipStream_t)stream;
-  bool tracing = false;
-  for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) tracing |= c->gs[l].trace_host != nullptr;
-  const bool graphable = c->use_graph && !tracing && c->nsub > 1 && n >= 4 * c->nsub;
-  if (!graphable) return calc_enqueue(c, n, I0, I1, initflow, outflow, s);
-  const bool same = c->g_n == n && c->g_I0 == I0 && c->g_I1 == I1 && c->g_init == initflow && c->g_out == outflow;
-  if (same && c->gexec) {                                       // replay
-    HIPCHK(hipGraphLaunch(c->gexec, s));
-    return FOTG_OK;
-  }
-  if (!same) {                                                  // new arguments: run eagerly, remember them
-    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-    c->g_n = n; c->g_I0 = I0; c->g_I1 = I1; c->g_init = initflow; c->g_out = outflow; c->g_seen = 1;
-    return calc_enqueue(c, n, I0, I1, initflow, outflow, s);
-  }
-  // second call with the same arguments: capture on the internal stream, instantiate, launch
-  hipGraph_t graph = nullptr;
-  HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-  const int st = calc_enqueue(c, n, I0, I1, initflow, outflow, c->cap_stream);
-  const hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
-  if (st != FOTG_OK || e != hipSuccess || !graph) {
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipGetLastError();
-    c->use_graph = 0;                                           // fall back to eager launches for good
-    return st != FOTG_OK ? st : calc_enqueue(c, n, I0, I1, initflow, outflow, s);
-  }
-  const hipError_t ei = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (ei != hipSuccess) {
-    (void)hipGetLastError();
-    c->gexec = nullptr; c->use_graph = 0;
-    return calc_enqueue(c, n, I0, I1, initflow, outflow, s);
-  }
-  HIPCHK(hipGraphLaunch(c->gexec, s));
-  return FOTG_OK;
+  return calc_range<float>(c, n, I0, I1, initflow, outflow, (hipStream_t)stream);
 }
 
 /* 8-bit frames (SURVEY 8f "next" row 2): same path, the pyramid base kernel converts on load (exact) and reads a
@@ -1583,7 +1471,7 @@ long fotg_debug_counter(const char *name)
 {
   if (name && !strcmp(name, "sor_stream")) return g_stream_launches;
   if (name && !strcmp(name, "sor_wide")) return g_wide_launches;
-  if (name && !strcmp(name, "vr_stage")) return g_stage_launches;
+  if (name && !strcmp(name, "vr_resident")) return g_res_launches;
   if (name && !strcmp(name, "sor_tiles")) return g_tile_launches;
   return -1;
 }
@@ -1605,7 +1493,7 @@ int fotg_level_timings(fotg_ctx *c, int l, float *ms5)
 long fotg_ctx_counter(fotg_ctx *c, const char *name)
 {
   if (!c || !name) return -1;
-  if (!strcmp(name, "stage_stamps_ptr")) return (long)(size_t)c->stamps;
+  if (!strcmp(name, "stamps_ptr")) return (long)(size_t)c->stamps;        // -DFOTG_TILE_STATS builds (tools/tile_stats.py)
 #ifdef FOTG_DEBUG
   if (!strcmp(name, "guard_violations")) {
     DevGuard dg(c->device);
@@ -1636,25 +1524,21 @@ long fotg_ctx_counter(fotg_ctx *c, const char *name)
     DevGuard dg(c->device);
     long tot = 0;
     if (!dg.ok || hipDeviceSynchronize() != hipSuccess) return -1;
-    for (int b = 0; b < 8; ++b) {
+    {
       int v = 0;
-      if (hipMemcpy(&v, c->tileSync + (size_t)b * (tile_sync_words(c->max_batch) + 32) + tile_sync_words(c->max_batch), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      if (hipMemcpy(&v, c->tileSync + tile_sync_words(c->max_batch), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
       tot += v;
     }
     return tot;
   }
-  if (!strcmp(name, "vr_stage_timeouts")) {
-    // bounded waits of the stage pipeline that gave up since the context was created (0 unless something is broken)
+  if (!strcmp(name, "vr_res_timeouts")) {
+    // bounded waits of the resident pipeline that gave up since the context was created (0 unless something is broken)
     if (!c->vrSync) return 0;
     DevGuard dg(c->device);
-    long tot = 0;
+    int v = 0;
     if (!dg.ok || hipDeviceSynchronize() != hipSuccess) return -1;
-    for (int b = 0; b < 8; ++b) {
-      int v = 0;
-      if (hipMemcpy(&v, c->vrSync + (size_t)b * stage_sync_words(c->max_batch) + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-      tot += v;
-    }
-    return tot;
+    if (hipMemcpy(&v, c->vrSync + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
   }
   return -1;
 }

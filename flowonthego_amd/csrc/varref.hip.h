@@ -43,7 +43,7 @@ struct VrArgs {
   long d_pair_stride;    // in float2
   int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows, band_mode, taps;
   int skew;              // 1: the planes are stored skewed like D (pixel (i,j) at [(i+j) * RPD + j], pl = (S+1) * RPD floats): the
-                         // stage-pipelined refinement (varref_stage.hip.h) reads them along anti-diagonals, coalesced
+                         // resident refinement pipeline (varref_resident.hip.h) reads them along anti-diagonals, coalesced
   __host__ __device__ int pix(int i, int j) const { return skew ? (i + j) * RPD + j : j * st + i; }
   __host__ __device__ float4 *Cp(int pair) const { return C + (size_t)pair * c_pair_stride; }
   __host__ __device__ float2 *Dp(int pair) const { return D + (size_t)pair * d_pair_stride; }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
     for (long k = (long)wg.x * 256 + threadIdx.x; k < a.d_pair_stride; k += (long)gridDim.x * 256) D[k] = make_float2(0.f, 0.f);
   }
   if (zero_d == 2 && zero_words) {
-    // stage-pipelined refinement: the ticket counter and the per-(pair, stage) progress words of the launch that follows
+    // resident refinement pipeline: the ticket counter and the progress words of the launch that follows
     for (long k = ((long)wg.y * gridDim.x + wg.x) * 256 + threadIdx.x; k < zero_n; k += (long)gridDim.x * gridDim.y * 256)
       if (k != 1) zero_words[k] = 0;                              // word 1 counts timed-out waits over the life of the context
   }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
   if (i < w && j < h) {
     const int o = a.pix(i, j);
     if (a.skew && NCH == 2) {
-      // stage pipeline: (wx,wy) interleaved, and the differences of wx, wy that sub_laplacian forms (opticalflow_aux.c:172-199;
+      // resident pipeline: (wx,wy) interleaved, and the differences of wx, wy that sub_laplacian forms (opticalflow_aux.c:172-199;
       // neighbours outside the image: the term is skipped there, any finite value will do)
       const float2 *f = reinterpret_cast<const float2 *>(flow + (size_t)pair * flow_stride);
       const int q = j * w + i;

@@ -57,12 +57,15 @@ def alley_golden_flow():
     return np.load(os.path.join(GOLDEN, "alley_0001_flo.npz"))["flow"]
 
 
-def load_fdf(noc):
-    z = np.load(os.path.join(GOLDEN, "fdf_ref_%s.npz" % ("gray" if noc == 1 else "rgb")))
+def load_fdf(noc, level4=True):
+    """golden vectors of the reference's own FDF code: three small levels (+ a 120 x 68 level = 1080p level 4; the depth-mode
+    fixtures cover the small levels only)"""
     cases = {}
-    for k in z.files:
-        name, key = k.split("/")
-        cases.setdefault(name, {})[key] = z[k]
+    for stem in ("fdf_ref_%s.npz", "fdf_ref_l4_%s.npz")[:2 if level4 else 1]:
+        z = np.load(os.path.join(GOLDEN, stem % ("gray" if noc == 1 else "rgb")))
+        for k in z.files:
+            name, key = k.split("/")
+            cases.setdefault(name, {})[key] = z[k]
     return cases
 
 

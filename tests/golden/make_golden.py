@@ -10,6 +10,9 @@ plain data and travel to the GPU box.
   fdf_ref_gray.npz      inputs and OUTPUTS OF THE REFERENCE'S OWN FDF1.0.1 CODE (oracle/_ref) for the
   fdf_ref_rgb.npz       variational-refinement chain (kroeger/refine_variational.cpp:153-241):
                         every intermediate plane of the last inner iteration + the refined flow
+  fdf_ref_l4_*.npz      the same chain on a 120 x 68 level (1080p level 4: images/road_HD.jpg and a shifted copy, padded to 1088 rows
+                        and halved four times; five inner iterations) -- the size class the engine's resident refinement pipeline
+                        (65..96 rows) handles
   fdf_ref_depth_*.npz   the same inputs through the reference's stereo-depth chain (RefLevelDE, :243-330)
   natural_images.npz    the reference's natural test images as 8-bit gray (same formula): images/road_HD.jpg (1920x1080) and
                         images/yosemite_4k.jpg (3840x2160) -- the inputs SURVEY.md 8(d) names for C2-C4 (the second frame of
@@ -84,6 +87,35 @@ def fdf_cases(noc):
     return out
 
 
+def fdf_level4_case(noc):
+    """1080p level 4 (120 x 68, lvl 4 -> five inner iterations) through the reference's FDF code"""
+    ref = R.FdfRef(noc)
+    a0 = rgb(REF + "/images/road_HD.jpg")
+    a1 = np.roll(a0, (2, 5), (0, 1))
+    if noc == 1:
+        f0, f1 = gray_cv(a0).astype(np.float32), gray_cv(a1).astype(np.float32)
+    else:
+        f0, f1 = a0[..., ::-1].astype(np.float32), a1[..., ::-1].astype(np.float32)
+    c0, c1 = O.pad_frame(f0, 6), O.pad_frame(f1, 6)
+    c0 = c0.reshape(c0.shape[0], c0.shape[1], noc); c1 = c1.reshape(c1.shape[0], c1.shape[1], noc)
+    for _ in range(4):
+        c0 = ((c0[0::2, 0::2] + c0[1::2, 0::2]) + (c0[0::2, 1::2] + c0[1::2, 1::2])) * np.float32(0.25)
+        c1 = ((c1[0::2, 0::2] + c1[1::2, 0::2]) + (c1[0::2, 1::2] + c1[1::2, 1::2])) * np.float32(0.25)
+    im1 = np.ascontiguousarray(c0.transpose(2, 0, 1)); im2 = np.ascontiguousarray(c1.transpose(2, 0, 1))
+    h, w = im1.shape[1:]
+    assert (w, h) == (120, 68)
+    wx, wy = smooth_flow(h, w, 7 + w, amp=0.6)
+    wx += np.float32(5.0 / 16); wy += np.float32(2.0 / 16)             # around the true shift at this level
+    dump = {}
+    ox, oy = ref.ref_level_of(im1, im2, wx, wy, 4, dump=dump)
+    name = "w120h68"
+    out = {name + "/im1": im1, name + "/im2": im2, name + "/wx": wx, name + "/wy": wy, name + "/lvl": np.int32(4),
+           name + "/out_x": ox, name + "/out_y": oy}
+    for k, v in dump.items():
+        out[name + "/" + k] = v
+    return out
+
+
 def depth_cases(noc):
     """stereo depth (SELECTMODE 2) refinement: same inputs as fdf_cases (read back from its fixture), outputs of the
     reference's compute_data_DE / sor_coupled_slow_but_readable_DE chain (RefLevelDE) for both camera sides.
@@ -112,6 +144,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "alley_0001_flo.npz"), flow=gold)
     np.savez_compressed(os.path.join(OUT, "fdf_ref_gray.npz"), **fdf_cases(1))
     np.savez_compressed(os.path.join(OUT, "fdf_ref_rgb.npz"), **fdf_cases(3))
+    np.savez_compressed(os.path.join(OUT, "fdf_ref_l4_gray.npz"), **fdf_level4_case(1))
+    np.savez_compressed(os.path.join(OUT, "fdf_ref_l4_rgb.npz"), **fdf_level4_case(3))
     np.savez_compressed(os.path.join(OUT, "fdf_ref_depth_gray.npz"), **depth_cases(1))
     np.savez_compressed(os.path.join(OUT, "fdf_ref_depth_rgb.npz"), **depth_cases(3))
     np.savez_compressed(os.path.join(OUT, "natural_images.npz"), road_HD=gray_cv(rgb(REF + "/images/road_HD.jpg")),

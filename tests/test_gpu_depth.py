@@ -90,7 +90,7 @@ def test_depth_varref_golden_reference_vectors(noc):
     chain (tests/golden/fdf_ref_depth_*.npz): system planes of the last inner iteration and the refined displacement"""
     F, OFClass, VarRefClass, O = _mods()
     z = np.load(os.path.join(GOLDEN, "fdf_ref_depth_%s.npz" % ("gray" if noc == 1 else "rgb")))
-    for name, c in load_fdf(noc).items():
+    for name, c in load_fdf(noc, level4=False).items():
         im1, im2, wx, lvl = c["im1"], c["im2"], c["wx"], int(c["lvl"])
         _, h, w = im1.shape
         op = depth_op(F, 2, 1024, noc)

@@ -133,16 +133,17 @@ def test_patchgrid_stages_parity(case, op_point, alley):
         prev_o = fo
 
 
-@pytest.mark.parametrize("stage", ["0", "1"])
+@pytest.mark.parametrize("resident", ["1", "0"])
 @pytest.mark.parametrize("noc", [1, 3])
-def test_varref_golden_reference_vectors(noc, stage, monkeypatch):
+def test_varref_golden_reference_vectors(noc, resident, monkeypatch):
     """VarRefClass against outputs of the reference's own FDF1.0.1 code (tests/golden/fdf_ref_*.npz): every
-    intermediate plane of the last inner iteration and the refined flow, bit for bit -- through the per-iteration
-    launches / fused levels (stage 0) and through the stage pipeline (stage 1: planes live skewed, taps from the last stage)"""
+    intermediate plane of the last inner iteration and the refined flow, bit for bit -- the small levels through the fused
+    per-level kernel, the 120 x 68 level through the resident pipeline (default: planes live skewed, the system of the last
+    iteration comes from the data workgroups, (du,dv) from the solver's writer) and through the per-iteration launches
+    (FOTG_VR_RESIDENT=0)"""
     F, OFClass, VarRefClass, O = _mods()
-    monkeypatch.setenv("FOTG_VR_STAGE", stage)
-    monkeypatch.setenv("FOTG_VR_STAGE_MINS", "24")
-    before = F.lib().fotg_debug_counter(b"vr_stage")
+    monkeypatch.setenv("FOTG_VR_RESIDENT", resident)
+    before = F.lib().fotg_debug_counter(b"vr_resident")
     for name, c in load_fdf(noc).items():
         im1, im2, wx, wy, lvl = c["im1"], c["im2"], c["wx"], c["wy"], int(c["lvl"])
         _, h, w = im1.shape
@@ -169,8 +170,8 @@ def test_varref_golden_reference_vectors(noc, stage, monkeypatch):
         for nm in ("Ix", "Iy", "Iz", "Ixx", "Ixy", "Iyy", "Ixz", "Iyz"):
             assert np.array_equal(plane(nm, noc), c[nm]), (name, nm)
         assert np.array_equal(out[..., 0], c["out_x"]) and np.array_equal(out[..., 1], c["out_y"]), name
-        assert F.lib().fotg_ctx_counter(ofc._h, b"vr_stage_timeouts") == 0
-    assert (F.lib().fotg_debug_counter(b"vr_stage") > before) == (stage == "1")
+        assert F.lib().fotg_ctx_counter(ofc._h, b"vr_res_timeouts") == 0
+    assert (F.lib().fotg_debug_counter(b"vr_resident") > before) == (resident == "1")
 
 
 @pytest.mark.parametrize("case,op_point,sor_mode", [("alley", 2, 0), ("alley", 2, 1), ("alley_rgb", 2, 0),
@@ -230,29 +231,27 @@ def test_switches_are_read_at_creation_and_debug_switches_are_compiled_out(alley
     before = F.lib().fotg_debug_counter(b"sor_stream")
     f0, f1 = synth_pair(1080, 1920, seed=9)
     op = F.operating_point(2, 1920, 1)
-    monkeypatch.setenv("FOTG_VR_STAGE", "0")
     ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=8))
     monkeypatch.setenv("FOTG_VR_STREAM", "0")             # too late for this context
     ofc.calc(dev(f0), dev(f1))
     assert F.lib().fotg_debug_counter(b"sor_stream") > before
 
 
-@pytest.mark.parametrize("mins", ["24", "80"])
-def test_stage_pipeline(mins, alley, monkeypatch):
-    """the stage-pipelined refinement (varref_stage.hip.h: one workgroup per inner iteration, (du,dv) handed from stage to
-    stage through global memory) against the oracle: the three ring geometries (levels of <= 36, <= 69, <= 97 rows), odd row
-    counts, RGB, batches larger than the chip holds at once (tickets), 1 and 2 sweeps; FOTG_VR_STAGE_MINS=24 also sends
-    the small coarse levels through it.  No wait may have timed out."""
+def test_resident_pipeline(alley, monkeypatch):
+    """the resident refinement pipeline (opt-in: FOTG_VR_RESIDENT=1) (varref_resident.hip.h: per pair a solver workgroup that stays resident over the inner
+    iterations + data workgroups on other CUs, handing (du,dv) and the system over through memory) against the oracle: both
+    ring geometries (levels of <= 69 and <= 97 rows), odd row counts, 1 / 2 / 3 sweeps, one inner iteration (no hand-over
+    at all) and several.  No wait may have timed out."""
     F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_VR_STAGE", "1")
-    monkeypatch.setenv("FOTG_VR_STAGE_MINS", mins)
+    monkeypatch.setenv("FOTG_VR_RESIDENT", "1")
     L = F.lib()
-    before = L.fotg_debug_counter(b"vr_stage")
-    cases = [((1024, 436), 2, 1, 3, 1), ((1920, 1080), 2, 1, 3, 2), ((1600, 1200), 2, 1, 3, 1), ((1904, 1064), 2, 1, 3, 1),
-             ((328, 200), 2, 3, 3, 2), ((500, 270), 2, 1, 2, 1), ((500, 270), 2, 1, 1, 1), ((720, 1000), 2, 1, 3, 1)]
-    for (w, h), op_point, noc, sweeps, n in cases:
+    before = L.fotg_debug_counter(b"vr_resident")
+    # (size, width the operating point is derived from, channels, sweeps, pairs)
+    cases = [((1920, 1080), 1920, 1, 3, 2), ((1600, 1200), 1920, 1, 3, 1), ((1904, 1064), 1920, 1, 3, 1), ((1280, 1050), 1920, 1, 3, 1),
+             ((1920, 1080), 1920, 1, 2, 1), ((1920, 1080), 1920, 1, 1, 1), ((1264, 1500), 1920, 1, 3, 1)]
+    for (w, h), wop, noc, sweeps, n in cases:
         pairs = [synth_pair(h, w, seed=31 + k, noc=noc) for k in range(n)]
-        op = F.operating_point(op_point, 1920 if (w, h) in ((1600, 1200), (1904, 1064)) else w, noc)
+        op = F.operating_point(2, wop, noc)
         op.var_ref_iter = sweeps
         ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=n)
         out = ofc.calc_batch(dev(np.stack([p[0] for p in pairs])), dev(np.stack([p[1] for p in pairs]))).cpu().numpy()
@@ -260,17 +259,27 @@ def test_stage_pipeline(mins, alley, monkeypatch):
         for k in range(n):
             ref = O.flow(O.pad_frame(pairs[k][0], p.sc_f), O.pad_frame(pairs[k][1], p.sc_f), p, 0)
             assert np.array_equal(out[k], ref), ((w, h), noc, sweeps, k, float(np.abs(out[k] - ref).max()))
-        assert L.fotg_ctx_counter(ofc._h, b"vr_stage_timeouts") == 0
+        assert L.fotg_ctx_counter(ofc._h, b"vr_res_timeouts") == 0
         ofc.close()
-    assert L.fotg_debug_counter(b"vr_stage") > before
+    assert L.fotg_debug_counter(b"vr_resident") >= before + len(cases)
+    # a level of 65..96 rows with ONE inner iteration: a single-scale operating point at scale 0 on a small image
+    f0, f1 = synth_pair(70, 160, seed=3)
+    op = F.operating_point(2, 160, 1)
+    op.coarsest_scale = op.finest_scale = 0
+    ofc = OFClass(op, F.img_params(width=160, height=70, padding=8))
+    p = oracle_params(O, op)
+    before = L.fotg_debug_counter(b"vr_resident")
+    assert np.array_equal(ofc.calc(dev(f0), dev(f1)).cpu().numpy(), O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0))
+    assert L.fotg_debug_counter(b"vr_resident") == before + 1 and L.fotg_ctx_counter(ofc._h, b"vr_res_timeouts") == 0
 
 
-def test_stage_pipeline_more_workgroups_than_cus(monkeypatch):
-    """80 pairs x 5 stages = 400 workgroups of one per CU on 256 CUs: the late tickets start when the early ones exit; every pair
-    still equals its single-pair result (and pair 0 the oracle)"""
+def test_resident_pipeline_more_workgroups_than_cus(monkeypatch):
+    """80 pairs x 4 workgroups of one per CU on 256 CUs: the late tickets start when the early pairs exit (a pair's workgroups
+    hold consecutive tickets, so at most one pair is ever partly started); every pair still equals its single-pair result (and
+    pairs 0, 1 the oracle)"""
     F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_VR_STAGE", "1")
-    before = F.lib().fotg_debug_counter(b"vr_stage")
+    monkeypatch.setenv("FOTG_VR_RESIDENT", "1")
+    before = F.lib().fotg_debug_counter(b"vr_resident")
     n = 80
     f0, f1 = synth_pair(1080, 1920, seed=77)
     I0 = dev(f0)[None].repeat(n, 1, 1).contiguous(); I1 = dev(f1)[None].repeat(n, 1, 1).contiguous()
@@ -282,8 +291,8 @@ def test_stage_pipeline_more_workgroups_than_cus(monkeypatch):
     p = oracle_params(O, op)
     assert np.array_equal(out[0].cpu().numpy(), O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0))
     assert np.array_equal(out[1].cpu().numpy(), O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0))
-    assert F.lib().fotg_ctx_counter(ofc._h, b"vr_stage_timeouts") == 0
-    assert F.lib().fotg_debug_counter(b"vr_stage") > before
+    assert F.lib().fotg_ctx_counter(ofc._h, b"vr_res_timeouts") == 0
+    assert F.lib().fotg_debug_counter(b"vr_resident") > before
 
 
 @pytest.mark.parametrize("mode", ["0", "1"])
@@ -294,7 +303,6 @@ def test_streaming_solver_kernel(mode, monkeypatch):
     (68-row level), a narrower 68-row level, a 75-row level (second LDS geometry) and an odd row count (67)"""
     F, OFClass, _, O = _mods()
     monkeypatch.setenv("FOTG_VR_STREAM", mode)
-    monkeypatch.setenv("FOTG_VR_STAGE", "0")                 # (these levels take the stage pipeline by default)
     before = F.lib().fotg_debug_counter(b"sor_stream")
     sizes = ((1920, 1080), (1280, 1050), (1600, 1200), (1904, 1072 - 8))
     expect = 0
@@ -460,7 +468,6 @@ def test_fused_level_system_in_global_memory(alley, monkeypatch):
     through global memory (what larger levels use): same bits"""
     F, OFClass, _, O = _mods()
     monkeypatch.setenv("FOTG_VR_CLDS", "0")
-    monkeypatch.setenv("FOTG_VR_STAGE", "0")
     for case, op_point in (("alley", 2), ("synth_rgb", 2)):
         f0, f1, noc = frames(case, alley)
         h, w = f0.shape[:2]
@@ -483,34 +490,6 @@ def test_lk_partial_waves(alley):
         out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
         p = oracle_params(O, op)
         assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
-
-
-@pytest.mark.parametrize("graph", ["0", "1"])
-def test_subbatch_streams_and_graph(graph, monkeypatch):
-    """optional sub-batch pipelining on internal streams (FOTG_SUBBATCH) with and without hipGraph capture: same bits,
-    also on replay and after the arguments change"""
-    F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_SUBBATCH", "2")
-    monkeypatch.setenv("FOTG_GRAPH", graph)
-    n = 8
-    pairs = [synth_pair(270, 500, seed=50 + k) for k in range(n)]
-    I0 = dev(np.stack([p[0] for p in pairs])); I1 = dev(np.stack([p[1] for p in pairs]))
-    op = F.operating_point(2, 500, 1)
-    ofc = OFClass(op, F.img_params(width=500, height=270, padding=8), max_batch=n)
-    p = oracle_params(O, op)
-    refs = [O.flow(O.pad_frame(a, p.sc_f), O.pad_frame(b, p.sc_f), p, 0) for a, b in pairs]
-    out = ofc.new_outflow(n)
-    for _ in range(4):                       # eager, capture+launch, replay, replay
-        out.zero_()
-        ofc.calc_batch(I0, I1, None, out)
-        got = out.cpu().numpy()
-        for k in range(n):
-            assert np.array_equal(got[k], refs[k]), k
-    J0 = I0.flip(0).contiguous(); J1 = I1.flip(0).contiguous()      # new arguments -> graph is dropped and rebuilt
-    for _ in range(3):
-        got = ofc.calc_batch(J0, J1).cpu().numpy()
-        for k in range(n):
-            assert np.array_equal(got[k], refs[n - 1 - k]), k
 
 
 def test_4k_quality_preset(monkeypatch):

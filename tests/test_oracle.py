@@ -236,7 +236,7 @@ def test_depth_fdf_golden_vectors(noc):
     from conftest import GOLDEN
     z = np.load(os.path.join(GOLDEN, "fdf_ref_depth_%s.npz" % ("gray" if noc == 1 else "rgb")))
     p = depth_params(2, 1024, noc)
-    for name, c in load_fdf(noc).items():
+    for name, c in load_fdf(noc, level4=False).items():
         im1, im2, wx, lvl = c["im1"], c["im2"], c["wx"], int(c["lvl"])
         _, h, w = im1.shape
         for camlr in (0, 1):

@@ -26,7 +26,7 @@ for trial in range(4):
         for _ in range(10): check(lib().fotg_bench_sor_call(ofc._h, lvl, 1, None))
         torch.cuda.synchronize()
         us = (time.perf_counter() - t) / 10 * 1e6
-        ptr = lib().fotg_ctx_counter(ofc._h, b"stage_stamps_ptr")
+        ptr = lib().fotg_ctx_counter(ofc._h, b"stamps_ptr")
         st = np.zeros((64, 32), np.int64)
         hip.hipMemcpy(st.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), st.nbytes, 2)
         st = st[st[:, 0] != 0]
