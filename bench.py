@@ -18,6 +18,8 @@ a time through a single context (fotg_calc_batch) is timed too and reported as `
 Extra objects in the JSON line:
   roofline      HBM roofline of the kernel that moves the path's algorithmic bytes (pyr_base_kernel: every input byte
                 exactly once), duration measured live with HIP events on the launch stream
+  rooflines     the same for the three kernels that hold most of a step's time (pyr_base, the fused refinement level, one
+                sor_coupled call of the finest level) + a compute-roof object for the LK kernel (useful flops / fp32 peak)
   stage_ms      per-stage GPU time of one step (each stage alone between HIP events); time_dominant_stage names the
                 largest
   cpu_baseline  the CPU oracle (oracle/, a scalar port of the reference's kroeger/ path) timed on this box's host
@@ -43,6 +45,10 @@ sys.path.insert(0, ROOT)
 
 W, H, OP_POINT = 1920, 1080, 2
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak
+TRAFFIC_FILE = "r03_pmc_traffic.json" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json"
+TRAFFIC_NOTE = ("HBM bytes per launch from profiles/%s (separate rocprofv3 --pmc passes of this command, gfx950 FETCH_SIZE correction) -- "
+                "NOT measured in this run" % TRAFFIC_FILE)
 
 
 def synth_batch(n, seed, device):
@@ -125,7 +131,7 @@ def roofline(ofc, I0, I1, lib, stream_ptr, batch):
     alg = batch * (2 * W * H * 4 + 2 * lw * lh * 4)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             k = json.load(f)["kernels"]
         key = [x for x in k if "pyr_base_kernel<float, 1, 4, true>" in x]
         if key and batch == 64:
@@ -135,7 +141,8 @@ def roofline(ofc, I0, I1, lib, stream_ptr, batch):
     gbs = alg / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,1,4,true> (frames -> pyramid level 4, both frames of the batch in one launch)",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms}
+            "traffic_source": TRAFFIC_NOTE, "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms,
+            "measured": "one launch at a time on an otherwise idle GPU; with %s batches in flight the same kernel stretches (profiles/)" % "several"}
 
 
 def roofline_dominant(ofc, lib, stream_ptr, batch, stage_ms):
@@ -152,7 +159,7 @@ def roofline_dominant(ofc, lib, stream_ptr, batch, stage_ms):
     alg = batch * lw * lh * 48
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             k = json.load(f)["kernels"]
         key = [x for x in k if "vr_sor_stream_kernel" in x]
         if key and batch == 64:
@@ -161,24 +168,84 @@ def roofline_dominant(ofc, lib, stream_ptr, batch, stage_ms):
         pass
     inner = lvl + 1
     gbs = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "fotg::vr_sor_stream_kernel<72,70,4,32> (one sor_coupled call = 3 lexicographic sweeps of the %dx%d level, "
-                                      "one workgroup per pair; %d launches per step)" % (lw, lh, inner),
-            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+    return {"bound": "hbm", "bound_note": "nearest roof the contract names; the kernel is latency-bound (bound_by) and its data is L2 resident",
+            "kernel": "fotg::vr_sor_stream_kernel<72,70,4,32> (one sor_coupled call = 3 lexicographic sweeps of the %dx%d level, "
+                      "one workgroup per pair; %d launches per step)" % (lw, lh, inner),
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_NOTE,
             "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_per_step": inner,
             "share_of_step": inner * ms / sum(stage_ms.values()),
             "bound_by": "dependency-chain latency: %d anti-diagonal steps in lock step (~%.0f ns each), one workgroup = one CU per pair; "
                         "the data it touches is L2 resident" % (lw + lh - 1 + 16, ms * 1e6 / (lw + lh - 1 + 16))}
 
 
+def roofline_fused_level(ofc, batch, stage_ms, lvl):
+    """vr_inner_fused_kernel: the whole refinement of a small level (5, 6) in ONE launch, one workgroup per pair.  Algorithmic
+    bytes per launch: per pair both padded level images once (2 (w+2ps)(h+2ps) 4 B), the flow in and
+    out (2 w h 8 B); everything else stays on chip.  Duration: the level's varref stage time (that stage IS the one launch)."""
+    lw, lh = ofc.width >> lvl, ofc.height >> lvl
+    ps = ofc.op.patch_size
+    alg = batch * (2 * (lw + 2 * ps) * (lh + 2 * ps) * 4 + 2 * lw * lh * 8)
+    ms = stage_ms["varref[%d]" % lvl]
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
+            k = json.load(f)["kernels"]
+        key = [x for x in k if "vr_inner_fused_kernel" in x]
+        if key and batch == 64:
+            traffic = k[key[0]]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    gbs = alg / (ms * 1e-3) / 1e9
+    inner = lvl + 1
+    return {"bound": "hbm", "bound_note": "nearest roof the contract names; the kernel is bound by the solver's dependency chain and the VALU of ONE CU per pair",
+            "kernel": "fotg::vr_inner_fused_kernel<1,8,32,true,true> (level %d, %dx%d: set-up + %d x {data term, 3 sweeps} + w+d in one launch, one workgroup per pair)" % (lvl, lw, lh, inner),
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_NOTE,
+            "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_per_step": 1, "share_of_step": ms / sum(stage_ms.values())}
+
+
+def roofline_lk(ofc, batch, stage_ms):
+    """compute roof of lk_kernel<8,1> at the finest level: USEFUL flops (per pixel of a patch and evaluation: 7 bilinear, 2 mean,
+    1 residual, 4 for the two projections, 2 for the L1 residual = 16; per patch and iteration ~30 for the 2x2 solve and the
+    tests, negligible) / launch time, against the fp32 vector peak.  The kernel is VALU-issue bound at ~65 instructions per
+    pixel-iteration (scalar per-patch code carried on 16 lanes, IEEE divisions, no FMA by the numerics contract)."""
+    op = ofc.op
+    lvl = op.finest_scale
+    lw, lh = ofc.width >> lvl, ofc.height >> lvl
+    steps = max(1, int(op.patch_size * (1 - op.patch_stride)))
+    nop = -(-lw // steps) * -(-lh // steps)
+    evals = op.grad_descent_iter + 1
+    flops = batch * nop * evals * op.patch_size * op.patch_size * 16
+    ms = stage_ms["lk[%d]" % lvl]
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"bound": "valu", "kernel": "fotg::lk_kernel<8,1,false> (level %d: %d patches x %d evaluations x 64 px per pair)" % (lvl, nop, evals),
+            "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "useful_flops_per_launch": flops,
+            "ms_per_launch": ms, "share_of_step": sum(v for k, v in stage_ms.items() if k.startswith("lk[")) / sum(stage_ms.values()),
+            "note": "useful flops only; the instruction stream is ~4x that (profiles/: SQ_INSTS_VALU)"}
+
+
 def cpu_baseline(I0, I1, budget_s=12.0):
     """the oracle (scalar C port of the reference's kroeger/ path, pyramid included) on the host: first single-threaded
     for a few pairs, then frame-parallel over all host cores (one pair per thread -- the CPU analogue of frame sharding,
     SURVEY 8d) on a bounded sample of the same batch.  `value` is the all-cores rate."""
-    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     flags = O.use_native()                # -O3 -msse4 -march=native of THIS host (the travelling library has no -march)
     p = O.op_point(OP_POINT, W, 1)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a container's CPU quota (cgroup v2 cpu.max / v1 cfs_quota) is what the process can really use: more threads than that only
+    # get throttled (the GPU boxes of this pool show 256 CPUs and a quota of 16)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except Exception:
+            pass
+    visible = cores
+    if quota:
+        cores = max(1, min(cores, int(quota + 0.5)))
     nb = I0.shape[0]
     host = {}
 
@@ -230,33 +297,41 @@ def cpu_baseline(I0, I1, budget_s=12.0):
         t = time.perf_counter()
         prev = O.varref(P0.im[sl], P1.im[sl], lw, lh, sl, p, fl)
         lap("varref[%d]" % sl, t)
-    # all cores: a calibration round of one pair per thread, then enough pairs for ~0.6 * budget_s at the measured rate
-    for k in range(min(cores, nb)):
-        pair(k)                                                            # device -> host copies outside the timed part
-    tc = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(one, range(cores)))
-        rate = cores / (time.perf_counter() - tc)
-        nall = max(cores, min(int(rate * 0.6 * budget_s), 64 * cores))
-        for k in range(min(nall, nb)):
-            pair(k)
-        t1 = time.perf_counter()
-        list(ex.map(one, range(nall)))
-        el = time.perf_counter() - t1
+    # all cores: dis_flow_many -- pthreads inside the C library, one pair per thread at a time, thread-private block caches (no
+    # allocation per pair after a thread's first), every thread runs one untimed pair first.  Threads are bounded by memory:
+    # a worker holds both pyramids of its pair (~90 MB at 1080p).
+    try:
+        import psutil
+        mem_threads = max(1, int(psutil.virtual_memory().available * 0.5 / 200e6))
+    except Exception:
+        mem_threads = cores
+    threads = max(1, min(cores, mem_threads))
+    nsrc = min(nb, 8)
+    H0 = np.stack([pair(k)[0] for k in range(nsrc)]); H1 = np.stack([pair(k)[1] for k in range(nsrc)])
+    # a short calibration run sizes the timed ones for ~0.3 * budget_s each
+    sec, _ = O.flow_many(H0, H1, p, threads, threads, True)
+    nall = max(threads, min(int(threads / max(sec, 1e-3) * 0.3 * budget_s), 64 * threads))
+    el, _ = O.flow_many(H0, H1, p, nall, threads, True)
+    sec, _ = O.flow_many(H0, H1, p, threads, threads, False)
+    nflow = max(threads, min(int(threads / max(sec, 1e-3) * 0.3 * budget_s), 256 * threads))
+    el_flow, _ = O.flow_many(H0, H1, p, nflow, threads, False)
     flow_ms = sum(v for k, v in st.items() if not k.startswith("pyramid"))
     # the reference's own per-scale timing line (kroeger/oflow.cpp:303), from the port's stage split
     time_lines = ["TIME (Sc: %d, #p:%6d, pconst, pinit, poptim, cflow, tvopt, total): %8.2f %8.2f %8.2f %8.2f %8.2f -> %8.2f ms."
                   % (sl, npatch[sl], 0.0, 0.0, st["lk[%d]" % sl], st["densify[%d]" % sl], st["varref[%d]" % sl],
                      st["lk[%d]" % sl] + st["densify[%d]" % sl] + st["varref[%d]" % sl]) for sl in range(p.sc_f, p.sc_l - 1, -1)]
-    return {"value": nall / el, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+    return {"value": nall / el, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+            "all_cores_flow_only": nflow / el_flow, "host_cpus_visible": visible, "cgroup_cpu_quota": quota,
+            "scaling_vs_single_thread": {"with_pyramid": nall / el / single, "flow_only": nflow / el_flow / (1e3 / flow_ms)},
             "single_thread": single, "single_thread_flow_only": 1e3 / flow_ms,
             "single_thread_stage_ms_per_pair": {k: round(v, 3) for k, v in st.items()}, "time_lines": time_lines,
             "sample": "%d of the batch's 1080p pairs (cycled), op-pt 2 + refinement, pyramid of all levels included like the "
                       "reference's driver builds it (kroeger/run_dense.cpp:130-178), oracle/dis_oracle.c built on this host with %s, "
-                      "one pair per thread on %d threads in %.1f s; single thread: %d pairs at %.1f pairs/s with the pyramid, %.1f pairs/s "
-                      "flow only (what the reference prints as O.Flow Run-Time, kroeger/oflow.cpp:355-360, excludes the pyramid); the "
-                      "survey's probe of the real kroeger build (Eigen, -O3 -msse4) measured ~130 pairs/s/core flow only on a 2.1 GHz Xeon"
-                      % (nall, flags, cores, el, n1, single, 1e3 / flow_ms)}
+                      "one pair per thread on %d pthreads (dis_flow_many: per-thread block caches, no allocation per pair) in %.1f s; "
+                      "flow only (pyramids built once per thread): %d pairs in %.1f s; single thread: %d pairs at %.1f pairs/s with the "
+                      "pyramid, %.1f pairs/s flow only (what the reference prints as O.Flow Run-Time, kroeger/oflow.cpp:355-360, excludes the "
+                      "pyramid); the survey's probe of the real kroeger build (Eigen, -O3 -msse4) measured ~130 pairs/s/core flow only on a "
+                      "2.1 GHz Xeon" % (nall, flags, threads, el, nflow, el_flow, n1, single, 1e3 / flow_ms)}
 
 
 def main():
@@ -322,6 +397,8 @@ def main():
             for _ in range(n):
                 ofc.calc_batch(I0, I1, None, out)
 
+    local_els = []
+
     def window(pipelined):
         """EXACTLY a.steps steps between barrier + synchronize on both sides; max over ranks"""
         barrier()
@@ -329,6 +406,8 @@ def main():
         run_steps(a.steps, pipelined)
         barrier()
         el = time.perf_counter() - t0
+        if pipelined or D == 1:
+            local_els.append(el)
         if dist:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -340,7 +419,10 @@ def main():
         torch.cuda.synchronize()      # the pipe's streams do not wait for torch's: slot 0 shares its buffers with the warm-up above
         run_steps(max(a.warmup, D), True)
         torch.cuda.synchronize()
-        same = all(torch.equal(ofc.calc_batch(f0, f1), o) for f0, f1, o in slots[:2])       # pipelined results = single-context results
+        same = all(torch.equal(ofc.calc_batch(f0, f1), o) for f0, f1, o in slots)           # pipelined results = single-context results, every slot
+        if not same:
+            print(json.dumps({"error": "a batch through the pipe differs from the same batch through one context", "rank": rank}))
+            sys.exit(1)
     # One window of K steps at this batch is ~10 ms -- too short to be robust against clock ramp and launch jitter.  The
     # K-step window is therefore repeated (every repeat is again exactly K steps between barriers); `value` / `ms_per_step`
     # are those of the MEDIAN window, the spread is reported beside them.
@@ -351,7 +433,24 @@ def main():
     els1 = sorted(window(False) for _ in range(max(1, min(a.windows, 9)))) if pipe else els
     el1 = els1[len(els1) // 2]
 
-    res = {"metric": "frame-pairs/sec @1080p DIS op-pt 2", "value": value, "unit": "frame-pairs/s", "n_gpus": world,
+    # host side: time to ISSUE one step's launches (submit returns at once; nothing waits) -- shows whether the launch path limits
+    # the in-flight rate (ms_per_step must stay above it)
+    if pipe:
+        pipe.synchronize()
+        t0 = time.perf_counter()
+        for i in range(4 * D):
+            f0, f1, o = slots[i % D]
+            pipe.submit(f0, f1, None, o, after_current_stream=False)
+        host_issue_ms = (time.perf_counter() - t0) / (4 * D) * 1e3
+        pipe.synchronize()
+    per_rank = None
+    if dist:
+        mine = torch.tensor([sorted(local_els)[len(local_els) // 2] / a.steps * 1e3], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        td.all_gather(allr, mine)
+        per_rank = [float(t.item()) for t in allr]
+
+    res = {"metric": "frame-pairs/sec @1080p DIS op-pt 2" + (" (%d batches of %d in flight)" % (D, a.batch) if pipe else ""), "value": value, "unit": "frame-pairs/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[2]: batch=%d synthetic 1920x1080 gray f32 pairs per GPU, DIS op-pt 2 "
@@ -359,6 +458,9 @@ def main():
                                   "%s SOR; inputs resident in HBM, output = finest-scale flow 120x68x2" %
                                   (a.batch, "lexicographic (reference order)" if a.sor_mode == 0 else "red-black"),
                       "global_batch": world * a.batch,
+                      "pairs_in_flight": world * a.batch * D,
+                      "pairs_in_flight_note": "`value` is measured with %d complete batches of %d pairs resident and overlapping per GPU; "
+                                              "`one_batch_at_a_time` is the figure with one batch of %d resident (the one comparable with round 1)" % (D, a.batch, a.batch),
                       "parallelism": "frame-pair sharding x%d (no collective)%s" % (world, "; %d batches in flight per GPU (engine contexts on "
                                      "internal streams, fotg_pipe_*): step i runs on context i %% %d" % (D, D) if pipe else "")},
            "timed_windows": {"n": len(els), "steps_each": a.steps, "ms_per_step_median": ms_step, "ms_per_step_min": els[0] / a.steps * 1e3,
@@ -369,6 +471,11 @@ def main():
                                            "each step starting when the previous one has finished on the GPU"}}
     if pipe:
         res["pipeline_matches_single_context"] = bool(same)
+        res["pipeline_slots_compared"] = D
+        res["host_issue_ms_per_step"] = host_issue_ms
+        res["host_issue_note"] = "wall time of fotg_pipe_submit (23 kernel launches) per step on the issuing thread; ms_per_step above it = the GPU, not the launch path, sets the rate"
+    if per_rank is not None:
+        res["ms_per_step_per_rank"] = per_rank
 
     if rank == 0:
         stream_ptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -377,11 +484,15 @@ def main():
             res["stage_ms"] = {k: round(v, 4) for k, v in st.items()}
             res["stage_ms_note"] = "each stage alone on one stream: their sum is the time of ONE batch from start to end (one_batch_at_a_time); with batches in flight the stages of different batches overlap"
             res["roofline"] = roofline(ofc, I0, I1, lib, stream_ptr, a.batch)
+            res["rooflines"] = [dict(res["roofline"], share_of_step=st["pyramid(I0,I1)"] / sum(st.values()))]
             if op.use_var_ref and a.sor_mode == 0:
                 try:
                     res["roofline_dominant"] = roofline_dominant(ofc, lib, stream_ptr, a.batch, st)
-                except Exception as e:          # (levels of the resident pipeline have no stand-alone sor_coupled launch)
+                    res["rooflines"].append(res["roofline_dominant"])
+                except Exception as e:          # (levels of the opt-in resident pipeline have no stand-alone sor_coupled launch)
                     res["roofline_dominant"] = {"unavailable": str(e)}
+                res["rooflines"].append(roofline_fused_level(ofc, a.batch, st, op.finest_scale + 1))
+            res["rooflines"].append(roofline_lk(ofc, a.batch, st))
             # the whole path against the same roof: pairs/s x 16 654 080 B / 8 TB/s
             res["whole_path_hbm_frac"] = value / world * (2 * W * H * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS
             res["time_dominant_stage"] = max(st, key=st.get)
@@ -396,7 +507,20 @@ def main():
                 ofc.calc_batch_u8(U0, U1, None, out)
             torch.cuda.synchronize()
             res["u8_frames"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
-                                "note": "same workload with uint8 input frames (exact conversion on load); informational"}
+                                "note": "same workload with uint8 input frames (exact conversion on load), one batch at a time; informational"}
+            if pipe:
+                u8 = [(f0.to(torch.uint8), f1.to(torch.uint8), o) for f0, f1, o in slots]
+                torch.cuda.synchronize()
+                for i in range(2 * D):
+                    pipe.submit(u8[i % D][0], u8[i % D][1], None, u8[i % D][2], after_current_stream=False)
+                pipe.synchronize()
+                t1 = time.perf_counter()
+                for i in range(a.steps):
+                    pipe.submit(u8[i % D][0], u8[i % D][1], None, u8[i % D][2], after_current_stream=False)
+                pipe.synchronize()
+                res["u8_frames"]["in_flight"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s", "batches_in_flight": D,
+                                                 "note": "fotg_pipe_submit_u8: the product mode for 8-bit video (SURVEY 8f row 2), %d batches in flight" % D}
+                del u8
             # BASELINE configs[1]: ONE 1080p pair, op-pt 2's patch parameters (ps 8, stride 4, 3 scales), no variational refinement:
             # the latency of a single call (informational; the headline value is configs[2])
             op1 = F.operating_point(OP_POINT, W, 1)
@@ -474,7 +598,10 @@ def main():
     if dist and a.scatter_gather:
         # end to end with the frames starting on rank 0 and the flows ending there (RCCL over xGMI: scatter + gather only)
         # chunked, double-buffered: chunk t+1 travels (grouped ncclSend/ncclRecv) while chunk t is computed; nothing is padded
-        from flowonthego_amd.shard import gather_flows_exact, pipelined_scatter_compute
+        from flowonthego_amd.shard import PipeEngine, gather_flows_exact, pipelined_scatter_compute
+        if pipe is None:
+            from flowonthego_amd.pipeline import FlowPipeline
+            pipe = FlowPipeline(op, F.img_params(width=W, height=H, padding=op.patch_size), max_batch=a.batch, depth=4, device=local)
         G0 = G1 = None
         if rank == 0:
             G0, G1 = I0.repeat((world,) + (1,) * (I0.dim() - 1)), I1.repeat((world,) + (1,) * (I1.dim() - 1))
@@ -482,7 +609,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         flows, _ = pipelined_scatter_compute(G0, G1, world * a.batch, tuple(I0.shape[1:]), I0.dtype, td,
-                                             lambda x, y: ofc.calc_batch(x.contiguous(), y.contiguous()), chunk, src=0, device=dev)
+                                             PipeEngine(pipe), chunk, src=0, device=dev)     # the same FlowPipeline as the N = 1 path
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         full = gather_flows_exact(flows, world * a.batch, td, dst=0)

@@ -75,8 +75,9 @@ def gather_flows(flow, n_pairs: int, dist, dst: int = 0):
 # Pipelined scatter ("grouped send/recv scatter of input frames from rank 0, pipelined in chunks under compute"):
 # rank `src` holds the whole batch; every rank's contiguous shard (shard_range) is cut into chunks of at most `chunk` pairs;
 # in step t every peer receives chunk t of its shard (one grouped batch_isend_irecv: RCCL ncclSend/ncclRecv groups on GPUs,
-# gloo on CPU) into one of two buffers while it computes on chunk t-1 from the other.  Nothing is padded and rank `src` never
-# builds a second copy of the batch: it sends views of its tensors and computes on views of its own shard.
+# gloo on CPU) into one of depth + 1 buffers while the chunks before it are in flight in the engine (the FlowPipeline of the
+# N = 1 path).  Nothing is padded, nothing is cloned, the host never waits inside the loop, and rank `src` never builds a second
+# copy of the batch: it sends views of its tensors and computes on views of its own shard.
 # ----------------------------------------------------------------------------------------------------------------------
 def chunk_plan(n_pairs: int, world: int, chunk: int):
     """steps[t][rank] = (begin, end) of the pairs rank `rank` receives (src: computes on) in step t, or None when its shard is
@@ -95,20 +96,50 @@ def chunk_plan(n_pairs: int, world: int, chunk: int):
     return steps
 
 
-def pipelined_scatter_compute(I0, I1, n_pairs, frame_shape, dtype, dist, compute, chunk: int, src: int = 0, device=None):
-    """Runs `compute(I0_chunk, I1_chunk) -> flow_chunk` over this rank's shard while the NEXT chunk is in flight from rank
-    `src` (double buffered).  I0 / I1: the whole batch on rank `src`, None elsewhere.  Returns this rank's flows (shard order)
-    and its (begin, end).  `compute` must have finished reading its arguments when it returns a tensor that is later read
-    (stream order on GPUs: the receive buffer of step t is only overwritten in step t+2, after a wait on the transfer of t+2
-    was issued behind the compute of t on the same stream by the caller's synchronisation point below)."""
+class PipeEngine:
+    """adapter: a flowonthego_amd.FlowPipeline as the `engine` of pipelined_scatter_compute (submit / wait / sync)"""
+
+    def __init__(self, pipe):
+        self.pipe, self.depth = pipe, pipe.depth
+
+    def new_out(self, n):
+        return self.pipe.new_outflow(n)
+
+    def submit(self, a, b, out):
+        # ordered behind the current stream (where the receive of this chunk was waited for); returns at once
+        return self.pipe.submit(a, b, None, out, after_current_stream=True)[0]
+
+    def wait(self, ticket):
+        self.pipe.wait(ticket, host=False)          # the current stream waits on the device; the host does not block
+
+    def sync(self):
+        self.pipe.synchronize()
+
+
+def pipelined_scatter_compute(I0, I1, n_pairs, frame_shape, dtype, dist, engine, chunk: int, src: int = 0, device=None):
+    """Runs this rank's shard through `engine` chunk by chunk while the NEXT chunks are in flight from rank `src`.
+    I0 / I1: the whole batch on rank `src`, None elsewhere.  Returns (flows of this rank in shard order, (begin, end)).
+
+    engine: the SAME asynchronous path bench.py times at N = 1 (PipeEngine over a FlowPipeline):
+      engine.depth                   submits that may be in flight
+      engine.new_out(n)              output tensor for n pairs
+      engine.submit(a, b, out) -> t  enqueue one chunk behind the current stream; returns at once; results land in `out`
+      engine.wait(t)                 the CURRENT STREAM (not the host) waits for submit t
+      engine.sync()                  host wait for everything submitted
+    No host synchronisation and no copy per chunk: a chunk is received into one of depth + 1 buffers (on GPUs a
+    request's wait() orders the current stream behind the transfer), submitted behind that wait, and its buffer is only
+    received into again after engine.wait() of the submit that read it has been enqueued in front of that receive; every
+    submit writes its own slice of one preallocated output."""
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
     steps = chunk_plan(n_pairs, world, chunk)
     b0, e0 = shard_range(n_pairs, rank, world)
+    nbuf = int(engine.depth) + 1
     bufs = None
     if rank != src:
-        bufs = [torch.empty((2, chunk) + tuple(frame_shape), dtype=dtype, device=device) for _ in range(2)]
-    flows = []
+        bufs = [torch.empty((2, chunk) + tuple(frame_shape), dtype=dtype, device=device) for _ in range(nbuf)]
+    out = engine.new_out(e0 - b0) if e0 > b0 else None
+    tickets = []
 
     def launch(t):
         ops = []
@@ -121,26 +152,29 @@ def pipelined_scatter_compute(I0, I1, n_pairs, frame_shape, dtype, dist, compute
                 ops.append(dist.P2POp(dist.isend, I1[lo:hi], r))
         elif steps[t][rank] is not None:
             lo, hi = steps[t][rank]
-            ops.append(dist.P2POp(dist.irecv, bufs[t % 2][0, : hi - lo], src))
-            ops.append(dist.P2POp(dist.irecv, bufs[t % 2][1, : hi - lo], src))
+            ops.append(dist.P2POp(dist.irecv, bufs[t % nbuf][0, : hi - lo], src))
+            ops.append(dist.P2POp(dist.irecv, bufs[t % nbuf][1, : hi - lo], src))
         return dist.batch_isend_irecv(ops) if ops else []
 
     pending = launch(0) if steps else []
     for t in range(len(steps)):
-        for req in pending:                      # chunk t has arrived
+        for req in pending:                      # chunk t has arrived (GPU: the current stream is ordered behind the transfer)
             req.wait()
-        pending = launch(t + 1) if t + 1 < len(steps) else []      # chunk t+1 travels while chunk t is computed
-        if steps[t][rank] is None:
-            continue
-        lo, hi = steps[t][rank]
-        if rank == src:
-            a, b = I0[lo:hi], I1[lo:hi]
+        if steps[t][rank] is not None:
+            lo, hi = steps[t][rank]
+            if rank == src:
+                a, b = I0[lo:hi], I1[lo:hi]
+            else:
+                a, b = bufs[t % nbuf][0, : hi - lo], bufs[t % nbuf][1, : hi - lo]
+            tickets.append(engine.submit(a, b, out[lo - b0:hi - b0]))
+        if t + 1 < len(steps):
+            # the buffer chunk t+1 lands in was read by submit t+1-nbuf: order the receive behind that submit
+            if rank != src and t + 1 >= nbuf and t + 1 - nbuf < len(tickets):
+                engine.wait(tickets[t + 1 - nbuf])
+            pending = launch(t + 1)              # chunk t+1 travels while chunks <= t are computed
         else:
-            a, b = bufs[t % 2][0, : hi - lo], bufs[t % 2][1, : hi - lo]
-        flows.append(compute(a, b).clone())
-        if device is not None and str(device).startswith("cuda"):
-            torch.cuda.current_stream(device).synchronize()       # the buffer of step t is free again before step t+2 receives into it
-    out = torch.cat(flows) if flows else None
+            pending = []
+    engine.sync()
     return out, (b0, e0)
 
 

@@ -123,15 +123,49 @@ def _pipe_worker(rank, world, port, n_pairs, chunk, q):
     if rank == 0:
         I0 = torch.arange(n_pairs, dtype=torch.float32).view(-1, 1, 1).expand(n_pairs, 6, 8).contiguous()
         I1 = I0 + 100
-    calls = []
+    calls, log = [], []
 
-    def compute(a, b):                                    # stand-in engine: a "flow" that identifies its pair
-        calls.append(a.shape[0])
-        return torch.stack([a[:, :3, :4], b[:, :3, :4]], -1)
+    class FakeEngine:
+        """stand-in for PipeEngine(FlowPipeline): a "flow" that identifies its pair, and a log of the order of events"""
+        depth = 2
 
-    flow, (lo, hi) = pipelined_scatter_compute(I0, I1, n_pairs, (6, 8), torch.float32, dist, compute, chunk, src=0)
+        def new_out(self, n):
+            return torch.zeros((n, 3, 4, 2))
+
+        def submit(self, a, b, out):
+            calls.append(a.shape[0])
+            out.copy_(torch.stack([a[:, :3, :4], b[:, :3, :4]], -1))
+            log.append(("submit", len(calls) - 1))
+            return len(calls) - 1
+
+        def wait(self, ticket):
+            log.append(("wait", ticket))
+
+        def sync(self):
+            log.append(("sync",))
+
+    real_batch = dist.batch_isend_irecv
+
+    def logged_batch(ops):                               # every launch of a grouped transfer, in order
+        log.append(("launch", sum(1 for e in log if e[0] == "launch")))
+        return real_batch(ops)
+    dist.batch_isend_irecv = logged_batch
+    flow, (lo, hi) = pipelined_scatter_compute(I0, I1, n_pairs, (6, 8), torch.float32, dist, FakeEngine(), chunk, src=0)
+    dist.batch_isend_irecv = real_batch
     ok = (lo, hi) == shard_range(n_pairs, rank, world) and sum(calls) == hi - lo and max(calls, default=0) <= chunk
     ok = ok and all(float(flow[k, 0, 0, 0]) == lo + k and float(flow[k, 0, 0, 1]) == 100 + lo + k for k in range(hi - lo))
+    # the order / overlap contract: exactly one host sync, at the end; chunk t+1 is launched BEFORE the host waits for anything
+    # (it travels while chunks <= t are in the engine); on a receiving rank the transfer into a buffer that submit k read
+    # (transfer k + depth + 1) is launched only after engine.wait(k) was enqueued
+    ok = ok and log.count(("sync",)) == 1 and log[-1] == ("sync",)
+    if rank != 0:
+        pos = {e: i for i, e in enumerate(log)}
+        nbuf = FakeEngine.depth + 1
+        for t in range(len(calls)):
+            if ("launch", t + 1) in pos:
+                ok = ok and pos[("submit", t)] < pos[("launch", t + 1)]
+            if t + nbuf < len(calls):
+                ok = ok and ("wait", t) in pos and pos[("wait", t)] < pos[("launch", t + nbuf)]
     full = gather_flows_exact(flow, n_pairs, dist, dst=0)
     if rank == 0:
         ok = ok and full.shape == (n_pairs, 3, 4, 2) and all(float(full[k, 0, 0, 0]) == k and float(full[k, 0, 0, 1]) == 100 + k for k in range(n_pairs))
@@ -142,10 +176,11 @@ def _pipe_worker(rank, world, port, n_pairs, chunk, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_pairs,chunk", [(8, 2), (7, 3), (9, 16)])
+@pytest.mark.parametrize("n_pairs,chunk", [(8, 2), (7, 3), (9, 16), (23, 2)])
 def test_two_rank_pipelined_scatter_gloo(n_pairs, chunk):
-    """chunked, double-buffered scatter under compute (batch_isend_irecv; RCCL send/recv groups on GPUs) + unpadded gather:
-    every pair computed once, in order, in chunks of <= chunk, the flows arrive on rank 0 in pair order"""
+    """chunked scatter under an asynchronous engine (the FlowPipeline of the N = 1 path; here a fake that logs) + unpadded
+    gather: every pair computed once, in order, in chunks of <= chunk, no host wait inside the loop, a receive buffer is
+    re-used only behind a device-side wait for the submit that read it, the flows arrive on rank 0 in pair order"""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
