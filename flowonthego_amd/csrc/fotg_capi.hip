@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 #include <new>
 #include "common.h"
 #include "pyramid.hip.h"
@@ -60,9 +62,7 @@ struct FotgTune {
   int vr_path;      // FOTG_VR_PATH: 0 automatic, 1 single-wave global-memory solver only, 2 no fused per-level kernel
   int vr_stream;    // FOTG_VR_STREAM: 0 = resident-D kernel instead of the streaming solver
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
-  int vr_wide;      // FOTG_VR_WIDE: 0 = single-wave kernel instead of the wide one
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
-  int vr_tiles;     // FOTG_VR_TILES: 0 = tall levels on one workgroup per pair (wide / single-wave kernels) instead of the tile pipeline
   int vr_resident;  // FOTG_VR_RESIDENT: 0 = launch-per-iteration refinement instead of the resident pipeline (varref_resident.hip.h)
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
@@ -265,9 +265,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_path = env_int("FOTG_VR_PATH", 0);
   c->tune.vr_stream = env_int("FOTG_VR_STREAM", 1);
   c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
-  c->tune.vr_wide = env_int("FOTG_VR_WIDE", 1);
   c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
-  c->tune.vr_tiles = env_int("FOTG_VR_TILES", 1);
   // opt-in: measured at batch 64 it is no faster than the per-iteration launches (0.255 vs 0.249 ms at level 4) and, with several
   // batches in flight, its polling workgroups hold whole CUs (120 k vs 168 k pairs/s) -- docs/EXPERIMENTS.md
   c->tune.vr_resident = env_int("FOTG_VR_RESIDENT", 0);
@@ -321,7 +319,9 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
     const LevelGeom &g = c->geom[p->sc_l];
     // lexicographic solver: up to 1024 rows any kernel, up to 4096 rows the wide kernel one sweep per launch; the depth solver
     // has one thread per row of a workgroup
+    // (more than 1024 rows: only the tile pipeline reaches them, and it runs one wave per sweep for up to four sweeps)
     if (g.h > (p->depth ? 1024 : 4096) && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
+    if (g.h > 1024 && !p->depth && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && p->tv_solverit > 4) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     if (g.w < 3 || c->geom[p->sc_f].h < 5 || c->geom[p->sc_f].w < 3) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc + (p->depth ? (int)DE_NPLANE : 0));
     ALLOC(c->vr, B * c->vr_pair_stride * sizeof(float));
@@ -356,7 +356,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       if (hipMemset(c->vrC[l], 0, cbytes) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       a.C = c->vrC[l]; a.D = c->vrD[l];
       // tall levels (beyond the LDS solvers' 96 rows): per-sweep arrays of the tile pipeline, zero outside the image for good
-      if (c->tune.vr_tiles && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && gl.h > 96 && p->tv_solverit >= 1 && p->tv_solverit <= 4 &&
+      if (p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && gl.h > 96 && p->tv_solverit >= 1 && p->tv_solverit <= 4 &&
           (gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS <= 64) {
         {
           // every lane of every band has a cell of its own in a row (no two lanes share a store target)
@@ -726,8 +726,10 @@ static void set_bands(VrArgs &b, int sweeps)
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: cache what was set per device
+static std::mutex g_lds_mu;             // contexts / pipes driven from different host threads share the per-kernel caches below
 static bool ensure_dyn_lds(const void *fn, int lds, int (&set)[32])
 {
+  std::lock_guard<std::mutex> lock(g_lds_mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) { (void)hipGetLastError(); dev = 0; }
   if (lds <= set[dev]) return true;
@@ -746,14 +748,13 @@ static bool launch_sor_pipe(int n, float omega, hipStream_t s, const VrArgs &b)
   return true;
 }
 
-static long g_wide_launches = 0;        // fotg_debug_counter("sor_wide")
-static long g_res_launches = 0;         // fotg_debug_counter("vr_resident")
-static long g_tile_launches = 0;        // fotg_debug_counter("sor_tiles")
+static std::atomic<long> g_res_launches{0};         // fotg_debug_counter("vr_resident")
+static std::atomic<long> g_tile_launches{0};        // fotg_debug_counter("sor_tiles")
 #ifndef FOTG_TILE_P
 #define FOTG_TILE_P 8                    // prefetch depth (diagonals) of the tile solver
 #endif
 static int a_level(const fotg_ctx *c, const VrArgs &a) { for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) if (c->vra[l].w == a.w && c->vra[l].h == a.h) return l; return c->p.sc_l; }
-static long g_stream_launches = 0;      // fotg_debug_counter("sor_stream"): tests assert the kernel really ran
+static std::atomic<long> g_stream_launches{0};      // fotg_debug_counter("sor_stream"): tests assert the kernel really ran
 // streaming solver (vr_sor_stream_kernel): diagonals travel through LDS rings, two rows per lane.
 template <int RD, int RCW>
 static bool launch_sor_stream_k(const VrArgs &b, int n, float omega, hipStream_t s)
@@ -851,8 +852,8 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
   const int path = c->tune.vr_path;    // 0 = automatic, 1 = single-wave global-memory solver only, 2 = no fused inner loop (tests)
   if (path != 1 && dispatch_sor_pipe(c, a, n, sweeps, omega, s)) return;
   // levels too tall for the LDS solvers: tiles = (sweep, band of 128 rows), one single-wave workgroup each, pipelined through
-  // global memory (varref_tiles.hip.h); tune.vr_tiles = 0: one workgroup per pair (the kernels below; tests)
-  if (path != 1 && c->vrX[a_level(c, a)] && c->tileSync) {
+  // global memory (varref_tiles.hip.h); FOTG_VR_PATH=1 (tests) keeps levels of <= 1024 rows on the single-wave kernel below
+  if ((path != 1 || a.h > 1024) && c->vrX[a_level(c, a)] && c->tileSync) {
     const int l = a_level(c, a);
     TileArgs g;
     g.X = c->vrX[l] + (size_t)(a.C - c->vrC[l]) / a.c_pair_stride * c->x_pair_stride[l];      // (views: same pair offset as C)
@@ -873,24 +874,6 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
     vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sweeps, 128, 0, s>>>(a, g, sweeps, omega);
     ++g_tile_launches;
     return;
-  }
-  if (a.h > 1024 && sweeps >= 1) {
-    // beyond the single-wave kernel's 16 rows per lane: four rows per lane, one sweep per launch (sweeps are sequential passes)
-    const int lp = (((a.h + 3) / 4 + 63) / 64) * 64;
-    for (int k = 0; k < sweeps; ++k) vr_sor_wide_kernel<4><<<n, lp, 0, s>>>(a, 1, omega);
-    g_wide_launches += sweeps;
-    return;
-  }
-  if (c->tune.vr_wide && path != 1 && sweeps >= 1 && sweeps <= 4 && a.h > 96) {
-    for (int k = 2; k <= 4; k += 2) {
-      if (a.K % k) continue;
-      const int lp = (((a.h + k - 1) / k + 63) / 64) * 64;
-      if (sweeps * lp > 1024) continue;
-      if (k == 2) vr_sor_wide_kernel<2><<<n, sweeps * lp, 0, s>>>(a, sweeps, omega);
-      else vr_sor_wide_kernel<4><<<n, sweeps * lp, 0, s>>>(a, sweeps, omega);
-      ++g_wide_launches;
-      return;
-    }
   }
   // prefetch depth: as deep as the register budget of K rows per lane allows, and 2P+2 <= S (ring never
   // runs ahead into rows the current sweep has not rewritten yet)
@@ -1016,6 +999,7 @@ static int varref_depth_impl(fotg_ctx *c, int l, int n, const float *I0, const f
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool set[32];
+    std::lock_guard<std::mutex> lock(g_lds_mu);
     if (dev >= 0 && dev < 32 && !set[dev]) {
       HIPCHK(hipFuncSetAttribute((const void *)vr_de_inner_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)vr_de_inner_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1034,6 +1018,7 @@ static int varref_depth_impl(fotg_ctx *c, int l, int n, const float *I0, const f
   if (lds_bytes > 64 * 1024) {
     int dev = 0;
     (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_lds_mu);
     if (dev >= 0 && dev < 32 && !g_de_lds_set[dev]) {
       HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)vr_de_sor_kernel<3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1470,7 +1455,6 @@ int fotg_calc_sequence_u8(fotg_ctx *c, int n_frames, const unsigned char *frames
 long fotg_debug_counter(const char *name)
 {
   if (name && !strcmp(name, "sor_stream")) return g_stream_launches;
-  if (name && !strcmp(name, "sor_wide")) return g_wide_launches;
   if (name && !strcmp(name, "vr_resident")) return g_res_launches;
   if (name && !strcmp(name, "sor_tiles")) return g_tile_launches;
   return -1;

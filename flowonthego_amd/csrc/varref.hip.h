@@ -604,102 +604,6 @@ __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float 
   }
 }
 
-// Wide variant for levels whose (du,dv) do not fit in LDS (more than ~130 rows at video widths: the fine levels of the
-// quality presets, e.g. 480x272 and 960x544).  The single wave of vr_sor_kernel has to walk K = 6..16 rows per lane, one
-// sweep after the other; here one workgroup of up to 1024 threads works on a pair: thread = (sweep n, lane), a lane owns
-// K = 2 or 4 rows, so up to 512 cells of a diagonal are relaxed per step, and the sweeps run concurrently, sweep n+1 DS = 6
-// diagonals behind sweep n.  Everything stays in the skewed global arrays (L2 / the CU's L1: each diagonal is a contiguous row,
-// so all accesses are coalesced); one workgroup barrier per step.  As in vr_sor_kernel the NEW left values stay in the
-// lane's registers and the new top value of a lane's first row comes from the lane above by DPP -- across a wave boundary
-// through a small double-buffered LDS array -- while C and the old values are loaded LA = 2 steps ahead of their use through a
-// ring of three register stages.  Hazard: sweep n+1 reads diagonal d (as the old right / bottom values of diagonal d-1) at step
-// t0 + DS - 1 - LA if sweep n wrote it at step t0; a wave's stores of step t0 are complete once it has consumed the loads it
-// issued after them (vector memory operations of a wave complete in order), i.e. at step t0 + LA, and a barrier later every
-// wave sees them: DS >= 2 LA + 2.  Same update order as the reference's row-major loop, hence the same bits.
-template <int K>
-__global__ __launch_bounds__(1024) void vr_sor_wide_kernel(VrArgs a, int sweeps, float omega)
-{
-  // look-ahead: K = 2 keeps two stages of loads in flight (ring of three); K = 4 one (ring of two: three stages of four rows
-  // would not fit the 128 registers a 1024-thread workgroup leaves a lane)
-  constexpr int LA = K >= 4 ? 1 : 2, DS = 2 * LA + 2;
-  __shared__ float2 edge[2][4][16];                  // [step parity][sweep][wave of the sweep]: prev[K-1] of the wave's lane 63
-  const int pair = blockIdx.x, tid = threadIdx.x, LP = blockDim.x / sweeps;
-  const int n = tid / LP, L = tid % LP, lane = tid & 63, wv = L >> 6;
-  const int nl = (a.h + K - 1) / K;                  // K divides the K the arrays were padded for, so rows nl*K-1 < RP exist (zero cells)
-  const bool act = L < nl;
-  const int r0 = act ? L * K : 0;                    // idle lanes load (and ignore) the first rows: every lane issues every load
-  const float4 *__restrict__ C = a.Cp(pair);
-  float2 *D = a.Dp(pair);
-  const int S = a.S, RP = a.RP, RPD = a.RPD;
-  struct Stage { float4 c[K][2]; float2 own[K]; float2 nxt[K + 1]; };
-  // unconditional (row clamped into the arrays): with a fixed number of loads per step the compiler's s_waitcnt counting
-  // stays exact and a stage is only waited for when it is consumed, LA steps later
-  auto issue = [&](Stage &st, int row_) {
-    const int row = row_ < 0 ? 0 : (row_ > S - 1 ? S - 1 : row_);
-    {
-      const float4 *cp = C + ((size_t)row * RP + r0) * 2;
-#pragma unroll
-      for (int m = 0; m < K; ++m) { st.c[m][0] = cp[2 * m]; st.c[m][1] = cp[2 * m + 1]; }
-      // explicit 16-byte loads (r0 and RPD are even): 3K + 1 load instructions per stage, the count the barrier's wait relies on
-      const float4 *d0 = reinterpret_cast<const float4 *>(D + (size_t)row * RPD + r0), *d1 = reinterpret_cast<const float4 *>(D + (size_t)(row + 1) * RPD + r0);
-#pragma unroll
-      for (int m = 0; m < K / 2; ++m) {
-        const float4 o = d0[m], x = d1[m];
-        st.own[2 * m] = make_float2(o.x, o.y); st.own[2 * m + 1] = make_float2(o.z, o.w);
-        st.nxt[2 * m] = make_float2(x.x, x.y); st.nxt[2 * m + 1] = make_float2(x.z, x.w);
-      }
-      st.nxt[K] = reinterpret_cast<const float2 *>(d1)[K];
-    }
-  };
-  float2 prev[K];
-  float hl[K];
-#pragma unroll
-  for (int m = 0; m < K; ++m) { prev[m] = make_float2(0.f, 0.f); hl[m] = 0.f; }
-  if (tid < 2 * 4 * 16) (&edge[0][0][0])[tid] = make_float2(0.f, 0.f);
-  __syncthreads();
-  Stage s0, s1, s2;                                  // ring of LA + 1 stages, rotated by unrolling (no copies of loads in flight)
-  issue(s0, 0 - DS * n);
-  if constexpr (LA == 2) issue(s1, 1 - DS * n);
-  const int T = S + DS * (sweeps - 1);
-  auto step = [&](Stage &cur, Stage &nx, int t) {
-    const int s = t - DS * n;                        // this sweep's diagonal (wave-uniform)
-    // the DPP shift is taken with all lanes enabled and selected afterwards (DPP does not fetch from inactive lanes)
-    float2 top0;
-    top0.x = dpp_wave_shr1(prev[K - 1].x);
-    top0.y = dpp_wave_shr1(prev[K - 1].y);
-    if (lane == 0) top0 = wv > 0 ? edge[(t + 1) & 1][n][wv - 1] : make_float2(0.f, 0.f);
-    if (act && s >= 0 && s < S) {
-      float2 res[K];
-#pragma unroll
-      for (int m = 0; m < K; ++m)
-        res[m] = sor_update(cur.own[m], cur.c[m][0], cur.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], cur.nxt[m], cur.nxt[m + 1], omega);
-      float2 *dst = D + (size_t)s * RPD + r0;
-#pragma unroll
-      for (int m = 0; m < K; ++m) { dst[m] = res[m]; prev[m] = res[m]; hl[m] = cur.c[m][1].y; }
-    }
-    if (lane == 63) edge[t & 1][n][wv] = prev[K - 1];
-    issue(nx, s + LA);                               // into the stage the previous step consumed
-    // The barrier waits for LDS (edge) but leaves the newest LA stages of loads and the stores between them in flight.  A
-    // step issues 3K + 1 loads (always: clamped rows) and at most K/2 stores, so a step's stores are at most
-    // LA (3K + 1) + (LA - 1) K/2 operations old two barriers later: complete by then, as the DS = 2 LA + 2 spacing requires.
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(LA * (3 * K + 1) + (LA - 1) * (K / 2)) : "memory");
-  };
-  // 6 steps per loop trip (the compiler drains all loads at the loop header); the steps past T that round the count up find
-  // s >= S and only keep the barriers.  Step t consumes stage t % 3 and refills stage (t + 2) % 3.
-  if constexpr (LA == 2) {
-    for (int t = 0; t < T; t += 6) {
-      step(s0, s2, t);     step(s1, s0, t + 1); step(s2, s1, t + 2);
-      step(s0, s2, t + 3); step(s1, s0, t + 4); step(s2, s1, t + 5);
-    }
-  } else {
-    // step t consumes stage t % 2 and refills the other one (consumed by the previous step)
-    for (int t = 0; t < T; t += 4) {
-      step(s0, s1, t);     step(s1, s0, t + 1);
-      step(s0, s1, t + 2); step(s1, s0, t + 3);
-    }
-  }
-}
-
 // (du,dv) of a level in LDS, skewed like the global arrays (the LDS solvers below).
 //
 // LDS map (dynamic): u64[0..16) = header (unused), u64[16 ..) = float2 cells of D ((S+2) rows of RPD cells: row S stays zero,

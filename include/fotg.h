@@ -195,7 +195,7 @@ int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, floa
 /* measurement tap: ONE sor_coupled call (the launch the refinement issues once per inner iteration) of `level` for n pairs on the
  * system the last fotg_varref left in the workspace; bench.py times it for the roofline of the time-dominant kernel */
 int fotg_bench_sor_call(fotg_ctx *ctx, int level, int n, void *stream);
-/* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_wide", "sor_tiles", "vr_resident"); -1 for unknown names */
+/* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_tiles", "vr_resident"); -1 for unknown names */
 long fotg_debug_counter(const char *name);
 /* per-context counters.  "stalls" (does NOT synchronise): how many times a bounded inter-workgroup wait of this context timed out,
  * as far as the host has seen (FOTG_ERR_STALL above); "inject_stall" (tests) raises the flag as a timed-out wait would.

@@ -17,11 +17,30 @@ def pytest_configure(config):
     # rebuilt and an up-to-date one costs nothing; hipcc cross-compiles gfx950 without a GPU).  A broken build fails here,
     # loudly, not later as an unrelated error.
     import subprocess
-    subprocess.run(["make", "-C", os.path.join(ROOT, "flowonthego_amd", "csrc")], check=True, stdout=subprocess.DEVNULL)
+    global BUILD_ERROR
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "flowonthego_amd", "csrc")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        # (no hipcc, a partial ROCm install ...): the oracle / shard / distributed tests do not need libfotg.so -- only the
+        # tests that load it fail, each with this message (fixture `libfotg` below and flowonthego_amd._lib itself)
+        BUILD_ERROR = "building libfotg.so failed:\n" + (r.stderr or "")[-2000:]
     # the checker (and, where the reference tree exists, oracle/_ref): the live-reference tests are skipped by a
     # collection-time test for oracle/_ref
-    from oracle import oracle as _O
-    _O.build()
+    try:
+        from oracle import oracle as _O
+        _O.build()
+    except Exception as e:               # (no gcc): the tests that use the oracle fail on their own
+        print("building the oracle failed: %s" % e)
+
+
+BUILD_ERROR = None
+
+
+@pytest.fixture(autouse=True)
+def _needs_libfotg(request):
+    """a broken HIP build FAILS every test that loads the library (gpu-marked tests, tests/test_host.py) -- loudly, never a
+    skip -- and leaves the oracle / shard / distributed tests running"""
+    if BUILD_ERROR and ("gpu" in request.keywords or "test_host" in request.node.nodeid):
+        pytest.fail(BUILD_ERROR)
 
 
 def pytest_collection_modifyitems(config, items):

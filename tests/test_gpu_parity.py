@@ -399,44 +399,18 @@ def test_tile_solver_more_tiles_than_cus():
     ofc.close()
 
 
-@pytest.mark.parametrize("wide", ["1", "0"])
-def test_wide_solver_kernel(wide, monkeypatch):
-    """levels too tall for the LDS solvers (the fine levels of the quality presets) are relaxed by vr_sor_wide_kernel: a whole
-    workgroup per pair, two or four rows per lane, sweeps side by side on the global arrays.  FOTG_VR_WIDE=0: the single-wave
-    kernel -- same bits.  Sizes: op-pt 3 at 1080p (level 2 = 480x272, two rows per lane), a 132-row level (three rows per
-    lane in the array padding: falls back), op-pt 4 on a tall frame (544-row level), and a batch of two"""
+@pytest.mark.parametrize("path", ["0", "1"])
+def test_levels_taller_than_1024_rows(path, monkeypatch):
+    """a refined level of more than 1024 rows (beyond 16 rows per lane of the single-wave solver) takes the tile pipeline (21
+    bands) -- also with FOTG_VR_PATH=1, which keeps every shorter level on the single-wave kernel.  op-pt 3 on a narrow tall
+    frame refines the full-resolution level (1304 rows)"""
     F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_VR_WIDE", wide)
-    monkeypatch.setenv("FOTG_VR_TILES", "0")                 # (tall levels take the tile pipeline by default)
-    before = F.lib().fotg_debug_counter(b"sor_wide")
-    ran = 0
-    for (w, h), op_point, width_for_op in (((1920, 1080), 3, 1920), ((640, 528), 3, 640), ((480, 2176), 4, 3840)):
-        f0, f1 = synth_pair(h, w, seed=4)
-        op = F.operating_point(op_point, width_for_op, 1)
-        if op_point == 4:
-            op.grad_descent_iter = 8                           # keep the oracle quick; the solver is what is under test
-        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
-        out = ofc.calc_batch(dev(np.stack([f0, f1])), dev(np.stack([f1, f0]))).cpu().numpy()
-        p = oracle_params(O, op)
-        a, b = O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f)
-        assert np.array_equal(out[0], O.flow(a, b, p, 0)) and np.array_equal(out[1], O.flow(b, a, p, 0)), (w, h)
-        ofc.close()
-    ran = F.lib().fotg_debug_counter(b"sor_wide") - before
-    assert (ran > 0) if wide == "1" else (ran == 0)
-
-
-@pytest.mark.parametrize("tiles", ["1", "0"])
-def test_levels_taller_than_1024_rows(tiles, monkeypatch):
-    """a refined level of more than 1024 rows (beyond 16 rows per lane of the single-wave solver): the tile pipeline (11 bands), or
-    with FOTG_VR_TILES=0 the wide kernel, four rows per lane, one sweep per launch.  op-pt 3 on a narrow tall frame refines the
-    full-resolution level (1304 rows)"""
-    F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_VR_TILES", tiles)
+    monkeypatch.setenv("FOTG_VR_PATH", path)
     w, h = 304, 1300
     f0, f1 = synth_pair(h, w, seed=8)
     op = F.operating_point(3, w, 1)
     assert op.finest_scale == 0
-    name = b"sor_tiles" if tiles == "1" else b"sor_wide"
+    name = b"sor_tiles"
     before = F.lib().fotg_debug_counter(name)
     ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
     out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()

@@ -175,7 +175,7 @@ def test_no_kernel_uses_scratch_memory():
     assert len(names) == len(scratch) and len(names) > 100
     bad = [(n, b) for n, b in zip(names, scratch) if b != 0]
     assert not bad, bad
-    for must in ("lk_kernel", "vr_sor_wide_kernel", "pyr_base_kernel", "vr_sor_stream_kernel"):
+    for must in ("lk_kernel", "vr_sor_tile_kernel", "pyr_base_kernel", "vr_sor_stream_kernel"):
         assert any(must in n for n in names), must
 
 
