@@ -1354,6 +1354,16 @@ int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int
 {
   if (!out || depth < 1 || depth > FOTG_PIPE_MAX_DEPTH) return FOTG_ERR_ARG;
   ON_DEVICE(device);
+  {
+    // HIP deals its streams to GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream included) and two busy streams on
+    // one queue run one after the other: more than three slots need the variable set BEFORE the HIP runtime is loaded
+    // (INTEGRATION.md section 4).  The library cannot set it any more at this point; say so once.
+    static std::atomic<bool> warned{false};
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    if (depth > 3 && (!e || atoi(e) < depth + 1) && !warned.exchange(true))
+      fprintf(stderr, "fotg_pipe_create: %d batches in flight need a hardware queue each; set GPU_MAX_HW_QUEUES=%d (or more) in the "
+                      "environment before the HIP runtime loads, otherwise slots share queues and do not overlap\n", depth, depth + 4);
+  }
   fotg_pipe *q = new (std::nothrow) fotg_pipe();
   if (!q) return FOTG_ERR_ARG;
   memset((void *)q, 0, sizeof(*q));
