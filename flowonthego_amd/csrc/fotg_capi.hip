@@ -1359,8 +1359,7 @@ int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int
     // one queue run one after the other: more than three slots need the variable set BEFORE the HIP runtime is loaded
     // (INTEGRATION.md section 4).  The library cannot set it any more at this point; say so once.
     static std::atomic<bool> warned{false};
-    const char *e = getenv("GPU_MAX_HW_QUEUES");
-    if (depth > 3 && (!e || atoi(e) < depth + 1) && !warned.exchange(true))
+    if (depth > 3 && env_int("GPU_MAX_HW_QUEUES", 4) < depth + 1 && !warned.exchange(true))      // (creation time, not the launch path)
       fprintf(stderr, "fotg_pipe_create: %d batches in flight need a hardware queue each; set GPU_MAX_HW_QUEUES=%d (or more) in the "
                       "environment before the HIP runtime loads, otherwise slots share queues and do not overlap\n", depth, depth + 4);
   }
