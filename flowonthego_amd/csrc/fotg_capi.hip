@@ -63,6 +63,7 @@ struct FotgTune {
   int vr_stream;    // FOTG_VR_STREAM: 0 = resident-D kernel instead of the streaming solver
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
+  int vr_fused_nt;  // FOTG_VR_FUSED_NT: threads per workgroup of the fused per-level kernel on gray levels of 1025..2048 pixels (512 / 1024)
   int vr_resident;  // FOTG_VR_RESIDENT: 0 = launch-per-iteration refinement instead of the resident pipeline (varref_resident.hip.h)
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
@@ -266,6 +267,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_stream = env_int("FOTG_VR_STREAM", 1);
   c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
   c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
+  c->tune.vr_fused_nt = env_int("FOTG_VR_FUSED_NT", 1024);
   // opt-in: measured at batch 64 it is no faster than the per-iteration launches (0.255 vs 0.249 ms at level 4) and, with several
   // batches in flight, its polling workgroups hold whole CUs (120 k vs 168 k pairs/s) -- docs/EXPERIMENTS.md
   c->tune.vr_resident = env_int("FOTG_VR_RESIDENT", 0);
@@ -808,15 +810,15 @@ static int fused_lds_bytes(const VrArgs &b, bool with_c)
   return 128 + (b.S + 2) * b.RPD * (int)sizeof(float2) + ((b.w * b.h + 3) / 4) * 16 + (with_c ? (b.SC * b.RP + 1) * 32 : 0);
 }
 
-template <int NOC, bool CL = false, bool RES = false>
+template <int NOC, bool CL = false, bool RES = false, int NT = 512>
 static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s,
                                const float *I0, const float *I1, long img_stride, int tw, int pad)
 {
   constexpr int P = 8, U = 32;
   const int lds = fused_lds_bytes(b, CL);
   static int lds_set[32] = {0};
-  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, P, U, CL, RES>), lds, lds_set)) return false;
-  vr_inner_fused_kernel<NOC, P, U, CL, RES><<<n, 512, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
+  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, P, U, CL, RES, NT>), lds, lds_set)) return false;
+  vr_inner_fused_kernel<NOC, P, U, CL, RES, NT><<<n, NT, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
   return true;
 }
 
@@ -840,6 +842,9 @@ static bool dispatch_inner_fused(const fotg_ctx *c, const VrArgs &a, int n, int 
   if (c->tune.vr_clds && fused_lds_bytes(a, true) <= 160 * 1024) {
     // gray levels of <= 4 pixels per thread also keep their per-pixel inputs in registers over the loop
     if constexpr (NOC == 1) {
+      // (levels of more than 1024 pixels: 1024 threads, two pixels each -- 4 waves per SIMD hide the latencies of the per-pixel phases)
+      if (c->tune.vr_fused_nt == 1024 && a.w * a.h > 1024 && a.w * a.h <= 2048 &&
+          launch_inner_fused<1, true, true, 1024>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
       if (a.w * a.h <= 4 * 512 && launch_inner_fused<1, true, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
     }
     if (launch_inner_fused<NOC, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;

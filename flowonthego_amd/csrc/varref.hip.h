@@ -1010,8 +1010,8 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
 // solver waves of the same workgroup.  Replaces 2*inner + 2 launches (and the LDS copy-in/out of D) per level.
 // CL (barrier-stepped waves only): the system cells C stay in LDS too -- the data phase writes them there and the solver
 // waves read them with ds_read_b128, so nothing but the level's input planes crosses the CU boundary inside the loop.
-template <int NOC, int P, int U, bool CL, bool RES = false>
-__global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
+template <int NOC, int P, int U, bool CL, bool RES = false, int NT = 512>
+__global__ __launch_bounds__(NT) void vr_inner_fused_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
                                                              float half_gamma_over3, float omega, float *__restrict__ flow, long flow_stride,
                                                              const float *__restrict__ I0, const float *__restrict__ I1, long img_stride, int tw, int pad)
 {
@@ -1072,12 +1072,12 @@ __global__ __launch_bounds__(512) void vr_inner_fused_kernel(VrArgs a, int inner
     for (int px = threadIdx.x; px < w * h; px += blockDim.x) deriv2_pixel<NOC>(a, pair, px % w, px / w);
     __syncthreads();
   }
-  constexpr int B = 4;                                           // pixels per thread whose global loads are in flight together
+  constexpr int B = 2048 / NT;                                   // pixels per thread whose global loads are in flight together
   const int npx = w * h, nth = blockDim.x;
   // Gray levels of at most B pixels per thread: everything the loop reads from global memory (mask, derivative planes,
   // wx / wy with their neighbours) is constant over the inner iterations -> load it once and keep it in registers;
   // inside the loop only LDS is touched.  (RGB has 35 values per pixel: reloaded every iteration.)
-  // (template flag RES, set by the host when NOC == 1 and npx <= B * 512)
+  // (template flag RES, set by the host when NOC == 1 and npx <= B * NT = 2048)
   constexpr bool resident = RES;
   PixIn<NOC> rp[RES ? B : 1];
   if constexpr (resident) {

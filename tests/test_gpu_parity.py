@@ -788,7 +788,32 @@ def test_batch64_default_path_and_depth4_pipeline():
     pipe.synchronize()
     for j, (_, o) in enumerate(tickets):
         assert torch.equal(o, out if j % 2 == 0 else out[perm]), j
+    # the same batch as 8-bit frames (the frames are integer valued): fotg_pipe_submit_u8 == fotg_calc_batch_u8 == the f32 result
+    U0, U1 = I0.to(torch.uint8), I1.to(torch.uint8)
+    torch.cuda.synchronize()
+    tickets = [pipe.submit(U0, U1) for _ in range(2)]
+    pipe.synchronize()
+    assert torch.equal(ofc.calc_batch_u8(U0, U1), out)
+    for _, o in tickets:
+        assert torch.equal(o, out)
     pipe.close(); ofc.close(); single.close()
+
+
+def test_bench_distributed_leg_on_one_gpu():
+    """bench.py's N > 1 code path with world size 1 on this GPU (FOTG_BENCH_FORCE_DIST=1: RCCL process group, barrier, max-over-ranks
+    and per-rank times, the chunked scatter through the FlowPipeline, the exact gather): runs, and the gathered flows have the
+    shape of the whole batch.  (The 1 -> 8 GPU curve itself is the driver's to measure.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FOTG_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "16", "--steps", "8", "--warmup", "2", "--windows", "3",
+                        "--no-cpu-baseline", "--no-breakdown", "--scatter-gather"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    main = [l for l in lines if "metric" in l][0]
+    sg = [l for l in lines if "scatter_gather" in l][0]["scatter_gather"]
+    assert main["n_gpus"] == 1 and main["value"] > 0 and len(main["ms_per_step_per_rank"]) == 1 and main["pipeline_matches_single_context"]
+    assert sg["gathered_shape"] == [16, 68, 120, 2] and sg["end_to_end_pairs_per_s"] > 0
 
 
 def test_single_1080p_pair_no_refinement():
