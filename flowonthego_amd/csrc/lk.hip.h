@@ -21,6 +21,7 @@
 // into a row-private LDS window of (2ps+4)^2 pixels, so the loop reads no global memory.
 #pragma once
 #include "common.h"
+#include "fdiv_hoist.h"
 
 namespace fotg {
 
@@ -178,6 +179,10 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
   const float L00 = sqrtf(H00);
   const float L10 = DEPTH ? 0.f : H01 / L00;
   const float L11 = DEPTH ? 1.f : sqrtf(H11 - L10 * L10);
+  // The solve divides by L00 and L11 four times per iteration: the reciprocal refinement of those divisions is hoisted
+  // (fdiv_hoist.h); a quotient outside the guarded range sends the whole wave through the compiler's divisions instead.
+  const InvDiv iL00 = make_invdiv(L00), iL11 = make_invdiv(L11);
+  const bool DEN_OK = iL00.ok && iL11.ok;
   bool CONV = !START_OK;                                 // :135-141; pweight stays 0 (oracle definition D2)
   int CNT = 0;
   float DP0 = 0.f, DP1 = 0.f, DPN_INIT = 1e-10f, MARES = 1e5f, MARES_OLD = 1e20f;
@@ -241,13 +246,26 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
   while (__builtin_amdgcn_ballot_w64(!CONV) != 0) {
     if (!CONV) {                                         // rows whose patch runs this iteration (all 16 lanes of a row agree)
       // 2x2 LLT solve (:184); depth mode: the 1x1 system, L = sqrt(H)
-      const float y0 = B0 / L00;
+      float y0 = fdiv_fast(B0, iL00);
       float x0, x1;
-      if constexpr (DEPTH) { x0 = y0 / L00; x1 = 0.f; }
+      bool QOK;
+      if constexpr (DEPTH) { x0 = fdiv_fast(y0, iL00); x1 = 0.f; QOK = DEN_OK & fdiv_in_range(y0) & fdiv_in_range(x0); }
       else {
-        const float y1 = (B1 - L10 * y0) / L11;
-        x1 = y1 / L11;
-        x0 = (y0 - L10 * x1) / L00;
+        const float y1 = fdiv_fast(B1 - L10 * y0, iL11);
+        x1 = fdiv_fast(y1, iL11);
+        x0 = fdiv_fast(y0 - L10 * x1, iL00);
+        const float hi = fmaxf(fmaxf(fabsf(y0), fabsf(y1)), fmaxf(fabsf(x1), fabsf(x0)));
+        const float lo = fminf(fminf(fabsf(y0), fabsf(y1)), fminf(fabsf(x1), fabsf(x0)));
+        QOK = DEN_OK & (lo >= 0x1p-40f) & (hi <= 0x1p40f);       // (a NaN escapes fmaxf / fminf but ends in x0, which is tested below)
+      }
+      if (__builtin_amdgcn_ballot_w64(!QOK) != 0) {              // zero / tiny / huge / non-finite operands: the IEEE divisions (wave-uniform)
+        y0 = B0 / L00;
+        if constexpr (DEPTH) { x0 = y0 / L00; x1 = 0.f; }
+        else {
+          const float y1 = (B1 - L10 * y0) / L11;
+          x1 = y1 / L11;
+          x0 = (y0 - L10 * x1) / L00;
+        }
       }
       float nP0 = P0 - x0, nP1 = P1 - x1;                // :186
       if constexpr (DEPTH) {                             // :188-193 std::min / std::max with 0
