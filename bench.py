@@ -489,7 +489,7 @@ def main():
                 try:
                     res["roofline_dominant"] = roofline_dominant(ofc, lib, stream_ptr, a.batch, st)
                     res["rooflines"].append(res["roofline_dominant"])
-                except Exception as e:          # (levels of the opt-in resident pipeline have no stand-alone sor_coupled launch)
+                except Exception as e:          # (a configuration without a stand-alone sor_coupled launch at the finest level)
                     res["roofline_dominant"] = {"unavailable": str(e)}
                 res["rooflines"].append(roofline_fused_level(ofc, a.batch, st, op.finest_scale + 1))
             res["rooflines"].append(roofline_lk(ofc, a.batch, st))

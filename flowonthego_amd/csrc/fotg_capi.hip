@@ -14,7 +14,6 @@
 #include "lk.hip.h"
 #include "densify.hip.h"
 #include "varref.hip.h"
-#include "varref_resident.hip.h"
 #include "varref_tiles.hip.h"
 #include "varref_depth.hip.h"
 #include "upsample.hip.h"
@@ -64,7 +63,6 @@ struct FotgTune {
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
   int vr_fused_nt;  // FOTG_VR_FUSED_NT: threads per workgroup of the fused per-level kernel on gray levels of 1025..2048 pixels (512 / 1024)
-  int vr_resident;  // FOTG_VR_RESIDENT: 0 = launch-per-iteration refinement instead of the resident pipeline (varref_resident.hip.h)
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
@@ -109,11 +107,6 @@ struct fotg_ctx {
   float4 *vrC[FOTG_MAXLEV];          // skewed system per level (cells outside the image stay zero forever)
   float2 *vrD[FOTG_MAXLEV];          // skewed (du,dv) per level
   VrArgs vra[FOTG_MAXLEV];
-  // resident refinement pipeline (varref_resident.hip.h): skewed constant planes, ticket / progress words
-  int res_geo[FOTG_MAXLEV];          // 0: level not eligible; 1, 2: ring geometry (RD, RCW) = (72, 70), (100, 98)
-  int skew_used[FOTG_MAXLEV];        // the last fotg_varref of the level took the pipeline (fotg_varref_plane de-skews)
-  VrArgs vraq[FOTG_MAXLEV];          // the level's arguments with the planes in the skewed workspace
-  float *vrQ;
   // verbosity (the reference's op.verbosity, src/oflow.cpp:246-365 / kroeger/oflow.cpp:298-360): > 0 makes the flow calls
   // synchronous and prints the reference's timing lines from HIP-event times of the stages
   int verbosity;
@@ -124,37 +117,13 @@ struct fotg_ctx {
   long x_pair_stride[FOTG_MAXLEV];
   int x_rt[FOTG_MAXLEV];
   int *tileSync;
-  int *vrSync;
-  // a bounded inter-workgroup wait that gave up (tile / resident pipelines) sets this word of pinned host memory from the device;
+  // a bounded inter-workgroup wait that gave up (tile solver pipeline) sets this word of pinned host memory from the device;
   // fotg_calc, fotg_pipe_wait(host_wait) and fotg_pipe_sync read it after their synchronisation and return FOTG_ERR_STALL
   int *stall_host, *stall_dev;
   long stalls;                       // host-side count of the times the word was found set
-  void *vrZero;
   unsigned long long *stamps;        // -DFOTG_TILE_STATS builds only
   GridState gs[FOTG_MAXLEV];
 };
-
-// resident pipeline: float4 / float2 units between the arrays of consecutive inner iterations of a pair
-// (every array has exactly E rows -- the diagonals of a solver round -- so the arrays of a pair are one contiguous run of rows)
-static long res_c_it_stride(const VrArgs &a, int nsweeps) { return (long)res_geom(a.w, a.h, nsweeps).E * a.RP * 2; }
-static long res_d_it_stride(const VrArgs &a, int nsweeps) { return (long)res_geom(a.w, a.h, nsweeps).E * a.RPD; }
-// ring geometry of a level that takes the resident pipeline (0: not eligible): lexicographic order, 1..3 sweeps (one solver wave
-// each), 65..96 rows (two rows per lane of one solver wave, two direct loads per system plane and diagonal), enough diagonals for
-// the unrolled loop; 1, 2: (RD, RCW) = (72, 70), (100, 98)
-static int res_level_geo(const fotg_ctx *c, int l)
-{
-  const fotg_params *p = &c->p;
-  const VrArgs &a = c->vra[l];
-  if (c->noc != 1) return 0;                   // (gray only: the RGB data term does not fit the 128 registers of a 1024-thread workgroup)
-  if (p->depth || p->sor_mode != FOTG_SOR_LEXICOGRAPHIC || !c->tune.vr_resident || c->tune.vr_path != 0 || p->tv_solverit < 1 || p->tv_solverit > 3) return 0;
-  const int inner = p->tv_innerit * (l + 1);
-  if (inner < 1 || a.K != 2 || a.RP < 64 || (a.RPD & 1) || a.h + 2 > a.RPD || a.S < 64) return 0;
-  const ResGeom q = res_geom(a.w, a.h, p->tv_solverit);
-  if (q.nww < 1) return 0;
-  if (a.RP + 1 <= 70 && a.h + 2 <= 72 && res_lds_bytes<72, 70>(q) <= 160 * 1024) return 1;
-  if (a.RP + 1 <= 98 && a.h + 2 <= 100 && res_lds_bytes<100, 98>(q) <= 160 * 1024) return 2;
-  return 0;
-}
 
 static void fill_geom(const fotg_params &p, int Wp, int Hp, int l, LevelGeom &g)
 {
@@ -243,7 +212,7 @@ void fotg_destroy(fotg_ctx *c)
     (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]); (void)hipFree(c->vrX[l]);
   }
   if (c->stall_host) (void)hipHostFree(c->stall_host);
-  (void)hipFree(c->vr); (void)hipFree(c->vrQ); (void)hipFree(c->vrSync); (void)hipFree(c->vrZero); (void)hipFree(c->tileSync);
+  (void)hipFree(c->vr); (void)hipFree(c->tileSync);
   for (auto &e : c->tev) if (e) (void)hipEventDestroy(e);
   delete c;
 }
@@ -268,12 +237,6 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
   c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
   c->tune.vr_fused_nt = env_int("FOTG_VR_FUSED_NT", 1024);
-  // opt-in: measured at batch 64 it is no faster than the per-iteration launches (0.255 vs 0.249 ms at level 4) and, with several
-  // batches in flight, its polling workgroups hold whole CUs (120 k vs 168 k pairs/s) -- docs/EXPERIMENTS.md
-  c->tune.vr_resident = env_int("FOTG_VR_RESIDENT", 0);
-  if (hipHostMalloc((void **)&c->stall_host, 64, hipHostMallocMapped) != hipSuccess ||
-      hipHostGetDevicePointer((void **)&c->stall_dev, c->stall_host, 0) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; }
-  memset(c->stall_host, 0, 64);
   fotg_padded_size(w_org, h_org, p->sc_f, &c->Wp, &c->Hp, &c->padw, &c->padh);
   c->base_lv = p->sc_l < 4 ? p->sc_l : 4;
   const size_t B = (size_t)max_batch;
@@ -341,20 +304,11 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       a.c_pair_stride = (long)a.SC * a.RP * 2;
       a.d_pair_stride = (long)(a.S + 1) * a.RPD;
       if (p->depth) continue;
-      // resident pipeline (varref_resident.hip.h): one system array and one (du,dv) array PER INNER ITERATION (write once);
-      // the launch-per-iteration kernels of such a level use the first one
-      if (const int geo = res_level_geo(c, l)) {
-        const int inner = p->tv_innerit * (l + 1);
-        a.RPD = geo == 1 ? 72 : 100;                   // = the kernel's ring geometry RD: one pitch for planes, arrays, rings and slabs
-        a.c_pair_stride = (long)inner * res_c_it_stride(a, p->tv_solverit);
-        a.d_pair_stride = (long)(inner + 1) * res_d_it_stride(a, p->tv_solverit) + 2 * a.RPD;      // array 0: zeros; + the writer's spare rows
-      }                        // depth mode solves on plain planes of the workspace (varref_depth.hip.h)
       // + slack: idle lanes of the solver read K cells past the row they are parked on, i.e. past the last pair's
       // last (spare) row
       const size_t cbytes = B * a.c_pair_stride * sizeof(float4) + 64 * 16 * 2 * sizeof(float4);
       ALLOC(c->vrC[l], cbytes);
       ALLOC(c->vrD[l], B * a.d_pair_stride * sizeof(float2) + 4096);
-      if (res_level_geo(c, l) && hipMemset(c->vrD[l], 0, B * a.d_pair_stride * sizeof(float2) + 4096) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       if (hipMemset(c->vrC[l], 0, cbytes) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       a.C = c->vrC[l]; a.D = c->vrD[l];
       // tall levels (beyond the LDS solvers' 96 rows): per-sweep arrays of the tile pipeline, zero outside the image for good
@@ -372,31 +326,6 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
         if (!c->tileSync) {
           ALLOC(c->tileSync, (tile_sync_words((int)B) + 32) * sizeof(int));
           if (hipMemset(c->tileSync, 0, (tile_sync_words((int)B) + 32) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
-        }
-      }
-    }
-    // Levels that take the resident pipeline (res_level_geo): skewed constant planes, ticket / progress words
-    {
-      long qmax = 0;
-      for (int l = p->sc_l; l <= p->sc_f; ++l) {
-        const VrArgs &a = c->vra[l];
-        c->res_geo[l] = res_level_geo(c, l);
-        if (!c->res_geo[l]) continue;
-        const long pl = (long)(a.S + 1) * a.RPD;
-        const long need = pl * (P_NSINGLE + C_NCOLOR * c->noc + FOTG_VR_NEXTRA) + 1024;
-        if (need > qmax) qmax = need;
-      }
-      if (qmax) {
-        ALLOC(c->vrQ, B * qmax * sizeof(float));
-        ALLOC(c->vrZero, 4096);
-        if (hipMemset(c->vrZero, 0, 4096) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
-        ALLOC(c->vrSync, res_sync_words((int)B) * sizeof(int));
-        if (hipMemset(c->vrSync, 0, res_sync_words((int)B) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
-        for (int l = p->sc_l; l <= p->sc_f; ++l) {
-          if (!c->res_geo[l]) continue;
-          VrArgs &aq = c->vraq[l];
-          aq = c->vra[l];
-          aq.skew = 1; aq.base = c->vrQ; aq.pair_stride = qmax; aq.pl = (long)(aq.S + 1) * aq.RPD;
         }
       }
     }
@@ -750,7 +679,6 @@ static bool launch_sor_pipe(int n, float omega, hipStream_t s, const VrArgs &b)
   return true;
 }
 
-static std::atomic<long> g_res_launches{0};         // fotg_debug_counter("vr_resident")
 static std::atomic<long> g_tile_launches{0};        // fotg_debug_counter("sor_tiles")
 #ifndef FOTG_TILE_P
 #define FOTG_TILE_P 8                    // prefetch depth (diagonals) of the tile solver
@@ -912,40 +840,6 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   const float half_gamma_over3 = c->p.tv_gamma * 0.5f / 3.0f;
   const float half_delta_over3 = c->p.tv_delta * 0.5f / 3.0f;
   const int inner = c->p.tv_innerit * (l + 1);
-  if constexpr (NOC == 1)
-  if (c->res_geo[l] && c->tune.vr_path == 0) {
-    // resident pipeline: set-up launch into the skewed planes (it also zeroes the ticket / progress words), then ONE launch of
-    // (1 + NDW) n workgroups: per pair a solver workgroup that stays resident over the inner iterations and NDW data workgroups
-    c->skew_used[l] = 1;
-    VrArgs aq = c->vraq[l];
-    aq.taps = c->taps ? 1 : 0;
-    aq.nsweeps = c->p.tv_solverit;
-    int *sync = c->vrSync;
-    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(aq, I0, I1, img_stride, g.tw, c->ps, flow, fs, 2, sync, res_sync_words(n));
-    LAUNCHCHK();
-    const ResGeom q = res_geom(g.w, g.h, c->p.tv_solverit);
-    ResArgs ra;
-    ra.inner = inner; ra.npairs = n; ra.nww = q.nww; ra.c_it_stride = res_c_it_stride(aq, c->p.tv_solverit); ra.d_it_stride = res_d_it_stride(aq, c->p.tv_solverit); ra.qa = quarter_alpha; ra.hd = half_delta_over3; ra.hg = half_gamma_over3; ra.omega = c->p.tv_sor;
-    ra.flow = flow; ra.flow_stride = fs; ra.zero = c->vrZero; ra.sync = sync; ra.stall_flag = c->stall_dev;
-    ra.stats = nullptr;
-#ifdef FOTG_RES_STATS
-    if (!c->stamps) { if (hipMalloc((void **)&c->stamps, 4 * 16 * 4 * 8) != hipSuccess) return FOTG_ERR_HIP; }
-    (void)hipMemsetAsync(c->stamps, 0, 4 * 16 * 4 * 8, s);
-    ra.stats = (long long *)c->stamps;
-#endif
-    static int lds_set[2][32];
-#define RESIDENT(GEO, RD_, RCW_) \
-    { const int lds = res_lds_bytes<RD_, RCW_>(q); \
-      if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_resident_kernel<NOC, RD_, RCW_>), lds, lds_set[GEO - 1])) return FOTG_ERR_HIP; \
-      vr_resident_kernel<NOC, RD_, RCW_><<<(1 + FOTG_RES_NDW) * n, 1024, lds, s>>>(aq, ra); }
-    if (c->res_geo[l] == 1) RESIDENT(1, 72, 70)
-    else RESIDENT(2, 100, 98)
-#undef RESIDENT
-    ++g_res_launches;
-    LAUNCHCHK();
-    return FOTG_OK;
-  }
-  c->skew_used[l] = 0;
   // small levels: the whole level (set-up stages, fixed-point loop, final w + d) in one launch, one workgroup per pair
   if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && c->tune.vr_path == 0 &&
       dispatch_inner_fused<NOC>(c, a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s,
@@ -1082,7 +976,7 @@ extern "C" {
 int fotg_bench_sor_call(fotg_ctx *c, int l, int n, void *stream)
 {
   int st = check_level(c, l, n); if (st) return st;
-  if (!c->vr || c->p.depth || !c->vrC[l] || c->p.tv_solverit < 1 || c->res_geo[l]) return FOTG_ERR_UNSUPPORTED;   // (resident levels: (du,dv) array 0 must stay zero)
+  if (!c->vr || c->p.depth || !c->vrC[l] || c->p.tv_solverit < 1) return FOTG_ERR_UNSUPPORTED;
   ON_DEVICE(c->device);
   dispatch_sor(c, c->vra[l], n, c->p.tv_solverit, c->p.tv_sor, (hipStream_t)stream);
   LAUNCHCHK();
@@ -1123,24 +1017,6 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
         return FOTG_OK;
       }
   }
-  if (c->skew_used[l]) {
-    // the level took the resident pipeline: its planes live in the skewed workspace (pixel (i,j) at [(i+j) * RPD + j]); de-skew on the host
-    const VrArgs &aq = c->vraq[l];
-    int first = -1, cnt = 1;
-    for (int i = 0; i < P_NSINGLE; ++i) if (!strcmp(name, singles[i])) first = i;
-    for (int i = 0; i < C_NCOLOR; ++i) if (!strcmp(name, colors[i])) { first = P_NSINGLE + i * c->noc; cnt = c->noc; }
-    if (first >= 0) {
-      float *tmp = (float *)malloc((size_t)aq.pl * cnt * sizeof(float));
-      if (!tmp) return FOTG_ERR_ARG;
-      hipError_t e = hipMemcpy(tmp, aq.base + (size_t)pair * aq.pair_stride + (size_t)first * aq.pl, (size_t)aq.pl * cnt * sizeof(float), hipMemcpyDeviceToHost);
-      if (e != hipSuccess) { free(tmp); g_last_hip = (int)e; return FOTG_ERR_HIP; }
-      memset(host_out, 0, pl * cnt * 4);
-      for (int ch = 0; ch < cnt; ++ch)
-        for (int j = 0; j < g.h; ++j) for (int i = 0; i < g.w; ++i) host_out[(size_t)ch * pl + (size_t)j * g.st + i] = tmp[(size_t)ch * aq.pl + aq.pix(i, j)];
-      free(tmp);
-      return FOTG_OK;
-    }
-  }
   for (int i = 0; i < P_NSINGLE; ++i)
     if (!strcmp(name, singles[i])) {
       HIPCHK(hipMemcpy(host_out, c->vr + (size_t)pair * c->vr_pair_stride + i * pl, pl * 4, hipMemcpyDeviceToHost));
@@ -1156,12 +1032,9 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
   // planes that live in the skewed solver arrays: copy and de-skew on the host
   for (int k = 0; k < 8; ++k)
     if (!strcmp(name, sys[k])) {
-      // (a level of the resident pipeline has one array per inner iteration: the last system is in the last one)
-      const size_t c_len = c->res_geo[l] ? (size_t)res_c_it_stride(a, c->p.tv_solverit) : (size_t)a.c_pair_stride;
-      const size_t c_off = c->skew_used[l] ? (size_t)(c->p.tv_innerit * (l + 1) - 1) * c_len : 0;
-      float *tmp = (float *)malloc(c_len * sizeof(float4));
+      float *tmp = (float *)malloc((size_t)a.c_pair_stride * sizeof(float4));
       if (!tmp) return FOTG_ERR_ARG;
-      hipError_t e = hipMemcpy(tmp, a.C + (size_t)pair * a.c_pair_stride + c_off, c_len * sizeof(float4), hipMemcpyDeviceToHost);
+      hipError_t e = hipMemcpy(tmp, a.C + (size_t)pair * a.c_pair_stride, (size_t)a.c_pair_stride * sizeof(float4), hipMemcpyDeviceToHost);
       if (e != hipSuccess) { free(tmp); g_last_hip = (int)e; return FOTG_ERR_HIP; }
       memset(host_out, 0, pl * 4);
       for (int j = 0; j < g.h; ++j) for (int i = 0; i < g.w; ++i) host_out[(size_t)j * g.st + i] = tmp[a.cidx(i, j) * 4 + k];
@@ -1169,12 +1042,9 @@ int fotg_varref_plane(fotg_ctx *c, int pair, const char *name, int l, float *hos
       return FOTG_OK;
     }
   if (!strcmp(name, "du") || !strcmp(name, "dv")) {
-    // (resident pipeline: array 0 is the zero state, iteration it writes array it + 1)
-    const size_t d_len = c->res_geo[l] ? (size_t)res_d_it_stride(a, c->p.tv_solverit) : (size_t)a.d_pair_stride;
-    const size_t d_off = c->skew_used[l] ? (size_t)(c->p.tv_innerit * (l + 1)) * d_len : 0;
-    float *tmp = (float *)malloc(d_len * sizeof(float2));
+    float *tmp = (float *)malloc((size_t)a.d_pair_stride * sizeof(float2));
     if (!tmp) return FOTG_ERR_ARG;
-    hipError_t e = hipMemcpy(tmp, a.D + (size_t)pair * a.d_pair_stride + d_off, d_len * sizeof(float2), hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpy(tmp, a.D + (size_t)pair * a.d_pair_stride, (size_t)a.d_pair_stride * sizeof(float2), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { free(tmp); g_last_hip = (int)e; return FOTG_ERR_HIP; }
     memset(host_out, 0, pl * 4);
     const int comp = name[1] == 'v';
@@ -1469,7 +1339,6 @@ int fotg_calc_sequence_u8(fotg_ctx *c, int n_frames, const unsigned char *frames
 long fotg_debug_counter(const char *name)
 {
   if (name && !strcmp(name, "sor_stream")) return g_stream_launches;
-  if (name && !strcmp(name, "vr_resident")) return g_res_launches;
   if (name && !strcmp(name, "sor_tiles")) return g_tile_launches;
   return -1;
 }
@@ -1528,15 +1397,6 @@ long fotg_ctx_counter(fotg_ctx *c, const char *name)
       tot += v;
     }
     return tot;
-  }
-  if (!strcmp(name, "vr_res_timeouts")) {
-    // bounded waits of the resident pipeline that gave up since the context was created (0 unless something is broken)
-    if (!c->vrSync) return 0;
-    DevGuard dg(c->device);
-    int v = 0;
-    if (!dg.ok || hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpy(&v, c->vrSync + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return v;
   }
   return -1;
 }

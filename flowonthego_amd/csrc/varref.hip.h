@@ -22,7 +22,6 @@ namespace fotg {
 
 enum VrPlane { P_WX = 0, P_WY, P_MASK, P_NSINGLE };
 enum VrCPlane { C_AVG = 0, C_IZ, C_IX, C_IY, C_IXX, C_IXY, C_IYY, C_IXZ, C_IYZ, C_NCOLOR };
-#define FOTG_VR_NEXTRA 10
 
 // Skewed (anti-diagonal major) arrays used by the solver: cell (i,j) of the image lives at [i+j][j].
 //   C[s][r] = {a11, a12 (2x2 block inverse), b1, b2 | a22, psi_right, psi_bottom, psi_top}   8 floats
@@ -42,9 +41,7 @@ struct VrArgs {
   long c_pair_stride;    // in float4
   long d_pair_stride;    // in float2
   int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows, band_mode, taps;
-  int skew;              // 1: the planes are stored skewed like D (pixel (i,j) at [(i+j) * RPD + j], pl = (S+1) * RPD floats): the
-                         // resident refinement pipeline (varref_resident.hip.h) reads them along anti-diagonals, coalesced
-  __host__ __device__ int pix(int i, int j) const { return skew ? (i + j) * RPD + j : j * st + i; }
+  __host__ __device__ int pix(int i, int j) const { return j * st + i; }
   __host__ __device__ float4 *Cp(int pair) const { return C + (size_t)pair * c_pair_stride; }
   __host__ __device__ float2 *Dp(int pair) const { return D + (size_t)pair * d_pair_stride; }
   __host__ __device__ size_t cidx(int i, int j) const { return ((size_t)(i + j) * RP + j) * 2; }
@@ -52,11 +49,6 @@ struct VrArgs {
   __host__ __device__ float *single(int pair, int p) const { return base + (size_t)pair * pair_stride + (size_t)p * pl; }
   __host__ __device__ float *color(int pair, int p, int c) const {
     return base + (size_t)pair * pair_stride + (size_t)(P_NSINGLE + p * noc + c) * pl;
-  }
-  // skewed workspace only: FOTG_VR_NEXTRA planes behind the colour planes -- 0..3 the wx differences sub_laplacian forms
-  // (centre-left, right-centre, centre-top, bottom-centre), 4..7 the same of wy, 8..9 (wx,wy) interleaved as float2
-  __host__ __device__ float *extra(int pair, int k) const {
-    return base + (size_t)pair * pair_stride + (size_t)(P_NSINGLE + C_NCOLOR * noc + k) * pl;
   }
 };
 
@@ -198,8 +190,7 @@ __global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
 template <int NOC, int NCH = 2>
 __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__restrict__ I0, const float *__restrict__ I1,
                                                        long img_stride, int tw, int pad,
-                                                       const float *__restrict__ flow, long flow_stride, int zero_d = 0,
-                                                       int *__restrict__ zero_words = nullptr, long zero_n = 0)
+                                                       const float *__restrict__ flow, long flow_stride, int zero_d = 0)
 {
   constexpr int TW_ = 32, TH_ = 8, XW = TW_ + 8, XH = TH_ + 8, YW = TW_ + 4, YH = TH_ + 4;
   __shared__ float Xa[NOC][XH * XW], Xz[NOC][XH * XW], Yx[NOC][YH * YW], Yy[NOC][YH * YW];
@@ -210,11 +201,6 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
     // image_erase(du), image_erase(dv) (refine_variational.cpp:185-186): the pair's tiles share the zeroing of its skewed D
     float2 *D = a.Dp(pair);
     for (long k = (long)wg.x * 256 + threadIdx.x; k < a.d_pair_stride; k += (long)gridDim.x * 256) D[k] = make_float2(0.f, 0.f);
-  }
-  if (zero_d == 2 && zero_words) {
-    // resident refinement pipeline: the ticket counter and the progress words of the launch that follows
-    for (long k = ((long)wg.y * gridDim.x + wg.x) * 256 + threadIdx.x; k < zero_n; k += (long)gridDim.x * gridDim.y * 256)
-      if (k != 1) zero_words[k] = 0;                              // word 1 counts timed-out waits over the life of the context
   }
   const int tx0 = (wg.x % tiles_x) * TW_, ty0 = (wg.x / tiles_x) * TH_;
   // stage A: warp + mask + average / difference at the clamped coordinate of every tile+4 position
@@ -251,16 +237,6 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
   const int i = tx0 + (threadIdx.x % TW_), j = ty0 + (threadIdx.x / TW_);
   if (i < w && j < h) {
     const int o = a.pix(i, j);
-    if (a.skew && NCH == 2) {
-      // resident pipeline: (wx,wy) interleaved, and the differences of wx, wy that sub_laplacian forms (opticalflow_aux.c:172-199;
-      // neighbours outside the image: the term is skipped there, any finite value will do)
-      const float2 *f = reinterpret_cast<const float2 *>(flow + (size_t)pair * flow_stride);
-      const int q = j * w + i;
-      const float2 fc = f[q], fl = f[i > 0 ? q - 1 : q], fr = f[i < w - 1 ? q + 1 : q], ft = f[j > 0 ? q - w : q], fb = f[j < h - 1 ? q + w : q];
-      a.extra(pair, 0)[o] = fc.x - fl.x; a.extra(pair, 1)[o] = fr.x - fc.x; a.extra(pair, 2)[o] = fc.x - ft.x; a.extra(pair, 3)[o] = fb.x - fc.x;
-      a.extra(pair, 4)[o] = fc.y - fl.y; a.extra(pair, 5)[o] = fr.y - fc.y; a.extra(pair, 6)[o] = fc.y - ft.y; a.extra(pair, 7)[o] = fb.y - fc.y;
-      reinterpret_cast<float2 *>(a.extra(pair, 8))[o] = fc;
-    }
 #pragma unroll
     for (int c = 0; c < NOC; ++c) {
       const float *xrow = Yx[c] + (j - ty0 + 2) * YW - tx0 + 2, *xcol = Yx[c] + (2 - ty0) * YW + i - tx0 + 2, *ycol = Yy[c] + (2 - ty0) * YW + i - tx0 + 2;
@@ -300,22 +276,6 @@ struct PixIn {
   __device__ __forceinline__ float dyt() const { return wyc - wyt; }
   __device__ __forceinline__ float dyb() const { return wyb - wyc; }
 };
-// the same with the eight differences precomputed (constant over the inner iterations): the stage pipeline's set-up launch
-// stores them as planes (same subtraction, same bits)
-template <int NOC>
-struct PixDiff {
-  float Ix[NOC], Iy[NOC], Iz[NOC], Ixx[NOC], Ixy[NOC], Iyy[NOC], Ixz[NOC], Iyz[NOC];
-  float m, d[8];
-  __device__ __forceinline__ float dxl() const { return d[0]; }
-  __device__ __forceinline__ float dxr() const { return d[1]; }
-  __device__ __forceinline__ float dxt() const { return d[2]; }
-  __device__ __forceinline__ float dxb() const { return d[3]; }
-  __device__ __forceinline__ float dyl() const { return d[4]; }
-  __device__ __forceinline__ float dyr() const { return d[5]; }
-  __device__ __forceinline__ float dyt() const { return d[6]; }
-  __device__ __forceinline__ float dyb() const { return d[7]; }
-};
-
 template <int NOC>
 __device__ __forceinline__ PixIn<NOC> data_load(const VrArgs &a, int pair, int i, int j)
 {
@@ -337,14 +297,9 @@ __device__ __forceinline__ PixIn<NOC> data_load(const VrArgs &a, int pair, int i
 
 // compute_data (:310-438) + sub_laplacian (:172-199) + the 2x2 block inverse of sor_coupled's first sweep
 // (solver.c:115-120) for pixel (i,j), given the four smoothness pair sums and (du,dv); writes the skewed system cell.
-struct NoMid { __device__ __forceinline__ void operator()(float &, float &, float &, float &, float &) const {} };
-
-// `mid` is called between the colour-constancy term and the gradient-constancy term with the five accumulators (the stage
-// pipeline puts a workgroup barrier there: about half of a cell's arithmetic on either side)
-template <int NOC, typename Mid = NoMid, typename PIN = PixIn<NOC>>
-__device__ __forceinline__ void data_term_cell(const VrArgs &a, int i, int j, const PIN &p, float hr, float hl, float vb, float vt,
-                                               float u, float v, float half_delta_over3, float half_gamma_over3, float4 &c0, float4 &c1,
-                                               const Mid &mid = Mid())
+template <int NOC>
+__device__ __forceinline__ void data_term_cell(const VrArgs &a, int i, int j, const PixIn<NOC> &p, float hr, float hl, float vb, float vt,
+                                               float u, float v, float half_delta_over3, float half_gamma_over3, float4 &c0, float4 &c1)
 {
   const int w = a.w, h = a.h;
   // compute_data (:310-438)
@@ -365,7 +320,6 @@ __device__ __forceinline__ void data_term_cell(const VrArgs &a, int i, int j, co
       B1 -= tmp * Iz * Ix;
       B2 -= tmp * Iz * Iy;
     }
-    mid(A11, A12, A22, B1, B2);
     n1 = Ixx * Ixx + Ixy * Ixy + dnorm;
     n2 = Iyy * Iyy + Ixy * Ixy + dnorm;
     tmp = Ixz + Ixx * u + Ixy * v;
@@ -398,7 +352,6 @@ __device__ __forceinline__ void data_term_cell(const VrArgs &a, int i, int j, co
         B1 -= k[c] * iz[c] * ix[c];  B2 -= k[c] * iz[c] * iy[c];
       }
     }
-    mid(A11, A12, A22, B1, B2);
     float n1[3], n2[3], t1[3], t2[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

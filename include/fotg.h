@@ -25,7 +25,7 @@ extern "C" {
 #define FOTG_ERR_HIP          2   /* a HIP runtime call failed (fotg_last_hip_error()) */
 #define FOTG_ERR_BATCH        3   /* n > max_batch */
 #define FOTG_ERR_UNSUPPORTED  4   /* valid in the reference but not implemented here */
-#define FOTG_ERR_STALL        5   /* a bounded wait between workgroups of a pipelined refinement kernel timed out (preempted or
+#define FOTG_ERR_STALL        5   /* a bounded wait between workgroups of the tile solver (levels of more than 96 rows) timed out (preempted or
                                      starved producer): the flow this call produced is NOT valid.  Returned by the entry points that
                                      synchronise with the host -- fotg_calc, fotg_pipe_wait(host_wait = 1), fotg_pipe_sync; callers of
                                      the asynchronous entry points ask fotg_ctx_counter(ctx, "stalls") after their own synchronisation
@@ -195,12 +195,12 @@ int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, floa
 /* measurement tap: ONE sor_coupled call (the launch the refinement issues once per inner iteration) of `level` for n pairs on the
  * system the last fotg_varref left in the workspace; bench.py times it for the roofline of the time-dominant kernel */
 int fotg_bench_sor_call(fotg_ctx *ctx, int level, int n, void *stream);
-/* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_tiles", "vr_resident"); -1 for unknown names */
+/* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_tiles"); -1 for unknown names */
 long fotg_debug_counter(const char *name);
 /* per-context counters.  "stalls" (does NOT synchronise): how many times a bounded inter-workgroup wait of this context timed out,
  * as far as the host has seen (FOTG_ERR_STALL above); "inject_stall" (tests) raises the flag as a timed-out wait would.
- * Test taps that synchronise the device: "tile_timeouts" / "vr_res_timeouts" = device-side counts of those time-outs of the tile
- * solver / of the resident refinement pipeline since the context was created -- 0 unless something is broken; -1 for unknown names */
+ * Test tap that synchronises the device: "tile_timeouts" = device-side count of those time-outs of the tile solver since the
+ * context was created -- 0 unless something is broken; -1 for unknown names */
 long fotg_ctx_counter(fotg_ctx *ctx, const char *name);
 const char *fotg_strerror(int status);
 int fotg_last_hip_error(void);

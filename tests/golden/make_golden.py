@@ -11,8 +11,8 @@ plain data and travel to the GPU box.
   fdf_ref_rgb.npz       variational-refinement chain (kroeger/refine_variational.cpp:153-241):
                         every intermediate plane of the last inner iteration + the refined flow
   fdf_ref_l4_*.npz      the same chain on a 120 x 68 level (1080p level 4: images/road_HD.jpg and a shifted copy, padded to 1088 rows
-                        and halved four times; five inner iterations) -- the size class the engine's resident refinement pipeline
-                        (65..96 rows) handles
+                        and halved four times; five inner iterations) -- the size class of the engine's streaming solver
+                        (65..96 rows)
   fdf_ref_depth_*.npz   the same inputs through the reference's stereo-depth chain (RefLevelDE, :243-330)
   natural_images.npz    the reference's natural test images as 8-bit gray (same formula): images/road_HD.jpg (1920x1080) and
                         images/yosemite_4k.jpg (3840x2160) -- the inputs SURVEY.md 8(d) names for C2-C4 (the second frame of

@@ -133,17 +133,13 @@ def test_patchgrid_stages_parity(case, op_point, alley):
         prev_o = fo
 
 
-@pytest.mark.parametrize("resident", ["1", "0"])
 @pytest.mark.parametrize("noc", [1, 3])
-def test_varref_golden_reference_vectors(noc, resident, monkeypatch):
-    """VarRefClass against outputs of the reference's own FDF1.0.1 code (tests/golden/fdf_ref_*.npz): every
+def test_varref_golden_reference_vectors(noc):
+    """VarRefClass against outputs of the reference's own FDF1.0.1 code (tests/golden/fdf_ref_*.npz, fdf_ref_l4_*.npz): every
     intermediate plane of the last inner iteration and the refined flow, bit for bit -- the small levels through the fused
-    per-level kernel, the 120 x 68 level through the resident pipeline (default: planes live skewed, the system of the last
-    iteration comes from the data workgroups, (du,dv) from the solver's writer) and through the per-iteration launches
-    (FOTG_VR_RESIDENT=0)"""
+    per-level kernel, the 120 x 68 level (1080p level 4, five inner iterations) through the set-up / data / streaming-solver
+    launches"""
     F, OFClass, VarRefClass, O = _mods()
-    monkeypatch.setenv("FOTG_VR_RESIDENT", resident)
-    before = F.lib().fotg_debug_counter(b"vr_resident")
     for name, c in load_fdf(noc).items():
         im1, im2, wx, wy, lvl = c["im1"], c["im2"], c["wx"], c["wy"], int(c["lvl"])
         _, h, w = im1.shape
@@ -170,8 +166,6 @@ def test_varref_golden_reference_vectors(noc, resident, monkeypatch):
         for nm in ("Ix", "Iy", "Iz", "Ixx", "Ixy", "Iyy", "Ixz", "Iyz"):
             assert np.array_equal(plane(nm, noc), c[nm]), (name, nm)
         assert np.array_equal(out[..., 0], c["out_x"]) and np.array_equal(out[..., 1], c["out_y"]), name
-        assert F.lib().fotg_ctx_counter(ofc._h, b"vr_res_timeouts") == 0
-    assert (F.lib().fotg_debug_counter(b"vr_resident") > before) == (resident == "1" and noc == 1)     # (the pipeline is gray only)
 
 
 @pytest.mark.parametrize("case,op_point,sor_mode", [("alley", 2, 0), ("alley", 2, 1), ("alley_rgb", 2, 0),
@@ -235,64 +229,6 @@ def test_switches_are_read_at_creation_and_debug_switches_are_compiled_out(alley
     monkeypatch.setenv("FOTG_VR_STREAM", "0")             # too late for this context
     ofc.calc(dev(f0), dev(f1))
     assert F.lib().fotg_debug_counter(b"sor_stream") > before
-
-
-def test_resident_pipeline(alley, monkeypatch):
-    """the resident refinement pipeline (opt-in: FOTG_VR_RESIDENT=1) (varref_resident.hip.h: per pair a solver workgroup that stays resident over the inner
-    iterations + data workgroups on other CUs, handing (du,dv) and the system over through memory) against the oracle: both
-    ring geometries (levels of <= 69 and <= 97 rows), odd row counts, 1 / 2 / 3 sweeps, one inner iteration (no hand-over
-    at all) and several.  No wait may have timed out."""
-    F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_VR_RESIDENT", "1")
-    L = F.lib()
-    before = L.fotg_debug_counter(b"vr_resident")
-    # (size, width the operating point is derived from, channels, sweeps, pairs)
-    cases = [((1920, 1080), 1920, 1, 3, 2), ((1600, 1200), 1920, 1, 3, 1), ((1904, 1064), 1920, 1, 3, 1), ((1280, 1050), 1920, 1, 3, 1),
-             ((1920, 1080), 1920, 1, 2, 1), ((1920, 1080), 1920, 1, 1, 1), ((1264, 1500), 1920, 1, 3, 1)]
-    for (w, h), wop, noc, sweeps, n in cases:
-        pairs = [synth_pair(h, w, seed=31 + k, noc=noc) for k in range(n)]
-        op = F.operating_point(2, wop, noc)
-        op.var_ref_iter = sweeps
-        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=n)
-        out = ofc.calc_batch(dev(np.stack([p[0] for p in pairs])), dev(np.stack([p[1] for p in pairs]))).cpu().numpy()
-        p = oracle_params(O, op)
-        for k in range(n):
-            ref = O.flow(O.pad_frame(pairs[k][0], p.sc_f), O.pad_frame(pairs[k][1], p.sc_f), p, 0)
-            assert np.array_equal(out[k], ref), ((w, h), noc, sweeps, k, float(np.abs(out[k] - ref).max()))
-        assert L.fotg_ctx_counter(ofc._h, b"vr_res_timeouts") == 0
-        ofc.close()
-    assert L.fotg_debug_counter(b"vr_resident") >= before + len(cases)
-    # a level of 65..96 rows with ONE inner iteration: a single-scale operating point at scale 0 on a small image
-    f0, f1 = synth_pair(70, 160, seed=3)
-    op = F.operating_point(2, 160, 1)
-    op.coarsest_scale = op.finest_scale = 0
-    ofc = OFClass(op, F.img_params(width=160, height=70, padding=8))
-    p = oracle_params(O, op)
-    before = L.fotg_debug_counter(b"vr_resident")
-    assert np.array_equal(ofc.calc(dev(f0), dev(f1)).cpu().numpy(), O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0))
-    assert L.fotg_debug_counter(b"vr_resident") == before + 1 and L.fotg_ctx_counter(ofc._h, b"vr_res_timeouts") == 0
-
-
-def test_resident_pipeline_more_workgroups_than_cus(monkeypatch):
-    """80 pairs x 4 workgroups of one per CU on 256 CUs: the late tickets start when the early pairs exit (a pair's workgroups
-    hold consecutive tickets, so at most one pair is ever partly started); every pair still equals its single-pair result (and
-    pairs 0, 1 the oracle)"""
-    F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_VR_RESIDENT", "1")
-    before = F.lib().fotg_debug_counter(b"vr_resident")
-    n = 80
-    f0, f1 = synth_pair(1080, 1920, seed=77)
-    I0 = dev(f0)[None].repeat(n, 1, 1).contiguous(); I1 = dev(f1)[None].repeat(n, 1, 1).contiguous()
-    I0[1::2] = dev(f1); I1[1::2] = dev(f0)
-    op = F.operating_point(2, 1920, 1)
-    ofc = OFClass(op, F.img_params(width=1920, height=1080, padding=8), max_batch=n)
-    out = ofc.calc_batch(I0, I1)
-    assert torch.equal(out[0::2], out[0:1].expand(n // 2, -1, -1, -1)) and torch.equal(out[1::2], out[1:2].expand(n // 2, -1, -1, -1))
-    p = oracle_params(O, op)
-    assert np.array_equal(out[0].cpu().numpy(), O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0))
-    assert np.array_equal(out[1].cpu().numpy(), O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0))
-    assert F.lib().fotg_ctx_counter(ofc._h, b"vr_res_timeouts") == 0
-    assert F.lib().fotg_debug_counter(b"vr_resident") > before
 
 
 @pytest.mark.parametrize("mode", ["0", "1"])

@@ -185,7 +185,7 @@ def test_launch_path_reads_no_environment():
     src = open(os.path.join(ROOT, "flowonthego_amd", "csrc", "fotg_capi.hip")).read()
     body = re.sub(r"#ifdef FOTG_DEBUG.*?#endif", "", src, flags=re.S)
     assert body.count("getenv(") == 1 and "static int env_int" in body
-    for hdr in ("varref.hip.h", "varref_tiles.hip.h", "varref_resident.hip.h", "lk.hip.h", "pyramid.hip.h", "densify.hip.h", "varref_depth.hip.h", "common.h"):
+    for hdr in ("varref.hip.h", "varref_tiles.hip.h", "lk.hip.h", "pyramid.hip.h", "densify.hip.h", "varref_depth.hip.h", "common.h"):
         assert "getenv" not in open(os.path.join(ROOT, "flowonthego_amd", "csrc", hdr)).read()
     mk = [l for l in open(os.path.join(ROOT, "flowonthego_amd", "csrc", "Makefile")).read().splitlines() if not l.lstrip().startswith("#")]
     assert not any("FOTG_DEBUG" in l for l in mk)
