@@ -190,7 +190,7 @@ def roofline_fused_level(ofc, batch, stage_ms, lvl):
     try:
         with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             k = json.load(f)["kernels"]
-        key = [x for x in k if "vr_inner_fused_kernel" in x]
+        key = [x for x in k if "vr_inner_fused_kernel" in x and ("1024>" in x) == (lw * lh > 1024)]     # (levels of > 1024 px run on 1024 threads)
         if key and batch == 64:
             traffic = k[key[0]]["hbm_bytes_per_launch_corrected"]
     except Exception:
@@ -198,7 +198,7 @@ def roofline_fused_level(ofc, batch, stage_ms, lvl):
     gbs = alg / (ms * 1e-3) / 1e9
     inner = lvl + 1
     return {"bound": "hbm", "bound_note": "nearest roof the contract names; the kernel is bound by the solver's dependency chain and the VALU of ONE CU per pair",
-            "kernel": "fotg::vr_inner_fused_kernel<1,8,32,true,true> (level %d, %dx%d: set-up + %d x {data term, 3 sweeps} + w+d in one launch, one workgroup per pair)" % (lvl, lw, lh, inner),
+            "kernel": "fotg::vr_inner_fused_kernel<1,8,32,true,true,%d> (level %d, %dx%d: set-up + %d x {data term, 3 sweeps} + w+d in one launch, one workgroup per pair)" % (1024 if lw * lh > 1024 else 512, lvl, lw, lh, inner),
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_NOTE,
             "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_per_step": 1, "share_of_step": ms / sum(stage_ms.values())}
 
