@@ -268,8 +268,7 @@ def test_tile_solver_pipeline():
         f0, f1 = synth_pair(h, w, seed=4)
         op = F.operating_point(op_point, width_for_op, 1)
         op.var_ref_iter = sweeps
-        if op_point == 4:
-            op.grad_descent_iter = 8                           # keep the oracle quick; the solver is what is under test
+        op.grad_descent_iter = 8                               # keep the oracle quick; the solver is what is under test
         ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
         out = ofc.calc_batch(dev(np.stack([f0, f1])), dev(np.stack([f1, f0]))).cpu().numpy()
         p = oracle_params(O, op)
@@ -403,12 +402,14 @@ def test_lk_partial_waves(alley):
 
 
 def test_4k_quality_preset(monkeypatch):
-    """BASELINE configs[3]: 3840x2160, op-pt 4 (ps=12, stride 3, scales 7..2 = 6 levels, 128 LK iterations, refinement
-    on a 960x544 finest level whose (du,dv) do not fit LDS -> K=12 rows per lane global-memory solver)"""
+    """3840x2160 synthetic pair at op-pt 4's geometry (ps=12, stride 3, scales 7..2 = 6 levels, refinement on a 960x544 finest level:
+    9 bands of the tile pipeline) with 16 instead of 128 LK iterations (the full preset runs on its named input in
+    test_natural_image_4k_quality_preset; the CPU oracle needs ~10 s for it)"""
     F, OFClass, _, O = _mods()
     f0, f1 = synth_pair(2160, 3840, seed=99)
     op = F.operating_point(4, 3840, 1)
-    assert (op.coarsest_scale, op.finest_scale) == (7, 2)
+    assert (op.coarsest_scale, op.finest_scale, op.grad_descent_iter) == (7, 2, 128)
+    op.grad_descent_iter = 16
     ofc = OFClass(op, F.img_params(width=3840, height=2160, padding=12))
     got = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
     assert got.shape == (544, 960, 2)
