@@ -753,6 +753,21 @@ def test_bench_distributed_leg_on_one_gpu():
     assert sg["gathered_shape"] == [16, 68, 120, 2] and sg["end_to_end_pairs_per_s"] > 0
 
 
+def test_hoisted_division_is_the_ieee_division(tmp_path):
+    """csrc/fdiv_hoist.h (the LK solve's divisions by the loop-invariant Cholesky factors: reciprocal refinement hoisted, scaling
+    and fix-up steps dropped, a range guard on the quotient): tools/div_hoist_probe.hip compares the guarded fast quotient with
+    x / d bit for bit on 2^30 pairs here (random mantissas / exponents, exact multiples +- 1 ulp, quotients next to the guard's
+    limits, zeros); profiles/r03_div_hoist_probe.json holds a 3.4e10-pair run"""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "div_hoist_probe")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                           "-w", os.path.join(root, "tools", "div_hoist_probe.hip"), "-o", exe])
+    r = subprocess.run([exe, "1024"], capture_output=True, text=True, timeout=300)
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and res["mismatches"] == 0 and res["pairs"] == 4096 * 256 * 1024 and res["passed_guard"] > res["pairs"] // 4, res
+
+
 def test_single_1080p_pair_no_refinement():
     """BASELINE configs[1] exactly: ONE 1920x1080 pair, patch_size 8, stride 4 (overlap 0.4), 3 pyramid levels (6-5-4), no
     variational refinement -- finest-scale flow, full-resolution flow and the patch state of every scale against the oracle"""
