@@ -832,6 +832,19 @@ def test_degenerate_inputs():
     big = np.roll(a, 60, axis=1)       # large motion: outlier resets / out-of-bounds starts
     out = ofc.calc(dev(a), dev(big)).cpu().numpy()
     assert np.array_equal(out, O.flow(O.pad_frame(a, p.sc_f), O.pad_frame(big, p.sc_f), p, 0))
+    # frames scaled far out of the 8-bit range: the Cholesky factors / quotients of the LK solve leave the guarded range of the
+    # hoisted division (csrc/fdiv_hoist.h) and every wave takes the compiler's IEEE divisions; LK only (the refinement's
+    # constants are tuned to 8-bit data), per-scale patch results and flow against the oracle
+    a, b = synth_pair(256, 512, seed=5)
+    opn = F.operating_point(2, 512, 1)
+    opn.use_var_ref = False
+    ofn = OFClass(opn, F.img_params(width=512, height=256, padding=8))
+    pn = oracle_params(O, opn)
+    for scale in (1e-25, 3e-13, 7e11, 1e16):
+        s0, s1 = (a * np.float32(scale)).astype(np.float32), (b * np.float32(scale)).astype(np.float32)
+        out = ofn.calc(dev(s0), dev(s1)).cpu().numpy()
+        ref = O.flow(O.pad_frame(s0, pn.sc_f), O.pad_frame(s1, pn.sc_f), pn, 0)
+        assert np.array_equal(out, ref, equal_nan=True), scale
 
 
 def test_errors():

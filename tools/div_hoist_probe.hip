@@ -59,6 +59,6 @@ int main(int argc, char **argv)
   hipLaunchKernelGGL(probe, dim3(4096), dim3(256), 0, 0, d_bad, d_bad + 1, d_bad + 2, rounds, d_first);
   hipDeviceSynchronize();
   hipMemcpy(h, d_bad, sizeof(h), hipMemcpyDeviceToHost); hipMemcpy(hf, d_first, 16, hipMemcpyDeviceToHost);
-  printf("{\"tool\": \"tools/div_hoist_probe\", \"pairs\": %llu, \"passed_guard\": %llu, \"mismatches\": %llu, \"first_mismatch\": [%a, %a, %a, %a]}\n", h[1], h[2], h[0], hf[0], hf[1], hf[2], hf[3]);
+  printf("{\"tool\": \"tools/div_hoist_probe\", \"pairs\": %llu, \"passed_guard\": %llu, \"mismatches\": %llu, \"first_mismatch_x_d_fast_ieee\": [\"%a\", \"%a\", \"%a\", \"%a\"]}\n", h[1], h[2], h[0], hf[0], hf[1], hf[2], hf[3]);
   return h[0] ? 1 : 0;
 }
