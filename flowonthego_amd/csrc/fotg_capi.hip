@@ -398,7 +398,7 @@ static int pyramid_impl(fotg_ctx *c, int n, const T *I0, const T *I1, hipStream_
     // other slots (dispatched oldest first) then get in at every launch boundary instead of after the whole pyramid.
     int split = 1;
     if (B && c->tune.pyr_split > 1)                     // the largest cut <= the target into groups of a multiple of 4 pairs (XCD-local placement)
-      for (int k = c->tune.pyr_split; k > 1; --k)
+      for (int k = sizeof(T) == 1 && c->tune.pyr_split > 8 ? 8 : c->tune.pyr_split; k > 1; --k)      // (8-bit frames: a quarter of the bytes per launch)
         if (n % k == 0 && (n / k) % 4 == 0) { split = k; break; }
     const int gs = n / split;
     const T *A0 = A, *B0 = B;
