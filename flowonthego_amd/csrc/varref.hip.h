@@ -890,10 +890,8 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
     }
     return;
   }
-  if (wv >= nsolver) {                                            // spare waves only count barriers
-    for (int I = 0; I < NI; ++I) asm volatile("s_barrier" ::: "memory");
-    return;
-  }
+  if (wv >= nsolver) return;      // spare waves leave: a barrier counts the waves that have not ended, and their wave slots (9 of the
+                                  // workgroup's 16) go back to the kernels of the other batches in flight
 
   {
     // ---------------- solver wave of sweep n, rows 2L and 2L+1 per lane ----------------
