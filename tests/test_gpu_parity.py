@@ -861,6 +861,58 @@ def test_errors():
         OFClass(bad, F.img_params(width=512, height=256, padding=10))
 
 
+def test_context_lifecycle_and_host_threads():
+    """contexts are independent objects: (1) creating and destroying them returns every byte (40 create / calc / destroy
+    rounds, device memory in use afterwards = before), (2) two host threads, each with a context and a stream of its own,
+    computing at the same time get the flows a single thread gets (the library's only shared state -- launch counters, the
+    dynamic-LDS attribute cache -- is atomic / mutex-guarded)"""
+    import threading
+    F, OFClass, _, O = _mods()
+    w, h = 640, 360
+    op = F.operating_point(2, w, 1)
+    ip = F.img_params(width=w, height=h, padding=8)
+    pairs = [synth_pair(h, w, seed=40 + k) for k in range(4)]
+    A = [dev(np.stack([p[0] for p in pairs[:2]])), dev(np.stack([p[0] for p in pairs[2:]]))]
+    B = [dev(np.stack([p[1] for p in pairs[:2]])), dev(np.stack([p[1] for p in pairs[2:]]))]
+    ofc = OFClass(op, ip, max_batch=2)
+    serial = [ofc.calc_batch(A[k], B[k]).cpu().numpy() for k in range(2)]
+    ofc.close()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        o = OFClass(op, ip, max_batch=2)
+        o.calc_batch(A[0], B[0])
+        o.close()
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) <= (4 << 20), (free0, torch.cuda.mem_get_info()[0])
+    results, errors = [None, None], []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                o = OFClass(op, ip, max_batch=2)
+                out = None
+                for _ in range(25):
+                    out = o.calc_batch(A[k], B[k])
+                st.synchronize()
+                results[k] = out.cpu().numpy()
+                o.close()
+        except Exception as e:           # noqa: BLE001 -- reported below
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        assert np.array_equal(results[k], serial[k])
+    pr = oracle_params(O, op)
+    assert np.array_equal(serial[0][0], O.flow(O.pad_frame(pairs[0][0], pr.sc_f), O.pad_frame(pairs[0][1], pr.sc_f), pr, 0))
+
+
 def test_stalled_wait_is_reported_by_the_product_api():
     """a bounded inter-workgroup wait that times out raises a word in pinned host memory; the entry points that synchronise
     with the host return FOTG_ERR_STALL once (the flow of that call is not valid), then the context is usable again"""
