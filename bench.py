@@ -220,7 +220,9 @@ def roofline_lk(ofc, batch, stage_ms):
     return {"bound": "valu", "kernel": "fotg::lk_kernel<8,1,false> (level %d: %d patches x %d evaluations x 64 px per pair)" % (lvl, nop, evals),
             "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "useful_flops_per_launch": flops,
             "ms_per_launch": ms, "share_of_step": sum(v for k, v in stage_ms.items() if k.startswith("lk[")) / sum(stage_ms.values()),
-            "note": "useful flops only; the instruction stream is ~4x that (profiles/: SQ_INSTS_VALU)"}
+            "note": "useful flops only; the instruction stream is ~4x that (profiles/r03_pmc_valu.json: SQ_INSTS_VALU); the launch retires one VALU "
+                    "wave-instruction per ~4.3 cycles and SIMD, where the hardware issues plain f32 / int adds at 2.3 and selects, compares, DPP, "
+                    "conversions, packed f32 at 4.1-4.4 (profiles/r03_valu_issue_probe.json): about three quarters of the issue rate of its mix"}
 
 
 def cpu_baseline(I0, I1, budget_s=12.0):
