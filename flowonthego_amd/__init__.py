@@ -9,7 +9,7 @@ from .params import AutoFirstScaleSelect, img_params, opt_params, operating_poin
 
 def __getattr__(name):
     # torch-dependent classes are imported lazily so the CPU-only checks (symbol export, host logic) stay light
-    if name in ("OFClass", "PatGridClass", "VarRefClass"):
+    if name in ("OFClass", "PatGridClass", "VarRefClass", "gradient_magnitude"):
         from . import oflow
         return getattr(oflow, name)
     if name == "FlowPipeline":

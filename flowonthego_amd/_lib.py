@@ -44,6 +44,8 @@ SYMBOLS = [
     ("fotg_pipe_context", C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     ("fotg_calc", C.c_int, [vp, vp, vp, vp, vp]),
     ("fotg_upsample_crop", C.c_int, [vp, C.c_int, vp, vp, vp]),
+    ("fotg_gradient_magnitude", C.c_int, [C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    ("fotg_gradient_magnitude_u8", C.c_int, [C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     ("fotg_level_size", C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("fotg_out_size", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("fotg_num_patches", C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -1453,4 +1453,31 @@ int fotg_upsample_crop(fotg_ctx *c, int n, const float *flow, float *out, void *
   return FOTG_OK;
 }
 
+extern "C++" {
+template <typename T>
+static int gradmag_impl(int device, int n, const T *frames, int w_org, int h_org, int channels, int sc_f, float *out, void *stream)
+{
+  if (!frames || !out || n < 1 || (channels != 1 && channels != 3)) return FOTG_ERR_ARG;
+  int Wp, Hp, padw, padh;
+  const int st = fotg_padded_size(w_org, h_org, sc_f, &Wp, &Hp, &padw, &padh);
+  if (st != FOTG_OK) return st;
+  if (Wp < 2 || Hp < 2) return FOTG_ERR_ARG;
+  ON_DEVICE(device);
+  const long per = (long)Wp * Hp * channels;
+  gradmag_kernel<T><<<dim3((unsigned)((per + 255) / 256), n), 256, 0, (hipStream_t)stream>>>(frames, (long)w_org * h_org * channels, w_org, h_org, channels,
+                                                                                            padw / 2, padh / 2, Wp, Hp, out);
+  LAUNCHCHK();
+  return FOTG_OK;
+}
+}  // extern "C++"
+
+int fotg_gradient_magnitude(int device, int n, const float *frames, int w_org, int h_org, int channels, int sc_f, float *out, void *stream)
+{
+  return gradmag_impl<float>(device, n, frames, w_org, h_org, channels, sc_f, out, stream);
+}
+int fotg_gradient_magnitude_u8(int device, int n, const unsigned char *frames, int w_org, int h_org, int channels, int sc_f, float *out, void *stream)
+{
+  return gradmag_impl<unsigned char>(device, n, frames, w_org, h_org, channels, sc_f, out, stream);
+}
+
 }  // extern "C"

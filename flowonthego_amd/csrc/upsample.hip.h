@@ -38,4 +38,24 @@ __global__ __launch_bounds__(256) void upsample_crop_kernel(const float *__restr
   }
 }
 
+// Gradient-magnitude input (kroeger/run_dense.cpp:138-147, the reference's SELECTCHANNEL==2 build): level 0 of the pyramid is
+// sqrt(dx^2 + dy^2) of the PADDED frame, dx = P(x+1) - P(x-1), dy = P(y+1) - P(y-1) per channel (cv::Sobel ksize 1) with
+// REFLECT_101 at the padded frame's edge.  P is the replicate-padded frame (run_dense.cpp:306-310), read through clamped
+// coordinates from the original one; out: n x Hp x Wp x noc.  One thread per value; a pre-pass outside the hot path.
+template <typename T>
+__global__ __launch_bounds__(256) void gradmag_kernel(const T *__restrict__ frames, long frame_stride, int w_org, int h_org, int noc,
+                                                      int left, int top, int Wp, int Hp, float *__restrict__ out)
+{
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Wp * Hp * noc) return;
+  const int c = (int)(idx % noc), x = (int)((idx / noc) % Wp), y = (int)(idx / ((long)noc * Wp));
+  const T *f = frames + (size_t)blockIdx.y * frame_stride;
+  auto P = [&](int px, int py) { return (float)f[((size_t)clampi(py - top, h_org) * w_org + clampi(px - left, w_org)) * noc + c]; };
+  const int xm = x > 0 ? x - 1 : 1, xp = x < Wp - 1 ? x + 1 : Wp - 2;
+  const int ym = y > 0 ? y - 1 : 1, yp = y < Hp - 1 ? y + 1 : Hp - 2;
+  const float dx = P(xp, y) - P(xm, y), dy = P(x, yp) - P(x, ym);
+  const float dx2 = dx * dx, dy2 = dy * dy;
+  out[(size_t)blockIdx.y * ((size_t)Wp * Hp * noc) + idx] = sqrtf(dx2 + dy2);
+}
+
 }  // namespace fotg

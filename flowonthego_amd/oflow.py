@@ -226,6 +226,27 @@ class OFClass:
                 pass
 
 
+def gradient_magnitude(frames, coarsest_scale, out=None):
+    """The reference's SELECTCHANNEL==2 input (kroeger/run_dense.cpp:138-147): frames (n, h, w[, channels]) float32 or uint8 on
+    the device -> (n, Hp, Wp[, channels]) float32, the gradient magnitude of the replicate-padded frames (padding to multiples of
+    2^coarsest_scale included).  Feed the result to an OFClass created for Wp x Hp."""
+    if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.is_contiguous() and frames.dtype in (torch.float32, torch.uint8)):
+        raise FotgError("frames must be a contiguous float32 or uint8 CUDA(HIP) tensor")
+    if frames.ndim not in (3, 4) or (frames.ndim == 4 and frames.shape[3] not in (1, 3)):
+        raise FotgError("frames must have shape (n, h, w) or (n, h, w, 1|3)")
+    n, h, w = frames.shape[:3]
+    noc = 1 if frames.ndim == 3 else frames.shape[3]
+    from .params import padded_size
+    wp, hp = padded_size(w, h, coarsest_scale)[:2]
+    shape = (n, hp, wp) + (() if frames.ndim == 3 else (noc,))
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=frames.device)
+    _dev_f32(out, "out", frames.device, shape)
+    fn = lib().fotg_gradient_magnitude if frames.dtype == torch.float32 else lib().fotg_gradient_magnitude_u8
+    check(fn(frames.device.index or 0, n, _ptr(frames), w, h, noc, coarsest_scale, _ptr(out), _stream(frames.device)))
+    return out
+
+
 def _hip_copy(dst_tensor, src_ptr):
     """device->device copy of a raw library pointer into a tensor (test/inspection helper)"""
     hip = C.CDLL("libamdhip64.so")

@@ -132,6 +132,14 @@ int fotg_calc(fotg_ctx *ctx, const float *I0, const float *I1, const float *init
  * padding.  in: n x hl x wl x 2 (device), out: n x h_org x w_org x 2 (device). */
 int fotg_upsample_crop(fotg_ctx *ctx, int n, const float *flow, float *out, void *stream);
 
+/* Gradient-magnitude input, the reference's SELECTCHANNEL==2 build (kroeger/run_dense.cpp:138-147): level 0 of the pyramid is
+ * sqrt(dx^2 + dy^2) of the padded frame (cv::Sobel ksize 1, REFLECT_101 at the padded edge).  frames: n x h_org x w_org x
+ * channels (device, f32 or 8-bit); out: n x Hp x Wp x channels f32 (device), Wp / Hp = fotg_padded_size(w_org, h_org, sc_f) --
+ * the replicate padding (run_dense.cpp:306-310) is part of the call, so the flow context for these frames is created with
+ * w_org = Wp, h_org = Hp (no further padding) and fotg_upsample_crop of a context of the original size crops the result. */
+int fotg_gradient_magnitude(int device, int n, const float *frames, int w_org, int h_org, int channels, int sc_f, float *out, void *stream);
+int fotg_gradient_magnitude_u8(int device, int n, const unsigned char *frames, int w_org, int h_org, int channels, int sc_f, float *out, void *stream);
+
 /* op.verbosity of the reference (src/oflow.cpp:246-365, kroeger/oflow.cpp:298-360).  0 (default): silent, asynchronous.
  * > 0: every flow call (fotg_calc, fotg_calc_batch, ...) waits for its launches and prints "TIME (O.Flow Run-Time   ) (ms): ..."
  * (the flow without the pyramid, like the reference); > 1: also one "TIME (Sc: .., #p: .., pconst, pinit, poptim, cflow, tvopt,

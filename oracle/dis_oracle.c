@@ -136,6 +136,25 @@ void dis_pad_frame(const float *in, int w, int h, int noc, int sc_f, float *out)
   }
 }
 
+/* kroeger/run_dense.cpp:138-147 (the SELECTCHANNEL==2 build): the pyramid's level 0 is the gradient magnitude of the padded
+ * frame -- cv::Sobel(ksize 1, BORDER_DEFAULT) = I(x+1) - I(x-1) / I(y+1) - I(y-1) per channel with REFLECT_101 at the frame's
+ * edge (index -1 -> 1, n -> n-2), then sqrt(dx*dx + dy*dy), all in f32.  in / out: w x h x noc, w, h >= 2. */
+void dis_gradient_magnitude(const float *in, int w, int h, int noc, float *out)
+{
+  for (int y = 0; y < h; ++y) {
+    int ym = y > 0 ? y - 1 : 1, yp = y < h - 1 ? y + 1 : h - 2;
+    for (int x = 0; x < w; ++x) {
+      int xm = x > 0 ? x - 1 : 1, xp = x < w - 1 ? x + 1 : w - 2;
+      for (int c = 0; c < noc; ++c) {
+        float dx = in[((size_t)y * w + xp) * noc + c] - in[((size_t)y * w + xm) * noc + c];
+        float dy = in[((size_t)yp * w + x) * noc + c] - in[((size_t)ym * w + x) * noc + c];
+        float dx2 = dx * dx, dy2 = dy * dy;
+        out[((size_t)y * w + x) * noc + c] = sqrtf(dx2 + dy2);
+      }
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* pyramid: kroeger/run_dense.cpp:130-178                                                      */
 /* ------------------------------------------------------------------------------------------- */

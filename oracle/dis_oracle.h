@@ -56,6 +56,8 @@ void dis_op_point(int op, int width_org, int noc, dis_params *p);
  * Returns padded sizes; out must hold Wp*Hp*noc floats.  padw/padh returned. */
 void dis_padded_size(int w, int h, int sc_f, int *wp, int *hp, int *padw, int *padh);
 void dis_pad_frame(const float *in, int w, int h, int noc, int sc_f, float *out);
+/* kroeger/run_dense.cpp:138-147 (SELECTCHANNEL==2): gradient magnitude of a (padded) frame as the pyramid's input */
+void dis_gradient_magnitude(const float *in, int w, int h, int noc, float *out);
 
 /* kroeger/run_dense.cpp:130-178.  img: Wp x Hp x noc interleaved f32.  For every level l in
  * 0..sc_f allocates (malloc) padded image / dx / dy of size (w_l+2ps) x (h_l+2ps) x noc.

@@ -116,6 +116,16 @@ def pad_frame(img, sc_f):
     return out
 
 
+def gradient_magnitude(img):
+    """(h, w[, noc]) float32 padded frame -> its gradient magnitude image (kroeger/run_dense.cpp:138-147, SELECTCHANNEL==2)"""
+    img = f32(img)
+    h, w = img.shape[:2]
+    noc = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty_like(img)
+    lib().dis_gradient_magnitude(P(img), w, h, noc, P(out))
+    return out
+
+
 class Pyramid:
     """dis_pyramid_build wrapper; levels as numpy copies: im[l], dx[l], dy[l] of shape
     (h_l+2ps, w_l+2ps, noc)"""

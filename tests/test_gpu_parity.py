@@ -861,6 +861,31 @@ def test_errors():
         OFClass(bad, F.img_params(width=512, height=256, padding=10))
 
 
+@pytest.mark.parametrize("noc,u8", [(1, False), (3, False), (1, True), (3, True)])
+def test_gradient_magnitude_input(noc, u8):
+    """the reference's SELECTCHANNEL==2 input (kroeger/run_dense.cpp:138-147): fotg_gradient_magnitude(frames) == the oracle's
+    gradient magnitude of the replicate-padded frames, and the flow of an engine fed with those images == the oracle's flow
+    on the same images (frames that need padding in both directions; float and 8-bit)"""
+    F, OFClass, _, O = _mods()
+    h, w = 270, 500
+    f0, f1 = synth_pair(h, w, seed=321, noc=noc)
+    op = F.operating_point(2, w, noc)
+    p = oracle_params(O, op)
+    g0, g1 = O.gradient_magnitude(O.pad_frame(f0, p.sc_f)), O.gradient_magnitude(O.pad_frame(f1, p.sc_f))
+    fr = np.stack([f0, f1])
+    t = torch.from_numpy(fr.astype(np.uint8)).cuda() if u8 else dev(fr)
+    G = F.gradient_magnitude(t, op.coarsest_scale)
+    got = G.cpu().numpy()
+    assert got.shape == (2,) + g0.shape
+    assert np.array_equal(got[0], g0) and np.array_equal(got[1], g1)
+    hp, wp = g0.shape[:2]
+    ofc = OFClass(op, F.img_params(width=wp, height=hp, padding=op.patch_size))
+    out = ofc.calc(G[0], G[1]).cpu().numpy()
+    assert np.array_equal(out, O.flow(g0, g1, p, 0))
+    with pytest.raises(F.FotgError):
+        F.gradient_magnitude(t.cpu(), op.coarsest_scale)
+
+
 def test_context_lifecycle_and_host_threads():
     """contexts are independent objects: (1) creating and destroying them returns every byte (40 create / calc / destroy
     rounds, device memory in use afterwards = before), (2) two host threads, each with a context and a stream of its own,

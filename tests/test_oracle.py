@@ -404,3 +404,19 @@ def test_flow_many_threads_equal_single_calls():
         assert sec > 0 and out.shape[0] == 3
         for k in range(3):
             assert np.array_equal(out[k], ref[k]), (with_pyr, k)
+
+
+def test_gradient_magnitude_input_restatement():
+    """SELECTCHANNEL==2 front end (kroeger/run_dense.cpp:138-147): the oracle's gradient magnitude against an independent numpy
+    restatement of cv::Sobel(ksize 1, BORDER_DEFAULT) + mul + add + cv::sqrt, gray and RGB, odd sizes; a constant frame gives 0"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    for shape in ((7, 9), (2, 2), (33, 18, 3), (5, 64, 3)):
+        a = (rng.random(shape) * 255).astype(np.float32)
+        pw = ((1, 1), (1, 1)) + (((0, 0),) if a.ndim == 3 else ())
+        p = np.pad(a, pw, mode="reflect")                       # REFLECT_101: -1 -> 1, n -> n-2
+        dx = p[1:-1, 2:] - p[1:-1, :-2]
+        dy = p[2:, 1:-1] - p[:-2, 1:-1]
+        ref = np.sqrt(dx * dx + dy * dy, dtype=np.float32)
+        assert np.array_equal(O.gradient_magnitude(a), ref), shape
+    assert not O.gradient_magnitude(np.full((6, 5), 77.0, np.float32)).any()
