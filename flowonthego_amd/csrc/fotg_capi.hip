@@ -62,6 +62,7 @@ struct FotgTune {
   int vr_stream;    // FOTG_VR_STREAM: 0 = resident-D kernel instead of the streaming solver
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
+  int vr_first_data; // FOTG_VR_FIRST_DATA: 0 = the first inner iteration's data term in a launch of its own (not in the set-up launch)
   int pyr_split;    // FOTG_PYR_SPLIT: launches the base pyramid kernel of a batch is cut into (1 = one launch)
   int vr_fused_nt;  // FOTG_VR_FUSED_NT: threads per workgroup of the fused per-level kernel on gray levels of 1025..2048 pixels (512 / 1024)
 };
@@ -237,6 +238,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_stream = env_int("FOTG_VR_STREAM", 1);
   c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
   c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
+  c->tune.vr_first_data = env_int("FOTG_VR_FIRST_DATA", 1);
   c->tune.vr_fused_nt = env_int("FOTG_VR_FUSED_NT", 1024);
   c->tune.pyr_split = env_int("FOTG_PYR_SPLIT", 1);
   if (hipHostMalloc((void **)&c->stall_host, 64, hipHostMallocMapped) != hipSuccess ||
@@ -871,10 +873,14 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     LAUNCHCHK();
     return FOTG_OK;
   }
+  bool merged_first = false;
   if (c->tune.vr_setup) {
     // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
     // (tune.vr_setup = 0: memset + the three plane-at-a-time launches; tests)
-    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1);
+    // (the launch also builds the system of the first inner iteration unless tune.vr_first_data = 0)
+    merged_first = c->tune.vr_first_data && inner > 0;
+    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
+                                                                                       merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
     LAUNCHCHK();
   } else {
     HIPCHK(hipMemsetAsync(a.D, 0, (size_t)n * a.d_pair_stride * sizeof(float2), s));      // image_erase(du), image_erase(dv) (:185-186)
@@ -886,8 +892,10 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     LAUNCHCHK();
   }
   for (int it = 0; it < inner; ++it) {
-    vr_data_kernel<NOC><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(a, quarter_alpha, half_delta_over3, half_gamma_over3);
-    LAUNCHCHK();
+    if (!(it == 0 && merged_first)) {
+      vr_data_kernel<NOC><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(a, quarter_alpha, half_delta_over3, half_gamma_over3);
+      LAUNCHCHK();
+    }
     if (c->p.tv_solverit > 0) {
       if (c->p.sor_mode == FOTG_SOR_REDBLACK) vr_sor_redblack_kernel<<<n, 1024, 0, s>>>(a, c->p.tv_solverit, c->p.tv_sor);
       else dispatch_sor(c, a, n, c->p.tv_solverit, c->p.tv_sor, s);

@@ -187,10 +187,18 @@ __global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
 // difference on the tile + 4 pixels (the second derivatives reach 2 + 2 pixels), first derivatives on the tile + 2.  Halo
 // entries outside the image hold the values of the clamped coordinate, exactly what the reference's replicate indexing
 // reads, and the 5-tap helpers index the LDS tiles through pointers biased to global coordinates.
+// (defined behind the data term: the first inner iteration's system, computed by the set-up launch itself)
+template <int NOC, int NCH>
+__device__ __forceinline__ void first_data_term(const VrArgs &a, int pair, int tx0, int ty0, const float *__restrict__ flow, long flow_stride,
+                                                float quarter_alpha, float half_delta_over3, float half_gamma_over3);
+
+// first_data != 0 (flow mode): the launch also builds the system of the FIRST inner iteration (du = dv = 0), i.e. what
+// vr_data_kernel would do next -- one launch and one read of the planes less per level.
 template <int NOC, int NCH = 2>
 __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__restrict__ I0, const float *__restrict__ I1,
                                                        long img_stride, int tw, int pad,
-                                                       const float *__restrict__ flow, long flow_stride, int zero_d = 0)
+                                                       const float *__restrict__ flow, long flow_stride, int zero_d = 0,
+                                                       int first_data = 0, float quarter_alpha = 0.f, float half_delta_over3 = 0.f, float half_gamma_over3 = 0.f)
 {
   constexpr int TW_ = 32, TH_ = 8, XW = TW_ + 8, XH = TH_ + 8, YW = TW_ + 4, YH = TH_ + 4;
   __shared__ float Xa[NOC][XH * XW], Xz[NOC][XH * XW], Yx[NOC][YH * YW], Yy[NOC][YH * YW];
@@ -243,6 +251,12 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
       a.color(pair, C_IXX, c)[o] = conv_h5(xrow, i, w);
       a.color(pair, C_IXY, c)[o] = conv_v5(xcol, j, h, YW);
       a.color(pair, C_IYY, c)[o] = conv_v5(ycol, j, h, YW);
+    }
+  }
+  if constexpr (NCH == 2) {
+    if (first_data) {
+      __syncthreads();                                           // the planes of the tile's pixels are in memory (stores of this workgroup)
+      first_data_term<NOC, NCH>(a, pair, tx0, ty0, flow, flow_stride, quarter_alpha, half_delta_over3, half_gamma_over3);
     }
   }
 }
@@ -457,6 +471,53 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_al
   const float vt = (j > 0) ? sm[sc - SW] + s_o : 0.0f;
 
   data_term_compute<NOC>(a, pair, i, j, pin, hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
+}
+
+// vr_data_kernel's work for the first inner iteration of a level, on the tile of a set-up workgroup (same 32 x 8 tiles): (du,dv) is
+// zero, so (uu,vv) = (wx + 0, wy + 0) with (wx,wy) straight from the incoming flow (the neighbours' wx / wy planes belong to other
+// workgroups of this launch and may not be written yet; same values), the planes of the tile's own pixels from global memory.
+template <int NOC, int NCH>
+__device__ __forceinline__ void first_data_term(const VrArgs &a, int pair, int x0, int y0, const float *__restrict__ flow, long flow_stride,
+                                                float quarter_alpha, float half_delta_over3, float half_gamma_over3)
+{
+  constexpr int UW = FOTG_TW + 4, UH = FOTG_TH + 4, SW = FOTG_TW + 2, SH = FOTG_TH + 2;
+  __shared__ float2 uv[UW * UH];
+  __shared__ float sm[SW * SH];
+  const int st = a.st, w = a.w, h = a.h;
+  const int lx = threadIdx.x % FOTG_TW, ly = threadIdx.x / FOTG_TW;
+  const int i = x0 + lx, j = y0 + ly;
+  const float *fl = flow + (size_t)pair * flow_stride;
+  auto W = [&](int ii, int jj) { const float *f = fl + NCH * (size_t)(jj * w + ii); return make_float2(f[0], f[NCH - 1]); };
+  for (int k = threadIdx.x; k < UW * UH; k += 256) {
+    const float2 wv = W(clampi(x0 - 2 + k % UW, w), clampi(y0 - 2 + k / UW, h));
+    uv[k] = make_float2(wv.x + 0.f, wv.y + 0.f);                // wx + du, wy + dv with du = dv = +0 (refine_variational.cpp:185-186, 208-214)
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < SW * SH; k += 256) {
+    const int sy = k / SW, sx = k % SW;
+    const int c = (sy + 1) * UW + (sx + 1);
+    sm[k] = smooth_w(uv[c - 1], uv[c], uv[c + 1], uv[c - UW], uv[c + UW], y0 - 1 + sy, h, quarter_alpha);
+  }
+  __syncthreads();
+  if (i >= w || j >= h) return;
+  const int sc = (ly + 1) * SW + (lx + 1), o = j * st + i;
+  const float s_o = sm[sc];
+  const float hr = (i < w - 1) ? s_o + sm[sc + 1] : 0.0f;
+  const float hl = (i > 0) ? sm[sc - 1] + s_o : 0.0f;
+  const float vb = (j < h - 1) ? s_o + sm[sc + SW] : 0.0f;
+  const float vt = (j > 0) ? sm[sc - SW] + s_o : 0.0f;
+  PixIn<NOC> p;
+#pragma unroll
+  for (int c = 0; c < NOC; ++c) {
+    p.Ix[c] = a.color(pair, C_IX, c)[o]; p.Iy[c] = a.color(pair, C_IY, c)[o]; p.Iz[c] = a.color(pair, C_IZ, c)[o];
+    p.Ixx[c] = a.color(pair, C_IXX, c)[o]; p.Ixy[c] = a.color(pair, C_IXY, c)[o]; p.Iyy[c] = a.color(pair, C_IYY, c)[o];
+    p.Ixz[c] = a.color(pair, C_IXZ, c)[o]; p.Iyz[c] = a.color(pair, C_IYZ, c)[o];
+  }
+  p.m = a.single(pair, P_MASK)[o];
+  const float2 wc = W(i, j), wl = W(i > 0 ? i - 1 : i, j), wr = W(i < w - 1 ? i + 1 : i, j), wt = W(i, j > 0 ? j - 1 : j), wb = W(i, j < h - 1 ? j + 1 : j);
+  p.wxc = wc.x; p.wxl = wl.x; p.wxr = wr.x; p.wxt = wt.x; p.wxb = wb.x;
+  p.wyc = wc.y; p.wyl = wl.y; p.wyr = wr.y; p.wyt = wt.y; p.wyb = wb.y;
+  data_term_compute<NOC>(a, pair, i, j, p, hr, hl, vb, vt, 0.f, 0.f, half_delta_over3, half_gamma_over3);
 }
 
 // one pixel update of sor_coupled (solver.c:122-130 etc.).  du_l/du_t are the NEW left/top values, du_r/du_b the OLD

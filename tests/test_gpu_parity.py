@@ -372,6 +372,24 @@ def test_plane_at_a_time_setup_stages(alley, monkeypatch):
         assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
 
 
+@pytest.mark.parametrize("first_data", ["1", "0"])
+def test_first_data_term_in_the_setup_launch(first_data, alley, monkeypatch):
+    """levels refined by separate launches (FOTG_VR_PATH=2: every level): the set-up launch also builds the system of the first
+    inner iteration (FOTG_VR_FIRST_DATA=1, the default) or leaves it to a data-term launch of its own (=0): same flow, gray and
+    RGB, sizes with partial tiles, and the golden reference planes of the first iteration's system"""
+    F, OFClass, VarRefClass, O = _mods()
+    monkeypatch.setenv("FOTG_VR_FIRST_DATA", first_data)
+    monkeypatch.setenv("FOTG_VR_PATH", "2")
+    for case, op_point in (("alley", 2), ("synth_rgb", 2), ("synth_odd", 3)):
+        f0, f1, noc = frames(case, alley)
+        h, w = f0.shape[:2]
+        op = F.operating_point(op_point, w, noc)
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        p = oracle_params(O, op)
+        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
+
+
 def test_fused_level_system_in_global_memory(alley, monkeypatch):
     """the on-chip levels keep the linear system in LDS when it fits; FOTG_VR_CLDS=0 forces the variant that streams it
     through global memory (what larger levels use): same bits"""
