@@ -920,6 +920,8 @@ def test_context_lifecycle_and_host_threads():
     ofc = OFClass(op, ip, max_batch=2)
     serial = [ofc.calc_batch(A[k], B[k]).cpu().numpy() for k in range(2)]
     ofc.close()
+    import gc
+    gc.collect()                                  # (contexts of earlier tests that are still waiting for their finalizer)
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
     for _ in range(40):
@@ -927,7 +929,7 @@ def test_context_lifecycle_and_host_threads():
         o.calc_batch(A[0], B[0])
         o.close()
     torch.cuda.synchronize()
-    assert abs(torch.cuda.mem_get_info()[0] - free0) <= (4 << 20), (free0, torch.cuda.mem_get_info()[0])
+    assert torch.cuda.mem_get_info()[0] >= free0 - (4 << 20), (free0, torch.cuda.mem_get_info()[0])      # nothing is left behind
     results, errors = [None, None], []
 
     def worker(k):
