@@ -336,6 +336,53 @@ def cpu_baseline(I0, I1, budget_s=12.0):
                       "2.1 GHz Xeon" % (nall, flags, threads, el, nflow, el_flow, n1, single, 1e3 / flow_ms)}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def fail(msg, rc=2, **extra):
+    """one JSON line on stdout (what the driver parses) + the same text on stderr, then a non-zero exit"""
+    print(json.dumps(dict({"error": msg}, **extra)))
+    print("bench.py: " + msg, file=sys.stderr)
+    sys.exit(rc)
+
+
+def self_launch(gpus, argv, device_count=None, run=None):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the launcher.  It starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process (never
+    os.exec*: a process must not replace itself once anything may have touched the GPU), relays its stdout / stderr and returns
+    its exit code.  The launcher itself makes no HIP call (torch.cuda.device_count() does not initialise the GPU on this image).
+    device_count / run: injection points of tests/test_host.py."""
+    import subprocess
+    have = (device_count or torch.cuda.device_count)()
+    if gpus > have:
+        fail("--gpus %d requested, %d GPU(s) visible on this node: refusing to run on fewer GPUs than asked for" % (gpus, have), requested_gpus=gpus, visible_gpus=have)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return (run or subprocess.run)(cmd, env=env).returncode
+
+
+def pci_bus_id(device):
+    """PCI bus id string of a HIP device ("0000:05:00.0") -- which physical GPU a rank sat on"""
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        hip.hipDeviceGetPCIBusId.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) == 0:
+            return buf.value.decode()
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,13 +402,42 @@ def main():
     ap.add_argument("--sor-mode", type=int, default=0, help="0 lexicographic (reference order, parity mode), 1 red-black")
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        fail("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become one (before anything touches the GPU) and relay the ranks' output and exit code
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        # `--gpus N` is a promise about the line this run prints ("n_gpus": N): a launcher that started another number of ranks
+        # must not produce a plausible-looking line for the wrong N
+        fail("--gpus %d but WORLD_SIZE=%d: the launcher started %d rank(s); start one rank per GPU (python -m torch.distributed.run "
+             "--nproc-per-node %d ... bench.py --gpus %d) or run `python bench.py --gpus %d` and let it launch them" %
+             (a.gpus, world, world, a.gpus, a.gpus, a.gpus), rank=rank)
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        fail("rank %d: LOCAL_RANK %d but %d GPU(s) visible" % (rank, local, ndev), rank=rank)
     dist = world > 1 or bool(os.environ.get("FOTG_BENCH_FORCE_DIST"))      # the switch exercises the RCCL path on a 1-GPU box
+    rccl_ranks = None
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # how many ranks RCCL really connected (an all-reduce of ones), and which physical GPU each one sits on
+        ones = torch.ones(1, device=torch.device("cuda", local), dtype=torch.float64)
+        td.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != a.gpus or td.get_world_size() != a.gpus:
+            fail("RCCL connected %d rank(s), --gpus %d" % (rccl_ranks, a.gpus), rank=rank)
+        placement = [None] * world
+        td.all_gather_object(placement, {"rank": rank, "local_rank": local, "pci_bus_id": pci_bus_id(local)})
+        if len({p["pci_bus_id"] for p in placement}) != world and world > 1 and not os.environ.get("FOTG_BENCH_ALLOW_SHARED_GPU"):
+            fail("two ranks share one GPU: %s" % placement, rank=rank)
+    else:
+        placement = [{"rank": 0, "local_rank": local, "pci_bus_id": pci_bus_id(local)}]
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -478,6 +554,8 @@ def main():
         res["host_issue_note"] = "wall time of fotg_pipe_submit (23 kernel launches) per step on the issuing thread; ms_per_step above it = the GPU, not the launch path, sets the rate"
     if per_rank is not None:
         res["ms_per_step_per_rank"] = per_rank
+    res["rccl_ranks"] = rccl_ranks            # ranks an all-reduce of ones counted (None: single process, RCCL not initialised)
+    res["rank_placement"] = placement
 
     if rank == 0:
         stream_ptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -617,9 +695,23 @@ def main():
         full = gather_flows_exact(flows, world * a.batch, td, dst=0)
         barrier()
         t3 = time.perf_counter()
+        ok = True
         if rank == 0:
+            # every rank's shard is a copy of rank 0's batch: the gathered flows must be `world` copies of the single-context
+            # result, bit for bit (a buffer re-used too early in the chunked scatter would show up here as a stale or torn frame)
+            want = ofc.calc_batch(I0, I1)
+            torch.cuda.synchronize()
+            ok = all(torch.equal(full[r * a.batch:(r + 1) * a.batch], want) for r in range(world))
             print(json.dumps({"scatter_gather": {"scatter_plus_compute_ms": (t2 - t0) * 1e3, "gather_ms": (t3 - t2) * 1e3, "chunk_pairs": chunk,
-                                                 "end_to_end_pairs_per_s": world * a.batch / (t3 - t0), "gathered_shape": list(full.shape)}}))
+                                                 "end_to_end_pairs_per_s": world * a.batch / (t3 - t0), "gathered_shape": list(full.shape),
+                                                 "gathered_flows_match_single_context": bool(ok)}}))
+        flag = torch.tensor([0 if ok else 1], device=dev)
+        td.all_reduce(flag)
+        if int(flag.item()):
+            if rank == 0:
+                print("bench.py: the flows gathered after the chunked scatter differ from the single-context result", file=sys.stderr)
+            td.destroy_process_group()
+            sys.exit(1)
     if dist:
         td.barrier()
         td.destroy_process_group()

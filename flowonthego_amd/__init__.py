@@ -15,4 +15,7 @@ def __getattr__(name):
     if name == "FlowPipeline":
         from .pipeline import FlowPipeline
         return FlowPipeline
+    if name == "FlowNode":
+        from .node import FlowNode
+        return FlowNode
     raise AttributeError(name)

@@ -42,6 +42,16 @@ SYMBOLS = [
     ("fotg_pipe_wait", C.c_int, [vp, C.c_long, vp, C.c_int]),
     ("fotg_pipe_sync", C.c_int, [vp]),
     ("fotg_pipe_context", C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    ("fotg_node_create", C.c_int, [C.POINTER(FotgParams), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    ("fotg_node_destroy", None, [vp]),
+    ("fotg_node_shard", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("fotg_node_submit", C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_long)]),
+    ("fotg_node_submit_u8", C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_long)]),
+    ("fotg_node_submit_scatter", C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_long)]),
+    ("fotg_node_wait", C.c_int, [vp, C.c_long]),
+    ("fotg_node_sync", C.c_int, [vp]),
+    ("fotg_node_info", C.c_int, [vp] + [C.POINTER(C.c_int)] * 4),
+    ("fotg_node_pipe", C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     ("fotg_calc", C.c_int, [vp, vp, vp, vp, vp]),
     ("fotg_upsample_crop", C.c_int, [vp, C.c_int, vp, vp, vp]),
     ("fotg_gradient_magnitude", C.c_int, [C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -65,6 +65,7 @@ struct FotgTune {
   int vr_first_data; // FOTG_VR_FIRST_DATA: 0 = the first inner iteration's data term in a launch of its own (not in the set-up launch)
   int pyr_split;    // FOTG_PYR_SPLIT: launches the base pyramid kernel of a batch is cut into (1 = one launch)
   int vr_fused_nt;  // FOTG_VR_FUSED_NT: threads per workgroup of the fused per-level kernel on gray levels of 1025..2048 pixels (512 / 1024)
+  int test_taps;    // FOTG_TEST_TAPS: 1 = fotg_ctx_counter(ctx, "inject_stall") is live (tests of the FOTG_ERR_STALL reporting)
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
@@ -228,6 +229,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   if (p->max_iter < 0 || p->tv_solverit < 0 || p->tv_innerit < 0) return FOTG_ERR_ARG;
   if (p->costfct < 0 || p->costfct > 2 || (p->costfct == 2 && !(p->normoutlier > 0))) return FOTG_ERR_ARG;
   if (p->depth && p->usetvref && p->sor_mode != FOTG_SOR_LEXICOGRAPHIC) return FOTG_ERR_UNSUPPORTED;
+  if (p->sor_mode < FOTG_SOR_LEXICOGRAPHIC || p->sor_mode > FOTG_SOR_POINT) return FOTG_ERR_ARG;
   ON_DEVICE(device);
   fotg_ctx *c = new (std::nothrow) fotg_ctx();
   if (!c) return FOTG_ERR_ARG;
@@ -241,6 +243,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_first_data = env_int("FOTG_VR_FIRST_DATA", 1);
   c->tune.vr_fused_nt = env_int("FOTG_VR_FUSED_NT", 1024);
   c->tune.pyr_split = env_int("FOTG_PYR_SPLIT", 1);
+  c->tune.test_taps = env_int("FOTG_TEST_TAPS", 0);
   if (hipHostMalloc((void **)&c->stall_host, 64, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void **)&c->stall_dev, c->stall_host, 0) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; }
   memset(c->stall_host, 0, 64);
@@ -294,6 +297,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
     // (more than 1024 rows: only the tile pipeline reaches them, and it runs one wave per sweep for up to four sweeps)
     if (g.h > (p->depth ? 1024 : 4096) && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     if (g.h > 1024 && !p->depth && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && p->tv_solverit > 4) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
+    if (g.h > 1024 && p->sor_mode == FOTG_SOR_POINT) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }      // (compatibility mode: single-wave solver only)
     if (g.w < 3 || c->geom[p->sc_f].h < 5 || c->geom[p->sc_f].w < 3) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc + (p->depth ? (int)DE_NPLANE : 0));
     ALLOC(c->vr, B * c->vr_pair_stride * sizeof(float));
@@ -304,6 +308,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       memset(&a, 0, sizeof(a));
       a.base = c->vr; a.pair_stride = c->vr_pair_stride; a.w = gl.w; a.h = gl.h; a.st = gl.st; a.noc = c->noc;
       a.pl = (long)gl.st * gl.h;
+      a.point = p->sor_mode == FOTG_SOR_POINT;
       int K = 16;
       for (int k : ks) if (k * 64 >= gl.h) { K = k; break; }
       a.K = K; a.nlanes = (gl.h + K - 1) / K; a.RP = a.nlanes * K; a.RPD = ((a.RP + K + 1 + 1) / 2) * 2;      // + K padding rows for idle lanes, + 1 for the bottom neighbour
@@ -806,6 +811,17 @@ static bool dispatch_inner_fused(const fotg_ctx *c, const VrArgs &a, int n, int 
   return launch_inner_fused<NOC>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
 }
 
+// FOTG_SOR_POINT (sor_coupled_slow_but_readable, a compatibility mode): the single-wave wavefront solver with the point update
+static void dispatch_sor_point(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
+{
+  switch (a.K) {
+#define PT(K_) case K_: vr_sor_kernel<K_, 1, (K_ <= 4 ? 4 : 1), true><<<n, 64, 0, s>>>(a, sweeps, omega); break
+    PT(1); PT(2); PT(3); PT(4); PT(6); PT(8); PT(12);
+    default: vr_sor_kernel<16, 1, 1, true><<<n, 64, 0, s>>>(a, sweeps, omega); break;
+#undef PT
+  }
+}
+
 static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
   const int path = c->tune.vr_path;    // 0 = automatic, 1 = single-wave global-memory solver only, 2 = no fused inner loop (tests)
@@ -898,6 +914,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     }
     if (c->p.tv_solverit > 0) {
       if (c->p.sor_mode == FOTG_SOR_REDBLACK) vr_sor_redblack_kernel<<<n, 1024, 0, s>>>(a, c->p.tv_solverit, c->p.tv_sor);
+      else if (c->p.sor_mode == FOTG_SOR_POINT) dispatch_sor_point(a, n, c->p.tv_solverit, c->p.tv_sor, s);
       else dispatch_sor(c, a, n, c->p.tv_solverit, c->p.tv_sor, s);
       LAUNCHCHK();
     }
@@ -1008,7 +1025,7 @@ extern "C" {
 int fotg_bench_sor_call(fotg_ctx *c, int l, int n, void *stream)
 {
   int st = check_level(c, l, n); if (st) return st;
-  if (!c->vr || c->p.depth || !c->vrC[l] || c->p.tv_solverit < 1) return FOTG_ERR_UNSUPPORTED;
+  if (!c->vr || c->p.depth || !c->vrC[l] || c->p.tv_solverit < 1 || c->p.sor_mode != FOTG_SOR_LEXICOGRAPHIC) return FOTG_ERR_UNSUPPORTED;
   ON_DEVICE(c->device);
   dispatch_sor(c, c->vra[l], n, c->p.tv_solverit, c->p.tv_sor, (hipStream_t)stream);
   LAUNCHCHK();
@@ -1239,7 +1256,14 @@ struct fotg_pipe {
   int device, depth;
   fotg_ctx *ctx[FOTG_PIPE_MAX_DEPTH];
   hipStream_t stream[FOTG_PIPE_MAX_DEPTH];
-  hipEvent_t ready[FOTG_PIPE_MAX_DEPTH], done[FOTG_PIPE_MAX_DEPTH];
+  hipEvent_t ready[FOTG_PIPE_MAX_DEPTH];
+  // completion events per TICKET, not per slot: ticket t records done[t % nring], nring = 4 * depth.  (Round 3 kept one event per
+  // slot; a device-side wait for ticket t then waited for whatever batch the slot carried by now -- the chunked scatter waits for
+  // ticket t - depth right after submitting ticket t into the same slot, i.e. it waited for the chunk it had just submitted and
+  // the transfer of the next chunk never overlapped with compute.)  nring is a multiple of depth, so an event that has been
+  // re-recorded belongs to a later batch of the SAME slot's stream, which still covers the older ticket.
+  hipEvent_t done[4 * FOTG_PIPE_MAX_DEPTH];
+  int nring;
   long submitted;
 };
 
@@ -1251,9 +1275,9 @@ void fotg_pipe_destroy(fotg_pipe *q)
     if (q->stream[k]) (void)hipStreamSynchronize(q->stream[k]);
     if (q->ctx[k]) fotg_destroy(q->ctx[k]);
     if (q->ready[k]) (void)hipEventDestroy(q->ready[k]);
-    if (q->done[k]) (void)hipEventDestroy(q->done[k]);
     if (q->stream[k]) (void)hipStreamDestroy(q->stream[k]);
   }
+  for (auto &e : q->done) if (e) (void)hipEventDestroy(e);
   delete q;
 }
 
@@ -1267,18 +1291,24 @@ int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int
     // (INTEGRATION.md section 4).  The library cannot set it any more at this point; say so once.
     static std::atomic<bool> warned{false};
     if (depth > 3 && env_int("GPU_MAX_HW_QUEUES", 4) < depth + 1 && !warned.exchange(true))      // (creation time, not the launch path)
-      fprintf(stderr, "fotg_pipe_create: %d batches in flight need a hardware queue each; set GPU_MAX_HW_QUEUES=%d (or more) in the "
-                      "environment before the HIP runtime loads, otherwise slots share queues and do not overlap\n", depth, depth + 4);
+      fprintf(stderr, "fotg_pipe_create: %d batches in flight need a hardware queue each (+ one for the null stream): GPU_MAX_HW_QUEUES "
+                      "must be >= %d in the environment BEFORE libamdhip64 is loaded (a setenv after that is not seen by the runtime, and "
+                      "not by this check either); otherwise slots share queues and do not overlap\n", depth, depth + 1);
   }
   fotg_pipe *q = new (std::nothrow) fotg_pipe();
   if (!q) return FOTG_ERR_ARG;
   memset((void *)q, 0, sizeof(*q));
-  q->device = device; q->depth = depth;
+  q->device = device; q->depth = depth; q->nring = 4 * depth;
   // the slots' streams first and back to back, so that the runtime spreads them over its hardware queues
   for (int k = 0; k < depth; ++k)
     if (hipStreamCreateWithFlags(&q->stream[k], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&q->ready[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&q->done[k], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&q->ready[k], hipEventDisableTiming) != hipSuccess) {
+      g_last_hip = (int)hipGetLastError();
+      fotg_pipe_destroy(q);
+      return FOTG_ERR_HIP;
+    }
+  for (int k = 0; k < q->nring; ++k)
+    if (hipEventCreateWithFlags(&q->done[k], hipEventDisableTiming) != hipSuccess) {
       g_last_hip = (int)hipGetLastError();
       fotg_pipe_destroy(q);
       return FOTG_ERR_HIP;
@@ -1310,7 +1340,7 @@ static int pipe_submit(fotg_pipe *q, int n, const T *I0, const T *I1, const floa
   }
   const int st = calc_range<T>(c, n, I0, I1, initflow, outflow, q->stream[k]);
   if (st != FOTG_OK) return st;
-  HIPCHK(hipEventRecord(q->done[k], q->stream[k]));
+  HIPCHK(hipEventRecord(q->done[q->submitted % q->nring], q->stream[k]));
   if (ticket) *ticket = q->submitted;
   ++q->submitted;
   return FOTG_OK;
@@ -1331,10 +1361,11 @@ int fotg_pipe_wait(fotg_pipe *q, long ticket, void *stream, int host_wait)
 {
   if (!q || ticket < 0 || ticket >= q->submitted) return FOTG_ERR_ARG;
   ON_DEVICE(q->device);
-  // (a slot that has been reused since carries a later batch of the same stream: waiting for that one covers the ticket)
-  const int k = (int)(ticket % q->depth);
-  if (host_wait) { HIPCHK(hipEventSynchronize(q->done[k])); return stall_status(q->ctx[k]); }
-  HIPCHK(hipStreamWaitEvent((hipStream_t)stream, q->done[k], 0));
+  // (an event re-recorded since -- more than 4 * depth tickets ago -- belongs to a later batch of the same slot's stream: waiting for
+  // that one covers the ticket)
+  const int k = (int)(ticket % q->depth), e = (int)(ticket % q->nring);
+  if (host_wait) { HIPCHK(hipEventSynchronize(q->done[e])); return stall_status(q->ctx[k]); }
+  HIPCHK(hipStreamWaitEvent((hipStream_t)stream, q->done[e], 0));
   return FOTG_OK;
 }
 
@@ -1420,7 +1451,13 @@ long fotg_ctx_counter(fotg_ctx *c, const char *name)
   // non-synchronising: host-side count of stalls reported so far + whether the device has flagged one since (meaningful once
   // the caller has synchronised with the context's stream); "inject_stall" sets the word like a timed-out wait would (tests)
   if (!strcmp(name, "stalls")) return c->stalls + (c->stall_host && *(volatile int *)c->stall_host ? 1 : 0);
-  if (!strcmp(name, "inject_stall")) { if (c->stall_host) *(volatile int *)c->stall_host = 1; return 0; }
+  // the consuming query for callers of the asynchronous entry points (fotg_calc_batch on their own stream, fotg_pipe_wait with
+  // host_wait = 0): AFTER their own synchronisation, 1 = a wait of this context timed out since the last query (the flows
+  // computed since then are not valid; counted in "stalls"), 0 = none.  Clears the flag, so a later stall is seen again and an
+  // old one is never blamed on a later call.
+  if (!strcmp(name, "take_stall")) return stall_status(c) == FOTG_ERR_STALL ? 1 : 0;
+  // test tap, only in contexts created with FOTG_TEST_TAPS=1 in the environment
+  if (!strcmp(name, "inject_stall")) { if (!c->tune.test_taps) return -1; if (c->stall_host) *(volatile int *)c->stall_host = 1; return 0; }
   if (!strcmp(name, "tile_timeouts")) {
     if (!c->tileSync) return 0;
     DevGuard dg(c->device);

@@ -41,6 +41,7 @@ struct VrArgs {
   long c_pair_stride;    // in float4
   long d_pair_stride;    // in float2
   int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows, band_mode, taps;
+  int point;             // FOTG_SOR_POINT: cells hold (A11 + sum psi, A12, b1, b2 | A22 + sum psi, psi_r, psi_b, psi_t), no block inverse
   __host__ __device__ int pix(int i, int j) const { return j * st + i; }
   __host__ __device__ float4 *Cp(int pair) const { return C + (size_t)pair * c_pair_stride; }
   __host__ __device__ float2 *Dp(int pair) const { return D + (size_t)pair * d_pair_stride; }
@@ -391,6 +392,18 @@ __device__ __forceinline__ void data_term_cell(const VrArgs &a, int i, int j, co
   if (j > 0)     { B1 -= vt * p.dxt(); B2 -= vt * p.dyt(); }
   if (j < h - 1) { B1 += vb * p.dxb(); B2 += vb * p.dyb(); }
 
+  if (a.point) {
+    // sor_coupled_slow_but_readable (solver.c:19-72) keeps the system as it is: A11 + sum_dpsis, A12, A22 + sum_dpsis with
+    // sum_dpsis accumulated top, left, bottom, right from 0 (:31-55)
+    float sum = 0.0f;
+    if (j > 0) sum += vt;
+    if (i > 0) sum += hl;
+    if (j < h - 1) sum += vb;
+    if (i < w - 1) sum += hr;
+    c0 = make_float4(A11 + sum, A12, B1, B2);
+    c1 = make_float4(A22 + sum, hr, vb, vt);
+    return;
+  }
   // first sweep of sor_coupled inverts the 2x2 block (solver.c:115-120): dpsis = hl+hr(+vt)(+vb)
   float dps = hl + hr;
   if (j > 0) dps = dps + vt;
@@ -537,6 +550,27 @@ __device__ __forceinline__ float2 sor_update(float2 cur, float4 c0, float4 c1, f
   return r;
 }
 
+// one pixel update of sor_coupled_slow_but_readable (solver.c:28-65): sigma accumulated top, left, bottom, right from 0; du from
+// the OLD dv, dv from the NEW du; cells as data_term_cell builds them with a.point.  Missing neighbours: psi = 0 and a finite
+// value, the skipped terms subtract +-0.  A cell outside the image is all zero (A11 = 0): it stays untouched, like a lane / step
+// that runs with omega = 0.
+__device__ __forceinline__ float2 sor_update_point(float2 cur, float4 c0, float4 c1, float hl, float2 left, float2 top, float2 right, float2 bottom, float omega)
+{
+  const float A11 = c0.x, A12 = c0.y, b1 = c0.z, b2 = c0.w, A22 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
+  float su = 0.0f - vt * top.x, sv = 0.0f - vt * top.y;
+  su = su - hl * left.x;   sv = sv - hl * left.y;
+  su = su - vb * bottom.x; sv = sv - vb * bottom.y;
+  su = su - hr * right.x;  sv = sv - hr * right.y;
+  const float B1 = b1 - su, B2 = b2 - sv;
+  float2 r;
+  r.x = (1.0f - omega) * cur.x + omega / A11 * (B1 - A12 * cur.y);
+  r.y = (1.0f - omega) * cur.y + omega / A22 * (B2 - A12 * r.x);
+  const bool live = omega != 0.f && A11 != 0.f;
+  r.x = live ? r.x : cur.x;
+  r.y = live ? r.y : cur.y;
+  return r;
+}
+
 __device__ __forceinline__ float dpp_wave_shr1(float v)
 {
   // lane L reads lane L-1 (wave_shr:1, GFX9 DPP); lane 0 gets 0 (bound_ctrl)
@@ -550,7 +584,8 @@ __device__ __forceinline__ float dpp_wave_shr1(float v)
 // from lane L-1 by DPP; left values stay in registers; everything else is old data streamed from the skewed arrays
 // P steps ahead through a register ring (coalesced 16-B/8-B loads), so the loop runs at the speed of its
 // ~10-instruction dependency chain, not at memory latency.
-template <int K, int P, int U>
+// POINT: the point update of sor_coupled_slow_but_readable (FOTG_SOR_POINT) in the same dependency order.
+template <int K, int P, int U, bool POINT = false>
 __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float omega)
 {
   const int pair = blockIdx.x, lane = threadIdx.x;
@@ -605,7 +640,8 @@ __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float 
       float2 res[K];
 #pragma unroll
       for (int m = 0; m < K; ++m)
-        res[m] = sor_update(st.own[m], st.c[m][0], st.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], st.nxt[m], st.nxt[m + 1], om);
+        res[m] = POINT ? sor_update_point(st.own[m], st.c[m][0], st.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], st.nxt[m], st.nxt[m + 1], om)
+                       : sor_update(st.own[m], st.c[m][0], st.c[m][1], hl[m], prev[m], m == 0 ? top0 : prev[m - 1], st.nxt[m], st.nxt[m + 1], om);
       float2 *dst = reinterpret_cast<float2 *>(Db + (size_t)((unsigned)s * d_row) + d_lane);
 #pragma unroll
       for (int m = 0; m < K; ++m) dst[m] = res[m];

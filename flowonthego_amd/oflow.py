@@ -211,6 +211,18 @@ class OFClass:
         check(lib().fotg_level_ptr(self._h, which, sl, kind, p, stride))
         return p.value, stride.value
 
+    def take_stall(self):
+        """for callers of the asynchronous entry points (calc_batch and friends return after enqueueing): AFTER their own
+        synchronisation, True = a bounded inter-workgroup wait of this context timed out since the last query (FOTG_ERR_STALL:
+        the flows computed since are not valid; re-submit).  Read-and-clear, does not synchronise."""
+        return bool(lib().fotg_ctx_counter(self._h, b"take_stall"))
+
+    def synchronize(self):
+        """wait for the context's work on the current stream of its device and raise if a stall was flagged"""
+        torch.cuda.current_stream(self.device).synchronize()
+        if self.take_stall():
+            check(5)                                        # FOTG_ERR_STALL
+
     def close(self):
         """OFClass::~OFClass (src/oflow.cpp:147-179)"""
         h = getattr(self, "_h", None)

@@ -71,6 +71,12 @@ class FlowPipeline:
     def synchronize(self):
         check(lib().fotg_pipe_sync(self._h))
 
+    def take_stalls(self):
+        """for callers of wait(ticket, host=False): AFTER their own synchronisation, how many slots report a timed-out
+        inter-workgroup wait since the last query (FOTG_ERR_STALL: the batches computed since are not valid; re-submit).
+        Read-and-clear, does not synchronise."""
+        return sum(int(lib().fotg_ctx_counter(self.context(k), b"take_stall")) for k in range(self.depth))
+
     def context(self, slot):
         h = C.c_void_p()
         check(lib().fotg_pipe_context(self._h, int(slot), h))

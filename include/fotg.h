@@ -28,11 +28,14 @@ extern "C" {
 #define FOTG_ERR_STALL        5   /* a bounded wait between workgroups of the tile solver (levels of more than 96 rows) timed out (preempted or
                                      starved producer): the flow this call produced is NOT valid.  Returned by the entry points that
                                      synchronise with the host -- fotg_calc, fotg_pipe_wait(host_wait = 1), fotg_pipe_sync; callers of
-                                     the asynchronous entry points ask fotg_ctx_counter(ctx, "stalls") after their own synchronisation
-                                     (it does not synchronise).  Re-submit the batch. */
+                                     the asynchronous entry points ask fotg_ctx_counter(ctx, "take_stall") after their own
+                                     synchronisation (it does not synchronise; read-and-clear).  Re-submit the batch. */
 
 #define FOTG_SOR_LEXICOGRAPHIC 0  /* kroeger FDF1.0.1/solver.c:77-421 order (parity mode, default) */
 #define FOTG_SOR_REDBLACK      1  /* red-black ordering of the same 2x2 block update (src/kernels/flowUtil.cu:297-362 ordering) */
+#define FOTG_SOR_POINT         2  /* kroeger FDF1.0.1/solver.c:19-72 sor_coupled_slow_but_readable, the solver of the reference's OpenMP
+                                     build (refine_variational.cpp:202-206), in the order of its serial loop: point update (du from the
+                                     old dv, dv from the new du), no block inverse.  Compatibility mode (levels of <= 1024 rows). */
 
 /* == optparam of kroeger/oflow.h:33-76 / opt_params of src/params.h:23-65 (explicitly set part) */
 typedef struct fotg_params {
@@ -107,7 +110,8 @@ int fotg_calc_sequence_u8(fotg_ctx *ctx, int n_frames, const unsigned char *fram
  * frames; NULL = default stream), or at once with after_stream = FOTG_NO_STREAM (frames already in place; note that an event
  * on a busy stream is only reached when that stream's queue has drained).  The caller keeps I0 / I1 / outflow alive and
  * untouched until the ticket has been waited for.  A pipe is used from one thread at a time (like a context); batches complete
- * in submission order per slot, and waiting for a ticket whose slot has been reused waits for the later batch in that slot. */
+ * in submission order per slot; every ticket has a completion event of its own for the next 4 * depth submissions (a wait for an
+ * older ticket waits for a later batch of the same slot, which covers it). */
 #define FOTG_PIPE_MAX_DEPTH 8
 #define FOTG_NO_STREAM ((void *)(-1))
 typedef struct fotg_pipe fotg_pipe;
@@ -124,6 +128,34 @@ int fotg_pipe_wait(fotg_pipe *pipe, long ticket, void *stream, int host_wait);
 int fotg_pipe_sync(fotg_pipe *pipe);
 /* the engine context of a slot (geometry queries, taps, counters) */
 int fotg_pipe_context(fotg_pipe *pipe, int slot, fotg_ctx **ctx);
+
+/* ---- one process, several GPUs (no reference equivalent: src/run_dense.cpp:277-289 drives one device) ------------
+ * Frame pairs are independent, so a batch of n pairs is cut into contiguous shards -- pair k goes to slot k * ndev / n
+ * (fotg_node_shard: sizes differ by at most one) -- and every slot runs its shard through a pipe of its own (above) on its device,
+ * issued by a host thread of its own; there is no exchange between the GPUs on the data path.  `devices` may name a device more
+ * than once (two slots on one GPU).  max_batch = pairs per pipe submission on ONE device (a shard larger than that runs as
+ * consecutive pieces on consecutive pipe slots), depth = batches in flight per device.  Up to 16 submitted jobs may be waiting to
+ * be waited for (FOTG_ERR_BATCH beyond that).  Results are bit-identical to fotg_calc_batch on the same pairs. */
+#define FOTG_NODE_MAX_DEV 16
+typedef struct fotg_node fotg_node;
+int fotg_node_create(const fotg_params *p, int w_org, int h_org, const int *devices, int ndev, int max_batch, int depth, fotg_node **out);
+void fotg_node_destroy(fotg_node *node);
+/* [begin, begin + count) of the pairs of slot d */
+int fotg_node_shard(int n, int ndev, int d, int *begin, int *count);
+/* resident frames: I0[d], I1[d], outflow[d] = the shard of slot d in the memory of devices[d] (frames / flows laid out as in
+ * fotg_calc_batch; entries of empty shards are ignored).  Returns at once; the frames must be in place (the work starts
+ * immediately) and, like outflow, stay untouched until fotg_node_wait(ticket). */
+int fotg_node_submit(fotg_node *node, int n, const float *const *I0, const float *const *I1, float *const *outflow, long *ticket);
+int fotg_node_submit_u8(fotg_node *node, int n, const unsigned char *const *I0, const unsigned char *const *I1, float *const *outflow, long *ticket);
+/* scatter / gather: I0, I1 (n frames each) and outflow (n flows) live on devices[0].  Slot 0 computes its shard in place; every
+ * other slot pulls its shard over xGMI in chunks of `chunk` <= max_batch pairs (hipMemcpyPeerAsync into depth + 1 staging buffers
+ * on a copy stream of its own), computes chunk t while chunk t + 1 travels, and writes its flows back into `outflow`. */
+int fotg_node_submit_scatter(fotg_node *node, int n, const float *I0, const float *I1, float *outflow, int chunk, long *ticket);
+/* the calling thread waits for job `ticket` (and every job before it) on all devices; FOTG_ERR_STALL as for fotg_pipe_wait */
+int fotg_node_wait(fotg_node *node, long ticket);
+int fotg_node_sync(fotg_node *node);
+int fotg_node_info(const fotg_node *node, int *ndev, int *out_w, int *out_h, int *flow_channels);
+int fotg_node_pipe(fotg_node *node, int slot, fotg_pipe **pipe);
 
 /* Single pair, outflow in HOST memory, synchronous -- the exact shape of the reference call. */
 int fotg_calc(fotg_ctx *ctx, const float *I0, const float *I1, const float *initflow, float *outflow_host);
@@ -205,8 +237,11 @@ int fotg_varref_plane(fotg_ctx *ctx, int pair, const char *name, int level, floa
 int fotg_bench_sor_call(fotg_ctx *ctx, int level, int n, void *stream);
 /* test tap: how often a kernel variant was launched by this process ("sor_stream", "sor_tiles"); -1 for unknown names */
 long fotg_debug_counter(const char *name);
-/* per-context counters.  "stalls" (does NOT synchronise): how many times a bounded inter-workgroup wait of this context timed out,
- * as far as the host has seen (FOTG_ERR_STALL above); "inject_stall" (tests) raises the flag as a timed-out wait would.
+/* per-context counters.  "take_stall" (does NOT synchronise; the query for callers of the asynchronous entry points, AFTER their own
+ * synchronisation): 1 = a bounded inter-workgroup wait of this context timed out since the last query / the last FOTG_ERR_STALL
+ * -- the flows computed since then are not valid --, 0 = none; it clears the flag.  "stalls" (does NOT synchronise, does not
+ * clear): how many such time-outs the host has seen so far (+ 1 while one is pending).  "inject_stall" raises the flag as a timed-out
+ * wait would -- only in contexts created with FOTG_TEST_TAPS=1 in the environment (tests), -1 otherwise.
  * Test tap that synchronises the device: "tile_timeouts" = device-side count of those time-outs of the tile solver since the
  * context was created -- 0 unless something is broken; -1 for unknown names */
 long fotg_ctx_counter(fotg_ctx *ctx, const char *name);

@@ -875,6 +875,29 @@ void dis_sor_coupled_redblack(float *du, float *dv, float *a11, float *a12, floa
           sor_pixel(du, dv, a11, a12, a22, b1, b2, horiz, vert, i, j, w, h, st, omega);
 }
 
+/* FDF1.0.1/solver.c:19-72 sor_coupled_slow_but_readable (SURVEY 8a row a17'): the solver an OpenMP build of the reference
+ * selects (refine_variational.cpp:202-206).  Point update -- du from the old dv, then dv from the NEW du, no block inverse --
+ * in the row-major order of the serial loop (without OpenMP the `parallel for` over rows is a plain loop; with it the rows race,
+ * SURVEY 8a probe).  Neighbour order of the sums: top, left, bottom, right.  a11 / a12 / a22 are NOT modified. */
+void dis_sor_coupled_slow(float *du, float *dv, const float *a11, const float *a12, const float *a22, const float *b1,
+                          const float *b2, const float *horiz, const float *vert, int w, int h, int iterations, float omega)
+{
+  const int st = dis_stride(w);
+  for (int it = 0; it < iterations; ++it)
+    for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) {
+      const int o = j * st + i;
+      float sigma_u = 0.0f, sigma_v = 0.0f, sum_dpsis = 0.0f;
+      if (j > 0)     { sigma_u -= vert[o - st] * du[o - st]; sigma_v -= vert[o - st] * dv[o - st]; sum_dpsis += vert[o - st]; }
+      if (i > 0)     { sigma_u -= horiz[o - 1] * du[o - 1];  sigma_v -= horiz[o - 1] * dv[o - 1];  sum_dpsis += horiz[o - 1]; }
+      if (j < h - 1) { sigma_u -= vert[o] * du[o + st];      sigma_v -= vert[o] * dv[o + st];      sum_dpsis += vert[o]; }
+      if (i < w - 1) { sigma_u -= horiz[o] * du[o + 1];      sigma_v -= horiz[o] * dv[o + 1];      sum_dpsis += horiz[o]; }
+      const float A11 = a11[o] + sum_dpsis, A12 = a12[o], A22 = a22[o] + sum_dpsis;
+      const float B1 = b1[o] - sigma_u, B2 = b2[o] - sigma_v;
+      du[o] = (1.0f - omega) * du[o] + omega / A11 * (B1 - A12 * dv[o]);        /* :63 */
+      dv[o] = (1.0f - omega) * dv[o] + omega / A22 * (B2 - A12 * du[o]);        /* :64, with the du just written */
+    }
+}
+
 /* kroeger/refine_variational.cpp:25-116 (ctor), :118-149 copyimage, :153-241 RefLevelOF */
 void dis_varref(const float *I0, const float *I1, int w, int h, int lvl, const dis_params *p,
                 float *flow, int sor_mode)
@@ -910,6 +933,7 @@ void dis_varref(const float *I0, const float *I1, int w, int h, int lvl, const d
     dis_sub_laplacian(b1, wx, sh, sv, w, h);
     dis_sub_laplacian(b2, wy, sh, sv, w, h);
     if (sor_mode == 0) dis_sor_coupled(du, dv, a11, a12, a22, b1, b2, sh, sv, w, h, p->tv_solverit, p->tv_sor);
+    else if (sor_mode == 2) dis_sor_coupled_slow(du, dv, a11, a12, a22, b1, b2, sh, sv, w, h, p->tv_solverit, p->tv_sor);
     else dis_sor_coupled_redblack(du, dv, a11, a12, a22, b1, b2, sh, sv, w, h, p->tv_solverit, p->tv_sor);
     for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) {
       int o = j * st + i; uu[o] = wx[o] + du[o]; vv[o] = wy[o] + dv[o];

@@ -124,12 +124,15 @@ void dis_sor_coupled(float *du, float *dv, float *a11, float *a12, float *a22, c
                      const float *b2, const float *horiz, const float *vert, int w, int h,
                      int iterations, float omega);
 /* red-black ordering of the same 2x2 block update (throughput mode of the engine; NOT reference) */
+/* FDF1.0.1/solver.c:19-72 sor_coupled_slow_but_readable, serial rows (a11 / a12 / a22 are read only) */
+void dis_sor_coupled_slow(float *du, float *dv, const float *a11, const float *a12, const float *a22, const float *b1,
+                          const float *b2, const float *horiz, const float *vert, int w, int h, int iterations, float omega);
 void dis_sor_coupled_redblack(float *du, float *dv, float *a11, float *a12, float *a22,
                               const float *b1, const float *b2, const float *horiz,
                               const float *vert, int w, int h, int iterations, float omega);
 /* whole VarRefClass ctor: I0/I1 padded level images, flow w x h x 2 interleaved, in place */
 void dis_varref(const float *I0, const float *I1, int w, int h, int lvl, const dis_params *p,
-                float *flow, int sor_mode /*0 lexicographic (reference), 1 red-black*/);
+                float *flow, int sor_mode /*0 lexicographic sor_coupled (reference default build), 1 red-black, 2 sor_coupled_slow_but_readable (reference OpenMP build, serial)*/);
 /* stereo depth (SELECTMODE 2): compute_data_DE (opticalflow_aux.c:446-540), sor_coupled_slow_but_readable_DE
  * (solver.c:428-466, serial = lexicographic Gauss-Seidel) and RefLevelDE (refine_variational.cpp:243-330);
  * flow is w x h x 1, camlr selects the sign clamp of the update (:299-314) */

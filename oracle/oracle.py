@@ -81,6 +81,7 @@ def lib():
         L.dis_compute_data.argtypes = [f32p] * 16 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
         L.dis_sor_coupled.argtypes = [f32p] * 9 + [C.c_int, C.c_int, C.c_int, C.c_float]
         L.dis_sor_coupled_redblack.argtypes = L.dis_sor_coupled.argtypes
+        L.dis_sor_coupled_slow.argtypes = L.dis_sor_coupled.argtypes
         _LIB = L
     return _LIB
 

@@ -768,7 +768,8 @@ def test_bench_distributed_leg_on_one_gpu():
     main = [l for l in lines if "metric" in l][0]
     sg = [l for l in lines if "scatter_gather" in l][0]["scatter_gather"]
     assert main["n_gpus"] == 1 and main["value"] > 0 and len(main["ms_per_step_per_rank"]) == 1 and main["pipeline_matches_single_context"]
-    assert sg["gathered_shape"] == [16, 68, 120, 2] and sg["end_to_end_pairs_per_s"] > 0
+    assert sg["gathered_shape"] == [16, 68, 120, 2] and sg["end_to_end_pairs_per_s"] > 0 and sg["gathered_flows_match_single_context"]
+    assert main["rccl_ranks"] == 1 and main["rank_placement"][0]["pci_bus_id"]
 
 
 def test_hoisted_division_is_the_ieee_division(tmp_path):
@@ -958,7 +959,7 @@ def test_context_lifecycle_and_host_threads():
     assert np.array_equal(serial[0][0], O.flow(O.pad_frame(pairs[0][0], pr.sc_f), O.pad_frame(pairs[0][1], pr.sc_f), pr, 0))
 
 
-def test_stalled_wait_is_reported_by_the_product_api():
+def test_stalled_wait_is_reported_by_the_product_api(monkeypatch):
     """a bounded inter-workgroup wait that times out raises a word in pinned host memory; the entry points that synchronise
     with the host return FOTG_ERR_STALL once (the flow of that call is not valid), then the context is usable again"""
     import ctypes as C
@@ -968,6 +969,10 @@ def test_stalled_wait_is_reported_by_the_product_api():
     w, h = 512, 256
     op = F.operating_point(2, w, 1)
     ip = F.img_params(width=w, height=h, padding=8)
+    plain = OFClass(op, ip, max_batch=1)
+    assert L.fotg_ctx_counter(plain._h, b"inject_stall") == -1            # the tap is dead in an ordinary context
+    plain.close()
+    monkeypatch.setenv("FOTG_TEST_TAPS", "1")                             # read once at fotg_create
     ofc = OFClass(op, ip, max_batch=1)
     a, b = synth_pair(h, w, seed=5)
     A, B = dev(a), dev(b)
@@ -982,6 +987,15 @@ def test_stalled_wait_is_reported_by_the_product_api():
     assert b"timed out" in L.fotg_strerror(5)
     assert L.fotg_calc(*args) == 0 and np.array_equal(host, good)
     assert L.fotg_ctx_counter(ofc._h, b"stalls") == 1
+    # asynchronous callers: the consuming query sees every stall once, and a stale flag is never blamed on a later call
+    out = ofc.calc_batch(A[None], B[None])
+    torch.cuda.synchronize()
+    assert ofc.take_stall() is False
+    L.fotg_ctx_counter(ofc._h, b"inject_stall")
+    assert ofc.take_stall() is True and ofc.take_stall() is False and L.fotg_ctx_counter(ofc._h, b"stalls") == 2
+    L.fotg_ctx_counter(ofc._h, b"inject_stall")
+    assert ofc.take_stall() is True                                       # a second stall is seen again
+    assert L.fotg_calc(*args) == 0 and np.array_equal(host, good)         # and the next synchronous call is not blamed for it
     pipe = FlowPipeline(op, ip, max_batch=1, depth=2)
     t, _ = pipe.submit(A[None], B[None])
     L.fotg_ctx_counter(pipe.context(0), b"inject_stall")
@@ -992,6 +1006,11 @@ def test_stalled_wait_is_reported_by_the_product_api():
     with pytest.raises(F.FotgError):
         pipe.synchronize()
     pipe.synchronize()
+    t, _ = pipe.submit(A[None], B[None])
+    pipe.wait(t, host=False)                                              # device-side wait: the host checks after its own sync
+    torch.cuda.synchronize()
+    L.fotg_ctx_counter(pipe.context(0), b"inject_stall"); L.fotg_ctx_counter(pipe.context(1), b"inject_stall")
+    assert pipe.take_stalls() == 2 and pipe.take_stalls() == 0
     pipe.close(); ofc.close()
 
 

@@ -189,3 +189,53 @@ def test_launch_path_reads_no_environment():
         assert "getenv" not in open(os.path.join(ROOT, "flowonthego_amd", "csrc", hdr)).read()
     mk = [l for l in open(os.path.join(ROOT, "flowonthego_amd", "csrc", "Makefile")).read().splitlines() if not l.lstrip().startswith("#")]
     assert not any("FOTG_DEBUG" in l for l in mk)
+
+
+# ---- bench.py as the N > 1 entry point (`--gpus` was parsed and never read) ----------------------
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fotg_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_gpus_flag_launches_one_rank_per_gpu():
+    """`python bench.py --gpus N` without a launcher starts `python -m torch.distributed.run --nproc-per-node N ... bench.py
+    --gpus N ...` as a child (stub here), relays its exit code, and refuses N > visible GPUs with a non-zero exit"""
+    import types
+    B = _load_bench()
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+
+    rc = B.self_launch(4, ["--gpus", "4", "--steps", "5"], device_count=lambda: 8, run=fake_run)
+    assert rc == 7                                                     # the child's exit code is the launcher's
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    with pytest.raises(SystemExit) as e:
+        B.self_launch(8, ["--gpus", "8"], device_count=lambda: 2, run=fake_run)
+    assert e.value.code != 0
+
+
+def test_bench_gpus_flag_cannot_print_a_line_for_another_n():
+    """on this box (no GPU): `--gpus 2` exits non-zero with a clear message (0 GPUs visible), and a rank whose launcher started
+    another number of ranks than --gpus (WORLD_SIZE=1, --gpus 2) exits non-zero BEFORE touching a GPU -- neither prints a
+    metric line"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and '"metric"' not in r.stdout
+        assert json.loads(r.stdout.strip().splitlines()[-1])["requested_gpus"] == 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and '"metric"' not in r.stdout
