@@ -65,6 +65,7 @@ struct FotgTune {
   int vr_first_data; // FOTG_VR_FIRST_DATA: 0 = the first inner iteration's data term in a launch of its own (not in the set-up launch)
   int pyr_split;    // FOTG_PYR_SPLIT: launches the base pyramid kernel of a batch is cut into (1 = one launch)
   int vr_fused_nt;  // FOTG_VR_FUSED_NT: threads per workgroup of the fused per-level kernel on gray levels of 1025..2048 pixels (512 / 1024)
+  int lk_shw;       // FOTG_LK_SHW: shared LDS window of a wave's four patches: -1 automatic (RGB patches of 8 x 8 and more), 0 off, 1 on; 2 / 3 with FOTG_TEST_TAPS: on + some / all rows on the global-memory path
   int test_taps;    // FOTG_TEST_TAPS: 1 = fotg_ctx_counter(ctx, "inject_stall") is live (tests of the FOTG_ERR_STALL reporting)
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
@@ -244,6 +245,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_fused_nt = env_int("FOTG_VR_FUSED_NT", 1024);
   c->tune.pyr_split = env_int("FOTG_PYR_SPLIT", 1);
   c->tune.test_taps = env_int("FOTG_TEST_TAPS", 0);
+  c->tune.lk_shw = env_int("FOTG_LK_SHW", -1);
   if (hipHostMalloc((void **)&c->stall_host, 64, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void **)&c->stall_dev, c->stall_host, 0) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; }
   memset(c->stall_host, 0, 64);
@@ -563,6 +565,7 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   a.trace = gs.trace_host ? c->trace_dev[l] : nullptr;
   a.g = g;
   a.max_iter = c->p.max_iter; a.min_iter = c->p.min_iter; a.patnorm = c->p.patnorm;
+  a.shw_test = (c->tune.test_taps && c->tune.lk_shw >= 2) ? c->tune.lk_shw - 1 : 0;
   a.costfct = c->p.costfct; a.huber_bsq = c->p.normoutlier * c->p.normoutlier; a.huber_2bsq = a.huber_bsq * 2.0f;   // kroeger/oflow.cpp:106-107
   a.dp_thresh_sq = c->p.dp_thresh * c->p.dp_thresh;                 // kroeger/oflow.cpp:88
   a.dr_thresh = c->p.dr_thresh; a.res_thresh = c->p.res_thresh;
@@ -576,7 +579,13 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   }
   // four patches per wave, one wave per workgroup (lk.hip.h)
   dim3 block(64), grid((g.nop + FOTG_LK_PPW - 1) / FOTG_LK_PPW, n);
-#define LK(PS_, NOC_) lk_kernel<PS_, NOC_, false><<<grid, block, 0, s>>>(a)
+  // the operating points' L2 cost: specialised kernels, with one shared LDS area per wave where private windows limit occupancy
+  // (measured: RGB patches -- two to three waves per SIMD with private windows -- gain 9-19 % per level; gray ones are bound by
+  // the issue rate of their instruction stream at any occupancy and lose the time of the packing plan: docs/EXPERIMENTS.md)
+  const bool shw = c->tune.lk_shw < 0 ? (c->noc == 3 && c->ps >= 8) : c->tune.lk_shw != 0;
+#define LK(PS_, NOC_) do { if (a.costfct == 0 && shw) lk_kernel<PS_, NOC_, false, true, true><<<grid, block, 0, s>>>(a); \
+                           else if (a.costfct == 0) lk_kernel<PS_, NOC_, false, true><<<grid, block, 0, s>>>(a); \
+                           else lk_kernel<PS_, NOC_, false><<<grid, block, 0, s>>>(a); } while (0)
 #define LKD(PS_, NOC_) lk_kernel<PS_, NOC_, true><<<grid, block, 0, s>>>(a)
   if (c->p.depth) {
     switch (c->ps * 10 + c->noc) {

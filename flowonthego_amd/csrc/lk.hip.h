@@ -39,6 +39,7 @@ struct LkArgs {
   LevelGeom g;
   int camlr;                          // depth mode: 0 displacement <= 0 (forward grid), 1 displacement >= 0 (oflow.cpp:153,157)
   int max_iter, min_iter, patnorm, costfct;
+  int shw_test;                       // test tap of the shared-window kernels (FOTG_LK_SHW=2 / 3 with FOTG_TEST_TAPS=1): 1 = rows 1, 3 read global memory, 2 = all rows
   float dp_thresh_sq, dr_thresh, res_thresh, outlier, outlier_sq, huber_bsq, huber_2bsq;
 };
 
@@ -62,8 +63,21 @@ __device__ __forceinline__ float div_nv(float x)
   return q;
 }
 
-template <int PS, int NOC, bool DEPTH = false>
-__global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
+// L2: the cost function is the L2 one of every operating point (costfct 0), known at compile time -- the per-element switch
+// of the general kernel and the code of the two other cost functions are gone from the loop.
+//
+// SHW: ONE LDS area for the wave's four windows.  The four patches of a wave are consecutive ids = vertical neighbours `steps`
+// pixels apart (patchgrid.cpp:57-66), so their reachable windows overlap by 3/4 and more; private windows cost 4 (2ps+4)^2 floats
+// per wave (12.5 KB at ps 12: three waves per SIMD), the union of four neighbours (2ps+4) x (2ps+4 + 3 steps).  The windows are
+// packed greedily, in row order, into at most two groups of overlapping windows (a wave whose ids wrap from the bottom of one
+// grid column to the top of the next, or that straddles a motion boundary, has two) inside SWW x RB pixels.  A window that
+// does not fit (starts further apart than the slack in x, or a third group) is not staged: that patch reads its taps from
+// global memory with the same clamping -- same values, only slower, and rare.
+// waves per SIMD the register allocation of the shared-window kernels must leave room for (what their LDS area allows)
+constexpr int lk_min_waves(int nv, bool shw) { return !shw ? 1 : nv == 48 ? 5 : nv <= 64 ? 6 : nv <= 144 ? 5 : nv <= 192 ? 3 : 1; }
+
+template <int PS, int NOC, bool DEPTH = false, bool L2 = false, bool SHW = false>
+__global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kernel(LkArgs a)
 {
   constexpr int NPIX = PS * PS;
   constexpr int NSL = NPIX / 16;                     // pixels per lane
@@ -71,8 +85,11 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
   constexpr int NV = NPIX * NOC;
   constexpr int PAD = PS;
   constexpr int WIN = 2 * PS + 4;                    // window edge, see the column bound below
+  constexpr int SWW = WIN + 4;                       // SHW: width of the shared area (slack for starts that differ in x)
+  constexpr int RB = 2 * WIN + 8;                    // SHW: rows of the shared area (two groups + 8 rows of vertical spread)
+  constexpr int WS = SHW ? SWW : WIN;                // row stride of a patch's window, pixels
   static_assert(NPIX % 16 == 0, "a patch fills the 16 lanes of its row");
-  __shared__ float win_all[FOTG_LK_PPW][WIN * WIN * NOC];
+  __shared__ float win_all[SHW ? SWW * RB * NOC : FOTG_LK_PPW * WIN * WIN * NOC];
   const int lane = threadIdx.x & 63, row = lane >> 4, j = lane & 15;
   const WgId wg = xcd_local_wg();                    // all patches of a pair on the XCD of its refinement workgroup
   const int ipw = wg.x * FOTG_LK_PPW;                // first patch of this wave
@@ -111,14 +128,19 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
   const int gx = IP / a.g.noph, gy = IP % a.g.noph;
   const float RX = (float)(gx * a.g.steps + a.g.offw), RY = (float)(gy * a.g.steps + a.g.offh);
   float T[NE], Tx[NE], Ty[NE], r[NE];                 // (the patch weights written at the end are |r|)
-  int poff[NSL];                                      // window offset of the lane's pixels relative to the patch centre
+  // window offset of the lane's pixels relative to the patch centre: pixel q = 16 s + j sits 16 PER / PS rows below pixel
+  // q - 16 PER in the same column (PER = slots after which 16 s is a multiple of the patch width), so PER per-lane offsets and a
+  // compile-time row term (an immediate of the LDS read) cover all slots
+  constexpr int PER = PS == 12 ? 3 : 1, PROWS = 16 * PER / PS;
+  static_assert((16 * PER) % PS == 0 && NSL % PER == 0, "slot period");
+  int pu[PER];
   {
     const int px = (int)RX + PAD, py = (int)RY + PAD;              // pt_ref is integer valued: round() is exact
 #pragma unroll
     for (int s = 0; s < NSL; ++s) {
       const int q = s * 16 + j;
       const int offy = q / PS - PS / 2, offx = q % PS - PS / 2;
-      poff[s] = (offy * WIN + offx) * NOC;
+      if (s < PER) pu[s] = ((offy - 1) * WS + offx - 1) * NOC;      // the upper left tap: the lowest address of the four
       const size_t idx = ((size_t)(px + offx) + (size_t)(py + offy) * tw) * NOC;
 #pragma unroll
       for (int c = 0; c < NOC; ++c) {
@@ -147,13 +169,65 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
   // Stage the reachable window of I1 in LDS.  Every evaluated position is within ps/2 of the start in x and y, so the
   // bilinear taps span columns floor(stx)-ps-1 .. floor(stx)+ps+2 (padded coordinates: + PAD); rows likewise.
   const int WX0 = (int)floorf(STX) + PAD - PS - 1, WY0 = (int)floorf(STY) + PAD - PS - 1;
-  float *const win = win_all[row];
-  if (START_OK) {
+  const float *win = win_all + row * (WIN * WIN * NOC);
+  bool USEG = false;                                     // SHW: this row's window is not staged, its taps come from global memory
+  if constexpr (SHW) {
+    // wave-uniform plan (all scalar): greedy packing of the starting rows' windows, in row order, into <= 2 groups A, B
+    unsigned need;
+    {
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(START_OK);
+      need = (unsigned)((b & 1) | ((b >> 15) & 2) | ((b >> 30) & 4) | ((b >> 45) & 8));
+      if (a.shw_test == 1) need &= 5u;                   // test tap: rows 1 and 3 take the global-memory path
+      if (a.shw_test == 2) need = 0;                     // test tap: every row takes it
+    }
+    int xa0 = 0, xa1 = 0, ya0 = 0, ya1 = 0, xb0 = 0, xb1 = 0, yb0 = 0, yb1 = 0, ng = 0;
+    unsigned staged = 0, grp1 = 0;                       // bit r: row r is staged / sits in group B
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int wxr = __builtin_amdgcn_readlane(WX0, 16 * r4), wyr = __builtin_amdgcn_readlane(WY0, 16 * r4);
+      if (!((need >> r4) & 1)) continue;
+      const bool inB = ng == 2;
+      const int cx0 = inB ? xb0 : xa0, cx1 = inB ? xb1 : xa1, cy0 = inB ? yb0 : ya0, cy1 = inB ? yb1 : ya1;
+      const int nx0 = min(cx0, wxr), nx1 = max(cx1, wxr + WIN), ny0 = min(cy0, wyr), ny1 = max(cy1, wyr + WIN);
+      const int ha = ya1 - ya0;
+      const bool fit = ng > 0 && nx1 - nx0 <= SWW && (inB ? ha : 0) + (ny1 - ny0) <= RB;
+      const bool fresh = !fit && (ng == 0 || (ng == 1 && ha + WIN <= RB));
+      if (fit) {
+        if (inB) { xb0 = nx0; xb1 = nx1; yb0 = ny0; yb1 = ny1; } else { xa0 = nx0; xa1 = nx1; ya0 = ny0; ya1 = ny1; }
+      } else if (fresh) {
+        if (ng == 0) { xa0 = wxr; xa1 = wxr + WIN; ya0 = wyr; ya1 = wyr + WIN; } else { xb0 = wxr; xb1 = wxr + WIN; yb0 = wyr; yb1 = wyr + WIN; }
+        ++ng;
+      }
+      if (fit || fresh) { staged |= 1u << r4; if (ng == 2) grp1 |= 1u << r4; }
+    }
+    const int base1 = ya1 - ya0;                         // first LDS row of group B
+    int woff = 0;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int wxr = __builtin_amdgcn_readlane(WX0, 16 * r4), wyr = __builtin_amdgcn_readlane(WY0, 16 * r4);
+      const bool b = (grp1 >> r4) & 1;
+      const int o = (((b ? base1 : 0) + wyr - (b ? yb0 : ya0)) * SWW + (wxr - (b ? xb0 : xa0))) * NOC;
+      woff = row == r4 ? o : woff;
+    }
+    win = win_all + woff;
+    USEG = START_OK && !((staged >> row) & 1);
+    for (int g = 0; g < ng; ++g) {
+      const int fy0 = g ? yb0 : ya0, fx0 = g ? xb0 : xa0;
+      const int cells = (g ? yb1 - yb0 : base1) * SWW, lbase = (g ? base1 : 0) * SWW;
+      for (int t = lane; t < cells; t += 64) {
+        const int sy = t / SWW, sx = t - sy * SWW;
+        const size_t src = ((size_t)clampi(fy0 + sy, a.g.th) * tw + clampi(fx0 + sx, tw)) * NOC;
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) win_all[(lbase + t) * NOC + c] = I1[src + c];
+      }
+    }
+  } else if (START_OK) {
+    float *const wdst = win_all + row * (WIN * WIN * NOC);
     for (int t = j; t < WIN * WIN; t += 16) {
       const int wy = t / WIN, wx = t - wy * WIN;
       const size_t src = ((size_t)clampi(WY0 + wy, a.g.th) * tw + clampi(WX0 + wx, tw)) * NOC;
 #pragma unroll
-      for (int c = 0; c < NOC; ++c) win[t * NOC + c] = I1[src + c];
+      for (int c = 0; c < NOC; ++c) wdst[t * NOC + c] = I1[src + c];
     }
   }
   // the window is filled by the lanes of the row and read by all of them: keep the compiler (which reasons per thread) from
@@ -175,6 +249,10 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
     H00 = (float)((double)H00 + 1e-10);
     H11 = (float)((double)H11 + 1e-10);
   }
+  if (a.hes && VALID && j == 0) {                        // (test tap; written here so that the three sums do not live through the loop)
+    float *hp = a.hes + ((size_t)pair * a.g.nop + IP) * 3;
+    hp[0] = H00; hp[1] = H01; hp[2] = H11;
+  }
   // Cholesky factor of the (constant) Hessian, hoisted out of the loop: same values every iteration
   const float L00 = sqrtf(H00);
   const float L10 = DEPTH ? 0.f : H01 / L00;
@@ -194,22 +272,50 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
   // ---- OptimizeComputeErrImg (:264-284) for the rows that are still running: bilinear query patch (:335-402), mean,
   //      residual, and the three sums the patch needs next -- the two projections on the steepest-descent images
   //      (:178-179, used by the NEXT update) and the L1 residual (:278)
+  // RC: the residual does not live across the loop; it is evaluated once more at the final position for the patch weights
+  // (the same position gives the same bits).  One evaluation in max_iter + 1 more, nine registers and their copies at the loop
+  // head less: for the 128-iteration operating points' 12 x 12 patches.
+  constexpr bool RC = L2 && !SHW && NSL >= 9;
   float B0 = 0.f, B1 = 0.f;
-  auto eval = [&]() {
+  auto residual = [&](float (&rr)[NE]) {
     const int pos2 = (int)floorf(PTX), pos3 = (int)floorf(PTY);
     const int pos0 = (int)ceilf(PTX + .00001f) + PAD - WX0, pos1 = (int)ceilf(PTY + .00001f) + PAD - WY0;   // window coordinates
     const float r0 = PTX - (float)pos2, r1 = PTY - (float)pos3;
     const float we0 = r0 * r1, we1 = (1 - r0) * r1, we2 = r0 * (1 - r1), we3 = (1 - r0) * (1 - r1);
-    const int iab = (pos1 * WIN + pos0) * NOC;
+    const int iab = (pos1 * WS + pos0) * NOC;
     float q[NE];
+    if (SHW && USEG) {
+      // this row's window is not in LDS (see SHW above): the same four taps from the level image, clamped like the staged copy
+#pragma unroll 1
+      for (int s = 0; s < NSL; ++s) {
+        const int qq = s * 16 + j;
+        const int ax = pos0 + WX0 + qq % PS - PS / 2, ay = pos1 + WY0 + qq / PS - PS / 2;
+        const int x1 = clampi(ax, tw), x0 = clampi(ax - 1, tw), y1 = clampi(ay, a.g.th), y0 = clampi(ay - 1, a.g.th);
 #pragma unroll
-    for (int s = 0; s < NSL; ++s) {
-      const int ia = iab + poff[s];
-      const int ic = ia - WIN * NOC;
+        for (int c = 0; c < NOC; ++c) {
+          const float va = I1[((size_t)y1 * tw + x1) * NOC + c], vb = I1[((size_t)y1 * tw + x0) * NOC + c];
+          const float vc = I1[((size_t)y0 * tw + x1) * NOC + c], vd = I1[((size_t)y0 * tw + x0) * NOC + c];
+          const float v = we0 * va + we1 * vb + we2 * vc + we3 * vd;
 #pragma unroll
-      for (int c = 0; c < NOC; ++c) {
-        const float va = win[ia + c], vb = win[ia - NOC + c], vc = win[ic + c], vd = win[ic - NOC + c];
-        q[s * NOC + c] = we0 * va + we1 * vb + we2 * vc + we3 * vd;
+          for (int s2 = 0; s2 < NSL; ++s2) if (s2 == s) q[s2 * NOC + c] = v;      // (register array: constant indices only)
+        }
+      }
+    } else {
+      // (the bases are made opaque: the compiler otherwise folds the window-centre constants into every tap's address and then
+      // needs one address add per tap -- 18 at ps 12 -- instead of the 8-bit offset fields of the LDS reads)
+      const float *tps[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) { int ib = iab + pu[u]; asm volatile("" : "+v"(ib)); tps[u] = win + ib; }
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) {
+        // taps at non-negative compile-time offsets from one per-lane base per slot class: immediates of the LDS reads
+        const float *tp = tps[s % PER];
+        const int o = (s / PER) * (PROWS * WS * NOC);
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) {
+          const float vd = tp[o + c], vc = tp[o + NOC + c], vb = tp[o + WS * NOC + c], va = tp[o + WS * NOC + NOC + c];
+          q[s * NOC + c] = we0 * va + we1 * vb + we2 * vc + we3 * vd;
+        }
       }
     }
     if (a.patnorm > 0) {
@@ -222,16 +328,22 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       float d = q[e] - T[e];                               // :230-236 L2: the difference image itself
+      if constexpr (L2) { rr[e] = d; continue; }
       if (a.costfct == 1) d = copysignf(sqrtf(fabsf(d)), d);                                      // :238-246 L1
       else if (a.costfct == 2) d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / a.huber_bsq) - 1.0f) * a.huber_2bsq), d);   // :247-261
-      r[e] = d;
+      rr[e] = d;
     }
-    B0 = row_allsum(lane_dot(Tx, r));
-    if constexpr (!DEPTH) B1 = row_allsum(lane_dot(Ty, r));
+  };
+  auto eval = [&]() {
+    float rl[NE];
+    float (&rr)[NE] = RC ? rl : r;
+    residual(rr);
+    B0 = row_allsum(lane_dot(Tx, rr));
+    if constexpr (!DEPTH) B1 = row_allsum(lane_dot(Ty, rr));
     const float dpn = DP0 * DP0 + DP1 * DP1;             // :272
     if (CNT == 1) DPN_INIT = dpn;
     MARES_OLD = MARES;
-    MARES = div_nv<NV>(row_allsum(lane_sum_abs(r)));     // :278
+    MARES = div_nv<NV>(row_allsum(lane_sum_abs(rr)));    // :278
     // :279-282 (the two rate tests only matter once cnt >= min_iter)
     bool go = (CNT < a.max_iter) & (MARES > a.res_thresh);
     if (go && CNT >= a.min_iter) go = (dpn / DPN_INIT >= a.dp_thresh_sq) & (MARES / MARES_OLD <= a.dr_thresh);
@@ -289,17 +401,19 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
   }
 
   // ---- results ----
+  if constexpr (RC) { if (START_OK) residual(r); }
   if (!VALID) return;
-  const size_t pb = (size_t)pair * a.g.nop + IP;
-  if (j == 0) {
+  size_t pb = (size_t)pair * a.g.nop + IP;
+  int jj = j;
+  asm volatile("" : "+v"(pb), "+v"(jj));                 // (keeps the store addresses / element indices from being formed before the loop and held across it)
+  if (jj == 0) {
     a.p_iter[pb * 2] = P0;
     a.p_iter[pb * 2 + 1] = P1;
     if (a.cnt) a.cnt[pb] = CNT;
-    if (a.hes) { a.hes[pb * 3] = H00; a.hes[pb * 3 + 1] = H01; a.hes[pb * 3 + 2] = H11; }
   }
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
-    const size_t e = pb * NV + (size_t)(s * 16 + j) * NOC;
+    const size_t e = pb * NV + (size_t)(s * 16 + jj) * NOC;
 #pragma unroll
     for (int c = 0; c < NOC; ++c) {
       a.pweight[e + c] = fabsf(r[s * NOC + c]);

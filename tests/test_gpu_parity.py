@@ -168,11 +168,14 @@ def test_varref_golden_reference_vectors(noc):
         assert np.array_equal(out[..., 0], c["out_x"]) and np.array_equal(out[..., 1], c["out_y"]), name
 
 
-@pytest.mark.parametrize("case,op_point,sor_mode", [("alley", 2, 0), ("alley", 2, 1), ("alley_rgb", 2, 0),
+@pytest.mark.parametrize("case,op_point,sor_mode", [("alley", 2, 0), ("alley", 2, 1), ("alley", 2, 2), ("synth_rgb", 2, 2), ("synth_odd", 3, 2), ("alley_rgb", 2, 0),
                                                     ("synth_odd", 3, 0), ("synth_odd", 1, 0), ("synth_rgb", 2, 0),
                                                     ("synth_rgb_fast", 2, 0), ("synth_rgb_lv3", 1, 0)])
 def test_end_to_end_parity(case, op_point, sor_mode, alley):
-    """OFClass::calc on original (unpadded) frames == oracle pipeline, finest-scale flow and full-resolution flow"""
+    """OFClass::calc on original (unpadded) frames == oracle pipeline, finest-scale flow and full-resolution flow.
+    sor_mode 0 = sor_coupled (the reference's default build: the parity mode), 1 = red-black (not reference-equivalent),
+    2 = sor_coupled_slow_but_readable (SURVEY row a17', the reference's OpenMP-build solver in serial order; the oracle's
+    restatement is pinned == against the reference library in tests/test_oracle.py)"""
     F, OFClass, _, O = _mods()
     f0, f1, noc = frames(case, alley)
     h, w = f0.shape[:2]
@@ -189,6 +192,28 @@ def test_end_to_end_parity(case, op_point, sor_mode, alley):
     assert np.array_equal(full, O.upsample_crop(ref, p.sc_l, padw, padh, w, h))
     # a second call on the same object gives the same answer (state is reset per call)
     assert np.array_equal(ofc.calc(dev(f0), dev(f1)).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("shw", ["0", "1", "2", "3"])
+def test_lk_shared_window_variants(shw, alley, monkeypatch):
+    """the LK kernel with ONE shared LDS area for a wave's four windows (automatic for patches of >= 144 values): forced off (0)
+    and on (1) for every patch size, and with some (2) / all (3) rows of every wave on the global-memory path that serves windows
+    which do not fit the shared area -- the same bits as the oracle in every variant, patch sizes 8 and 12, gray and RGB,
+    including levels whose patch columns are shorter than a wave (ids wrap between columns: two groups)"""
+    F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_LK_SHW", shw)
+    monkeypatch.setenv("FOTG_TEST_TAPS", "1")
+    for case, op_point in (("alley", 2), ("synth_rgb", 2), ("synth_odd", 3), ("synth_odd", 4)):
+        f0, f1, noc = frames(case, alley)
+        h, w = f0.shape[:2]
+        op = F.operating_point(op_point, w, noc)
+        op.grad_descent_iter = min(op.grad_descent_iter, 24)
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+        out = ofc.calc_batch(torch.stack([dev(f0), dev(f1)]), torch.stack([dev(f1), dev(f0)])).cpu().numpy()
+        p = oracle_params(O, op)
+        assert np.array_equal(out[0], O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (shw, case, op_point)
+        assert np.array_equal(out[1], O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0)), (shw, case, op_point)
+        ofc.close()
 
 
 @pytest.mark.parametrize("path", ["1", "2"])
