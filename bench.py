@@ -23,7 +23,15 @@ Extra objects in the JSON line:
   stage_ms      per-stage GPU time of one step (each stage alone between HIP events); time_dominant_stage names the
                 largest
   cpu_baseline  the CPU oracle (oracle/, a scalar port of the reference's kroeger/ path) timed on this box's host
-                cores on a bounded sample of the same workload (rank 0, N = 1 only)
+                cores on a bounded sample of the same workload (rank 0, N = 1 only); value = the flow-only all-core rate
+  single_pair_no_refine, config_4k_op4   BASELINE configs[1] and configs[3], each with its own roofline object(s)
+  rgb_frames    the same batch as 3-channel frames (the layout the reference's src/ path feeds) + the roofline of its pyramid kernel
+  redblack      the same batch with red-black SOR (value + distance from the lexicographic result)
+  sequence_mode, u8_frames   the video entry point and 8-bit input
+  rccl_ranks, rank_placement   how many ranks RCCL connected and which GPU (PCI bus id) each one used
+
+--gpus N > 1 without a launcher: this process starts `python -m torch.distributed.run --nproc-per-node N ... bench.py` as a
+child (before touching the GPU) and relays its output and exit code; under a launcher every rank checks WORLD_SIZE == N.
 """
 import argparse
 import ctypes as C
@@ -46,9 +54,11 @@ sys.path.insert(0, ROOT)
 W, H, OP_POINT = 1920, 1080, 2
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak
-TRAFFIC_FILE = "r03_pmc_traffic.json" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json"
-TRAFFIC_NOTE = ("HBM bytes per launch from profiles/%s (separate rocprofv3 --pmc passes of this command, gfx950 FETCH_SIZE correction) -- "
-                "NOT measured in this run" % TRAFFIC_FILE)
+TRAFFIC_FILE = next((f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+                     if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f))), "r02_pmc_traffic.json")
+TRAFFIC_NOTE = ("HBM bytes per launch from profiles/%s (separate rocprofv3 --pmc passes of this command; bytes = 2 x FETCH_SIZE + WRITE_SIZE: the "
+                "x 2 is the guide's gfx950 correction, established for 16-byte-per-lane streaming reads (pyr_base_kernel) -- kernels that read "
+                "with dword loads (lk, densify, vr_data) may be OVERSTATED by up to 2x on the read side) -- NOT measured in this run" % TRAFFIC_FILE)
 
 
 def synth_batch(n, seed, device):
@@ -225,10 +235,105 @@ def roofline_lk(ofc, batch, stage_ms):
                     "conversions, packed f32 at 4.1-4.4 (profiles/r03_valu_issue_probe.json): about three quarters of the issue rate of its mix"}
 
 
+def timed(fn, sync, steps, warm=2):
+    """wall time per call of fn (enqueue `steps` calls, one synchronisation)"""
+    for _ in range(warm):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def synth_frame_pair(h, w, seed, device):
+    """one synthetic pair of any size (same generator as synth_batch)"""
+    global H, W
+    keep = (H, W)
+    H, W = h, w
+    try:
+        f0, f1 = synth_batch(1, seed, device)
+    finally:
+        H, W = keep
+    return f0, f1
+
+
+def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr):
+    """BASELINE configs[3]: ONE 3840x2160 pair at operating point 4 (ps 12, stride 3, scales 7..2, 128 LK iterations, refinement on
+    every level up to 960x544): ms per pair one at a time and with four pairs in flight, and the rooflines of its two dominant
+    kernels, each timed alone with HIP events on the launch stream."""
+    from flowonthego_amd.pipeline import FlowPipeline
+    w4, h4 = 3840, 2160
+    op = F.operating_point(4, w4, 1)
+    ip = F.img_params(width=w4, height=h4, padding=op.patch_size)
+    ofc = OFClass(op, ip, max_batch=1, device=local)
+    f0, f1 = synth_frame_pair(h4, w4, 77, dev)
+    out = ofc.new_outflow(1)
+    sync = torch.cuda.synchronize
+    ms1 = timed(lambda: ofc.calc_batch(f0, f1, None, out), sync, 5) * 1e3
+    st = stage_breakdown(ofc, f0, f1, out, lib, stream_ptr, reps=3)
+    res = {"workload": "BASELINE configs[3]: one 3840x2160 gray f32 pair, DIS op-pt 4 (ps 12, stride 3, scales %d..%d, %d LK iterations, refinement, "
+                       "lexicographic SOR); inputs resident in HBM, output = finest-scale flow 960x544x2" % (op.coarsest_scale, op.finest_scale, op.grad_descent_iter),
+           "ms_per_pair": ms1, "value": 1e3 / ms1, "unit": "frame-pairs/s",
+           "stage_ms": {k: round(v, 4) for k, v in st.items()},
+           "reference_point": "19 ms on a GTX 1080 for the reference's CUDA build at this preset (/root/reference/docs/index.md:167-175; other hardware, "
+                              "other numerics -- context only)"}
+    # LK at the finest level: useful flops / fp32 vector peak
+    lvl = op.finest_scale
+    lw, lh = ofc.width >> lvl, ofc.height >> lvl
+    steps = max(1, int(op.patch_size * (1 - op.patch_stride)))
+    nop = -(-lw // steps) * -(-lh // steps)
+    evals = op.grad_descent_iter + 1
+    flops = nop * evals * op.patch_size * op.patch_size * 16
+    ms = st["lk[%d]" % lvl]
+    tf = flops / (ms * 1e-3) / 1e12
+    lk_all = sum(v for k, v in st.items() if k.startswith("lk["))
+    res["rooflines"] = [{"bound": "valu", "kernel": "fotg::lk_kernel<12,1,false,true,false> (level %d: %d patches x %d evaluations x 144 px)" % (lvl, nop, evals),
+                         "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "useful_flops_per_launch": flops,
+                         "ms_per_launch": ms, "share_of_pair": lk_all / sum(st.values()),
+                         "note": "useful flops only (16 per pixel-evaluation); the kernel is bound by the issue rate of its instruction stream "
+                                 "(~285 VALU wave-instructions per four-patch iteration at ~4 cycles each; more waves per SIMD do not speed it up: docs/EXPERIMENTS.md)"}]
+    # one sor_coupled call of the finest level through the tile pipeline
+    try:
+        ev = HipEvents()
+        from flowonthego_amd._lib import check
+        mss = ev.time_ms(lambda: check(lib.fotg_bench_sor_call(ofc._h, lvl, 1, stream_ptr)), stream_ptr, 5)
+        alg = lw * lh * 48 * op.var_ref_iter
+        gbs = alg / (mss * 1e-3) / 1e9
+        inner = lvl + 1
+        res["rooflines"].append({"bound": "hbm", "bound_note": "nearest roof the contract names; the kernel is a pipeline of dependency chains (bound_by)",
+                                 "kernel": "fotg::vr_sor_tile_kernel<8> (one sor_coupled call = %d lexicographic sweeps of the %dx%d level as tiles of 64 rows "
+                                           "x one sweep on %d workgroups; %d launches per pair at this level)" % (op.var_ref_iter, lw, lh, -(-lh // 64) * op.var_ref_iter, inner),
+                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                 "algorithmic_bytes_per_launch": alg, "ms_per_launch": mss, "launches_per_pair": inner,
+                                 "share_of_pair": sum(v for k, v in st.items() if k.startswith("varref[")) / sum(st.values()),
+                                 "bound_by": "%d anti-diagonal steps of one wave per tile (~%.0f ns each) + the pipeline lag between tiles" %
+                                             (lw + lh - 1, mss * 1e6 / (lw + lh - 1))})
+    except Exception as e:
+        res["rooflines"].append({"unavailable": str(e)})
+    # four pairs in flight (a 4K video: consecutive pairs, one per submit)
+    D = 4
+    pipe = FlowPipeline(op, ip, max_batch=1, depth=D, device=local)
+    outs = [pipe.new_outflow(1) for _ in range(D)]
+    sync()
+    k = [0]
+
+    def sub():
+        pipe.submit(f0, f1, None, outs[k[0] % D], after_current_stream=False)
+        k[0] += 1
+    msD = timed(sub, pipe.synchronize, 4 * D, warm=D) * 1e3
+    res["in_flight"] = {"batches_in_flight": D, "ms_per_pair": msD, "value": 1e3 / msD, "unit": "frame-pairs/s",
+                        "same_bits_as_one_at_a_time": bool(torch.equal(outs[0], ofc.calc_batch(f0, f1)))}
+    pipe.close(); ofc.close()
+    return res
+
+
 def cpu_baseline(I0, I1, budget_s=12.0):
-    """the oracle (scalar C port of the reference's kroeger/ path, pyramid included) on the host: first single-threaded
-    for a few pairs, then frame-parallel over all host cores (one pair per thread -- the CPU analogue of frame sharding,
-    SURVEY 8d) on a bounded sample of the same batch.  `value` is the all-cores rate."""
+    """the oracle (scalar C port of the reference's kroeger/ path) on the host: first single-threaded for a few pairs, then
+    frame-parallel over all host cores (one pair per thread -- the CPU analogue of frame sharding) on a bounded
+    sample of the same batch.  `value` is the all-cores FLOW-ONLY rate (the quantity the reference itself times); the rate with the
+    port's scalar pyramid included is reported beside it."""
     from oracle import oracle as O
     flags = O.use_native()                # -O3 -msse4 -march=native of THIS host (the travelling library has no -march)
     p = O.op_point(OP_POINT, W, 1)
@@ -322,8 +427,14 @@ def cpu_baseline(I0, I1, budget_s=12.0):
     time_lines = ["TIME (Sc: %d, #p:%6d, pconst, pinit, poptim, cflow, tvopt, total): %8.2f %8.2f %8.2f %8.2f %8.2f -> %8.2f ms."
                   % (sl, npatch[sl], 0.0, 0.0, st["lk[%d]" % sl], st["densify[%d]" % sl], st["varref[%d]" % sl],
                      st["lk[%d]" % sl] + st["densify[%d]" % sl] + st["varref[%d]" % sl]) for sl in range(p.sc_f, p.sc_l - 1, -1)]
-    return {"value": nall / el, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
-            "all_cores_flow_only": nflow / el_flow, "host_cpus_visible": visible, "cgroup_cpu_quota": quota,
+    return {"value": nflow / el_flow, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+            "value_is": "flow only on all cores -- what the reference times and prints as O.Flow Run-Time (kroeger/oflow.cpp:355-360); the pyramids "
+                        "are built once per thread outside the timed region",
+            "all_cores_flow_only": nflow / el_flow,
+            "all_cores_with_pyramid": nall / el,
+            "with_pyramid_note": "the port's pyramid is scalar C where the reference calls OpenCV's SIMD resize / Sobel / copyMakeBorder "
+                                 "(kroeger/run_dense.cpp:150-175): this figure under-states the reference's CPU path and is NOT the baseline value",
+            "host_cpus_visible": visible, "cgroup_cpu_quota": quota,
             "scaling_vs_single_thread": {"with_pyramid": nall / el / single, "flow_only": nflow / el_flow / (1e3 / flow_ms)},
             "single_thread": single, "single_thread_flow_only": 1e3 / flow_ms,
             "single_thread_stage_ms_per_pair": {k: round(v, 3) for k, v in st.items()}, "time_lines": time_lines,
@@ -395,8 +506,7 @@ def main():
                     "through a single context (fotg_calc_batch), which is also timed and reported beside `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time the video entry point fotg_calc_sequence (off by default: "
-                    "its half-size pyramid launches would blur the per-kernel averages of a rocprofv3 --stats run of this command)")
+    ap.add_argument("--extras", action="store_true", help="also time the stereo depth mode")
     ap.add_argument("--scatter-gather", action="store_true", help="multi-rank runs: also time rank 0 scattering the frames of all "
                     "ranks over RCCL and gathering the flows back (SURVEY 8e); reported beside `value`, never part of it")
     ap.add_argument("--sor-mode", type=int, default=0, help="0 lexicographic (reference order, parity mode), 1 red-black")
@@ -615,38 +725,60 @@ def main():
                 ofc1.calc_batch(I0[:1], I1[:1], None, o1)
             torch.cuda.synchronize()
             ms1 = (time.perf_counter() - t1) * 10.0
+            alg1 = 2 * W * H * 4 + 2 * 120 * 68 * 4
             res["single_pair_no_refine"] = {"ms_per_pair": ms1, "value": 1e3 / ms1, "unit": "frame-pairs/s",
-                                            "note": "BASELINE configs[1]: one 1080p pair per call, 3 scales, no refinement; informational"}
+                                            "note": "BASELINE configs[1]: one 1080p pair per call, 3 scales, no refinement; informational",
+                                            "roofline": {"bound": "hbm", "kernel": "whole call (8 launches: pyramid 2, LK 3, densify 3)", "achieved": alg1 / (ms1 * 1e-3) / 1e9,
+                                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                         "algorithmic_bytes_per_launch": alg1, "ms_per_launch": ms1,
+                                                         "bound_by": "latency: eight dependent launches of one pair's work (a 1080p pair fills 2 % of the chip at the coarse levels)"}}
             ofc1.close()
-        if a.extras:
-            # video mode (fotg_calc_sequence): batch+1 consecutive frames -> batch flows, every pyramid built once
+            sync = torch.cuda.synchronize
+            nst = max(5, min(a.steps, 20))
+            # video mode (fotg_calc_sequence): batch + 1 consecutive frames -> batch flows, every pyramid built once
             seq = torch.cat([I0, I1[-1:]]).contiguous()
-            for _ in range(2):
-                ofc.calc_sequence(seq, None, out)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(a.steps):
-                ofc.calc_sequence(seq, None, out)
-            torch.cuda.synchronize()
-            res["sequence_mode"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
-                                    "note": "%d consecutive f32 frames -> %d flows, one pyramid per frame; informational" % (a.batch + 1, a.batch)}
+            tsq = timed(lambda: ofc.calc_sequence(seq, None, out), sync, nst)
+            res["sequence_mode"] = {"value": a.batch / tsq, "unit": "frame-pairs/s", "ms_per_step": tsq * 1e3,
+                                    "note": "%d consecutive f32 frames -> %d flows, one pyramid per frame (fotg_calc_sequence), one batch at a time" % (a.batch + 1, a.batch)}
             del seq
-            # interleaved RGB frames, the layout of the reference's src/ path (channels = 3): own context, same batch
+            # red-black SOR (the ordering north_star names; not reference-equivalent): same workload, own context
+            if a.sor_mode == 0:
+                oprb = F.operating_point(OP_POINT, W, 1, sor_mode=1)
+                ofcrb = OFClass(oprb, F.img_params(width=W, height=H, padding=oprb.patch_size), max_batch=a.batch, device=local)
+                outrb = ofcrb.new_outflow(a.batch)
+                trb = timed(lambda: ofcrb.calc_batch(I0, I1, None, outrb), sync, nst)
+                ofc.calc_batch(I0, I1, None, out)
+                sync()
+                d = (outrb - out) * float(1 << op.finest_scale)            # full-resolution pixels
+                res["redblack"] = {"value": a.batch / trb, "unit": "frame-pairs/s", "ms_per_step": trb * 1e3,
+                                   "mean_epe_px_vs_lexicographic": float(torch.sqrt((d ** 2).sum(-1)).mean().item()),
+                                   "note": "FOTG_SOR_REDBLACK: red-black ordering of the same 2x2 block update, one batch at a time; the parity mode is the "
+                                           "lexicographic order of the reference's sor_coupled (`value` above)"}
+                ofcrb.close()
+                del outrb
+            # the reference's own input layout: 3-channel interleaved f32 frames (src/run_dense.cpp:147), own context, same batch
             op3 = F.operating_point(OP_POINT, W, 3, sor_mode=a.sor_mode)
             ofc3 = OFClass(op3, F.img_params(width=W, height=H, padding=op3.patch_size), max_batch=a.batch, device=local)
             R0 = torch.stack([I0, I0.roll(3, 2), I0.roll(5, 1)], -1).contiguous()
             R1 = torch.stack([I1, I1.roll(3, 2), I1.roll(5, 1)], -1).contiguous()
-            for _ in range(2):
-                ofc3.calc_batch(R0, R1, None, out)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(a.steps):
-                ofc3.calc_batch(R0, R1, None, out)
-            torch.cuda.synchronize()
-            res["rgb_frames"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
-                                 "note": "same workload with 3-channel interleaved f32 frames (3x the input bytes); informational"}
+            t3 = timed(lambda: ofc3.calc_batch(R0, R1, None, out), sync, nst)
+            ev = HipEvents()
+            p3 = lambda t: C.c_void_p(t.data_ptr())
+            from flowonthego_amd._lib import check as _check
+            ms3 = ev.time_ms(lambda: _check(lib.fotg_pyramid_pair(ofc3._h, a.batch, p3(R0), p3(R1), 1, stream_ptr)), stream_ptr, 10)
+            alg3 = a.batch * (2 * W * H * 3 * 4 + 2 * 120 * 68 * 3 * 4)
+            res["rgb_frames"] = {"value": a.batch / t3, "unit": "frame-pairs/s", "ms_per_step": t3 * 1e3,
+                                 "note": "same workload with 3-channel interleaved f32 frames, the layout the reference's src/ path feeds (src/run_dense.cpp:147); "
+                                         "3x the input bytes; one batch at a time",
+                                 "whole_path_hbm_frac": a.batch / t3 * (2 * W * H * 3 * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS,
+                                 "roofline": {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,3,4,true> (RGB frames -> pyramid level 4)", "achieved": alg3 / (ms3 * 1e-3) / 1e9,
+                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                              "algorithmic_bytes_per_launch": alg3, "ms_per_launch": ms3}}
             ofc3.close()
             del R0, R1
+            # BASELINE configs[3]
+            res["config_4k_op4"] = config_4k_op4(F, OFClass, lib, local, dev, stream_ptr)
+        if a.extras:
             # stereo depth mode (kroeger SELECTMODE=2): same frames as a rectified pair, one displacement channel
             opd = F.operating_point(OP_POINT, W, 1, sor_mode=0)
             opd.depth_mode = True

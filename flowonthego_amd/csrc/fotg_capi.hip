@@ -294,11 +294,9 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   }
   if (p->usetvref) {
     const LevelGeom &g = c->geom[p->sc_l];
-    // lexicographic solver: up to 1024 rows any kernel, up to 4096 rows the wide kernel one sweep per launch; the depth solver
-    // has one thread per row of a workgroup
-    // (more than 1024 rows: only the tile pipeline reaches them, and it runs one wave per sweep for up to four sweeps)
+    // lexicographic solver: up to 1024 rows any kernel, up to 4096 rows the tile pipeline (at most four sweeps per launch); the
+    // depth solver has one thread per row of a workgroup
     if (g.h > (p->depth ? 1024 : 4096) && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
-    if (g.h > 1024 && !p->depth && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && p->tv_solverit > 4) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     if (g.h > 1024 && p->sor_mode == FOTG_SOR_POINT) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }      // (compatibility mode: single-wave solver only)
     if (g.w < 3 || c->geom[p->sc_f].h < 5 || c->geom[p->sc_f].w < 3) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc + (p->depth ? (int)DE_NPLANE : 0));
@@ -326,14 +324,16 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       if (hipMemset(c->vrC[l], 0, cbytes) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
       a.C = c->vrC[l]; a.D = c->vrD[l];
       // tall levels (beyond the LDS solvers' 96 rows): per-sweep arrays of the tile pipeline, zero outside the image for good
-      if (p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && gl.h > 96 && p->tv_solverit >= 1 && p->tv_solverit <= 4 &&
+      // (more than four sweeps -- the operating points use three -- run as consecutive launches of at most four: only levels of
+      // more than 1024 rows, which no other solver reaches, pay for that)
+      if (p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && gl.h > 96 && p->tv_solverit >= 1 && (p->tv_solverit <= 4 || gl.h > 1024) &&
           (gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS <= 64) {
         {
           // every lane of every band has a cell of its own in a row (no two lanes share a store target)
           const int nbr = ((gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS) * FOTG_TILE_ROWS, need = ((gl.h + 2 + 15) / 16) * 16;
           c->x_rt[l] = nbr > need ? nbr : need;
         }
-        c->x_pair_stride[l] = (long)p->tv_solverit * (a.S + 1 + FOTG_TILE_DUMP) * c->x_rt[l];
+        c->x_pair_stride[l] = (long)(p->tv_solverit < 4 ? p->tv_solverit : 4) * (a.S + 1 + FOTG_TILE_DUMP) * c->x_rt[l];
         const size_t xb = B * c->x_pair_stride[l] * sizeof(float2);
         ALLOC(c->vrX[l], xb);
         if (hipMemset(c->vrX[l], 0, xb) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
@@ -797,10 +797,14 @@ static bool dispatch_inner_fused(const fotg_ctx *c, const VrArgs &a, int n, int 
 {
   const int lds = fused_lds_bytes(a, false);
   // one workgroup does the per-pixel phases of its pair: only worth it for small levels (measured: 60x34 yes, 120x68 no)
-  if (sweeps < 1 || sweeps > 4 || inner < 1 || lds > 156 * 1024 || a.S < 24 || a.w * a.h > 3000) return false;
+  // (red-black has no dependency chain: its half-sweeps use all the workgroup's threads, and one launch per level beats
+  // 2 + inner (1 + 2 sweeps) launches at any level whose (du,dv) and smoothness plane fit in LDS -- 1080p level 4 included)
+  const bool rb = c->p.sor_mode == FOTG_SOR_REDBLACK;
+  if (sweeps < 1 || sweeps > 4 || inner < 1 || lds > 156 * 1024 || a.S < 24 || (a.w * a.h > 3000 && !rb)) return false;
   VrArgs b = a;
   b.taps = taps;
   b.nsweeps = sweeps;
+  b.redblack = rb;
 #ifdef FOTG_DEBUG
   if (getenv("FOTG_DEBUG_NOSOR")) b.nsweeps = 0;                // timing experiments only
 #endif
@@ -817,6 +821,7 @@ static bool dispatch_inner_fused(const fotg_ctx *c, const VrArgs &a, int n, int 
     }
     if (launch_inner_fused<NOC, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
   }
+
   return launch_inner_fused<NOC>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
 }
 
@@ -854,9 +859,14 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
     (void)hipMemsetAsync(c->stamps, 0, 4096 * 32 * 8, s);
     g.stats = (long long *)c->stamps;
 #endif
-    (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n) * sizeof(int), s);
-    vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sweeps, 128, 0, s>>>(a, g, sweeps, omega);
-    ++g_tile_launches;
+    // the sweeps are sequential passes over the same system, every launch starts from and ends in the level's D: more than four
+    // sweeps = consecutive launches of at most four (one wave per sweep and band, X buffers for four), the same bits
+    for (int done = 0; done < sweeps; done += 4) {
+      const int sw = sweeps - done < 4 ? sweeps - done : 4;
+      (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n) * sizeof(int), s);
+      vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sw, 128, 0, s>>>(a, g, sw, omega);
+      ++g_tile_launches;
+    }
     return;
   }
   // prefetch depth: as deep as the register budget of K rows per lane allows, and 2P+2 <= S (ring never
@@ -892,7 +902,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   const float half_delta_over3 = c->p.tv_delta * 0.5f / 3.0f;
   const int inner = c->p.tv_innerit * (l + 1);
   // small levels: the whole level (set-up stages, fixed-point loop, final w + d) in one launch, one workgroup per pair
-  if (c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->p.tv_solverit > 0 && c->tune.vr_path == 0 &&
+  if (c->p.sor_mode != FOTG_SOR_POINT && c->p.tv_solverit > 0 && c->tune.vr_path == 0 &&
       dispatch_inner_fused<NOC>(c, a, n, c->p.tv_solverit, inner, quarter_alpha, half_delta_over3, half_gamma_over3, c->p.tv_sor, flow, fs, s,
                                 I0, I1, img_stride, g.tw, c->ps, c->taps ? 1 : 0)) {
     LAUNCHCHK();
@@ -922,7 +932,14 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
       LAUNCHCHK();
     }
     if (c->p.tv_solverit > 0) {
-      if (c->p.sor_mode == FOTG_SOR_REDBLACK) vr_sor_redblack_kernel<<<n, 1024, 0, s>>>(a, c->p.tv_solverit, c->p.tv_sor);
+      if (c->p.sor_mode == FOTG_SOR_REDBLACK) {
+        // one launch per half-sweep: every cell of the even, then of the odd diagonals, the whole batch at once
+        for (int sw = 0; sw < c->p.tv_solverit; ++sw)
+          for (int col = 0; col < 2; ++col) {
+            const int nd = (a.S - col + 1) / 2;
+            vr_rb_halfsweep_kernel<<<dim3((nd * a.RP + 255) / 256, n), 256, 0, s>>>(a, col, c->p.tv_sor);
+          }
+      }
       else if (c->p.sor_mode == FOTG_SOR_POINT) dispatch_sor_point(a, n, c->p.tv_solverit, c->p.tv_sor, s);
       else dispatch_sor(c, a, n, c->p.tv_solverit, c->p.tv_sor, s);
       LAUNCHCHK();

@@ -41,6 +41,7 @@ struct VrArgs {
   long c_pair_stride;    // in float4
   long d_pair_stride;    // in float2
   int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows, band_mode, taps;
+  int redblack;          // FOTG_SOR_REDBLACK: the fused per-level kernel relaxes with red-black half-sweeps instead of the wavefront solver
   int point;             // FOTG_SOR_POINT: cells hold (A11 + sum psi, A12, b1, b2 | A22 + sum psi, psi_r, psi_b, psi_t), no block inverse
   __host__ __device__ int pix(int i, int j) const { return j * st + i; }
   __host__ __device__ float4 *Cp(int pair) const { return C + (size_t)pair * c_pair_stride; }
@@ -1052,6 +1053,33 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
   }
 }
 
+// the same half-sweeps on a level whose (du,dv) -- and, with CL, whose system -- sit in LDS (the fused per-level kernel)
+template <bool CL>
+__device__ __forceinline__ void rb_sweeps_lds(const VrArgs &a, int pair, int sweeps, float omega, const float4 *lc)
+{
+  const int RP = a.RP, RPD = a.RPD, S = a.S;
+  const float4 *Cg = a.Cp(pair);
+  const int pl1 = a.SC * RP + 1;
+  for (int it = 0; it < sweeps; ++it)
+    for (int col = 0; col < 2; ++col) {
+      const int nd = (S - col + 1) / 2;
+      for (int k = threadIdx.x; k < nd * RP; k += blockDim.x) {
+        const int s = col + 2 * (k / RP), r = k - (k / RP) * RP, i = s - r;
+        if (r >= a.h || i < 0 || i >= a.w) continue;
+        const int c = s * RP + r, d = s * RPD + r;
+        float4 c0, c1;
+        float hl;
+        if constexpr (CL) { c0 = lc[c]; c1 = lc[c + pl1]; hl = i > 0 ? lc[c - RP + pl1].y : 0.f; }
+        else { c0 = Cg[2 * (size_t)c]; c1 = Cg[2 * (size_t)c + 1]; hl = i > 0 ? Cg[2 * (size_t)(c - RP) + 1].y : 0.f; }
+        const float2 z = make_float2(0.f, 0.f);
+        const float2 nl = s > 0 ? lds_d_ld(d - RPD) : z, nt = (s > 0 && r > 0) ? lds_d_ld(d - RPD - 1) : z;
+        const float2 nr = lds_d_ld(d + RPD), nb = lds_d_ld(d + RPD + 1);
+        lds_d_st(d, sor_update(lds_d_ld(d), c0, c1, hl, nl, nt, nr, nb, omega));
+      }
+      __syncthreads();
+    }
+}
+
 // The whole fixed-point loop of one level in ONE launch, one workgroup per pair (refine_variational.cpp:182-221):
 //   repeat inner times { smoothness, data term + sub_laplacian + block inverse -> system C ; sor_coupled } ; flow = w + d.
 // (du,dv) never leave LDS; the smoothness weights live in an LDS plane; C goes through global memory (L2) to the
@@ -1258,8 +1286,11 @@ __global__ __launch_bounds__(NT) void vr_inner_fused_kernel(VrArgs a, int inner,
       }
     }
     __syncthreads();                                             // also drains the C stores (vmcnt(0)) before the solver reads them
-    sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M, CL, true, true>(a, pair, omega, wv, lane, lc);   // host: single band only
-    __syncthreads();
+    if (a.redblack) rb_sweeps_lds<CL>(a, pair, a.nsweeps, omega, lc);
+    else {
+      sor_sync_wave<P, U, FOTG_FUSED_NT, FOTG_SYNC_M, CL, true, true>(a, pair, omega, wv, lane, lc);   // host: single band only
+      __syncthreads();
+    }
   }
   float *f = flow + (size_t)pair * flow_stride;                  // refine_variational.cpp:208-221
   for (int px = threadIdx.x; px < w * h; px += blockDim.x) {
@@ -1277,31 +1308,27 @@ __global__ __launch_bounds__(NT) void vr_inner_fused_kernel(VrArgs a, int inner,
   }
 }
 
-// red-black ordering of the same block update (throughput mode; deviates from the reference by ~0.07 px)
-__global__ __launch_bounds__(1024) void vr_sor_redblack_kernel(VrArgs a, int iterations, float omega)
+// Red-black ordering of the same 2x2 block update (FOTG_SOR_REDBLACK; not reference-equivalent: ~0.07 px on alley_1).
+// In the skewed arrays a pixel's colour (i + j) & 1 is the parity of its diagonal s = i + j: a half-sweep relaxes every cell of the
+// even (odd) diagonals -- whole contiguous rows of C and D -- from values of the odd (even) ones, all cells independent.
+//   left (i-1, j) = [s-1][r]   top (i, j-1) = [s-1][r-1]   right (i+1, j) = [s+1][r]   bottom (i, j+1) = [s+1][r+1]   (r = j)
+// Neighbours outside the image are zero cells of D (and their weights psi in the live cell are 0): no border cases.
+// One launch per half-sweep, the whole batch and every CU at once; D and C stay in L2.
+__global__ __launch_bounds__(256) void vr_rb_halfsweep_kernel(VrArgs a, int col, float omega)
 {
-  const int pair = blockIdx.x, w = a.w, h = a.h;
+  const WgId wg = xcd_local_wg();
+  const int pair = wg.y, RP = a.RP, RPD = a.RPD;
+  const int k = wg.x * blockDim.x + threadIdx.x;
+  const int s = col + 2 * (k / RP), r = k - (k / RP) * RP, i = s - r;
+  if (s >= a.S || r >= a.h || i < 0 || i >= a.w) return;
   const float4 *C = a.Cp(pair);
   float2 *D = a.Dp(pair);
+  const size_t c = ((size_t)s * RP + r) * 2, d = (size_t)s * RPD + r;
+  const float hl = i > 0 ? C[c - 2 * (size_t)RP + 1].y : 0.f;     // psi_right of the left neighbour
   const float2 z = make_float2(0.f, 0.f);
-  for (int it = 0; it < iterations; ++it)
-    for (int col = 0; col < 2; ++col) {
-      for (int idx = threadIdx.x; idx < w * h; idx += blockDim.x) {
-        const int i = idx % w, j = idx / w;
-        if (((i + j) & 1) != col) continue;
-        const float4 *c = C + a.cidx(i, j);
-        const float hl = i > 0 ? C[a.cidx(i - 1, j) + 1].y : 0.f;
-        // neighbours outside the image: load the cell itself and zero the value (no select between addresses)
-        float2 nl = D[a.didx(i > 0 ? i - 1 : i, j)], nt = D[a.didx(i, j > 0 ? j - 1 : j)];
-        float2 nr = D[a.didx(i < w - 1 ? i + 1 : i, j)], nb = D[a.didx(i, j < h - 1 ? j + 1 : j)];
-        if (i == 0) nl = z;
-        if (j == 0) nt = z;
-        if (i == w - 1) nr = z;
-        if (j == h - 1) nb = z;
-        D[a.didx(i, j)] = sor_update(D[a.didx(i, j)], c[0], c[1], hl, nl, nt, nr, nb, omega);
-      }
-      __syncthreads();
-    }
+  // (row 0 has no row above: the cell [s-1][-1] would belong to the previous diagonal's padding)
+  const float2 nl = s > 0 ? D[d - RPD] : z, nt = (s > 0 && r > 0) ? D[d - RPD - 1] : z, nr = D[d + RPD], nb = D[d + RPD + 1];
+  D[d] = sor_update(D[d], C[c], C[c + 1], hl, nl, nt, nr, nb, omega);
 }
 
 __global__ __launch_bounds__(256) void vr_finish_kernel(VrArgs a, float *__restrict__ flow, long flow_stride)

@@ -1142,7 +1142,7 @@ typedef struct {
   float *out; long out_stride; long next; pthread_barrier_t bar; pthread_mutex_t mu; struct timespec t0, t1; int tid_seq;
 } dis_many;
 
-static void dis_many_pair(dis_many *m, int k, int tid, float *pad0, float *pad1, float *flow, const dis_pyramid *P0, const dis_pyramid *P1)
+static void dis_many_pair(dis_many *m, int k, int tid, int first, float *pad0, float *pad1, float *flow, const dis_pyramid *P0, const dis_pyramid *P1)
 {
   const dis_params *p = m->p;
   /* source pair: k % nsrc with the pyramid in the loop; without it every thread keeps the pyramids of pair tid % nsrc */
@@ -1154,7 +1154,10 @@ static void dis_many_pair(dis_many *m, int k, int tid, float *pad0, float *pad1,
   } else {
     dis_flow_pyr(P0, P1, p, NULL, flow, 0, NULL);
   }
-  if (m->out && k >= 0 && src < m->n_total) memcpy(m->out + (size_t)src * m->out_stride, flow, sizeof(float) * (size_t)m->out_stride);
+  /* every output slot is written exactly once, by one thread: with the pyramid in the loop by pair k < nsrc (= its first
+   * occurrence), without it by thread tid < nsrc on its first timed pair (`first`) */
+  const int store = m->with_pyramid ? (k >= 0 && k < m->nsrc) : (k >= 0 && tid < m->nsrc && first);
+  if (m->out && store && src < m->n_total) memcpy(m->out + (size_t)src * m->out_stride, flow, sizeof(float) * (size_t)m->out_stride);
 }
 
 static void *dis_many_worker(void *arg)
@@ -1175,13 +1178,13 @@ static void *dis_many_worker(void *arg)
     P0 = dis_pyramid_build(pad0, m->wp, m->hp, p->noc, p->sc_f, p->ps);
     P1 = dis_pyramid_build(pad1, m->wp, m->hp, p->noc, p->sc_f, p->ps);
   }
-  dis_many_pair(m, -1 - tid, tid, pad0, pad1, flow, P0, P1);              /* warm-up pair (source pair |k| % nsrc), not stored */
+  dis_many_pair(m, -1 - tid, tid, 0, pad0, pad1, flow, P0, P1);           /* warm-up pair (source pair |k| % nsrc), not stored */
   if (pthread_barrier_wait(&m->bar) == PTHREAD_BARRIER_SERIAL_THREAD) clock_gettime(CLOCK_MONOTONIC, &m->t0);
   pthread_barrier_wait(&m->bar);
-  for (;;) {
+  for (int first = 1;; first = 0) {
     const long k = __atomic_fetch_add(&m->next, 1, __ATOMIC_RELAXED);
     if (k >= m->n_total) break;
-    dis_many_pair(m, (int)k, tid, pad0, pad1, flow, P0, P1);
+    dis_many_pair(m, (int)k, tid, first, pad0, pad1, flow, P0, P1);
   }
   if (pthread_barrier_wait(&m->bar) == PTHREAD_BARRIER_SERIAL_THREAD) clock_gettime(CLOCK_MONOTONIC, &m->t1);
   pthread_barrier_wait(&m->bar);
@@ -1203,16 +1206,27 @@ double dis_flow_many(const float *I0, const float *I1, long pair_stride, int nsr
   m.I0 = I0; m.I1 = I1; m.pair_stride = pair_stride; m.nsrc = nsrc; m.w = w; m.h = h; m.p = p;
   m.n_total = n_total; m.with_pyramid = with_pyramid; m.out = out;
   m.out_stride = (long)(m.wp >> p->sc_l) * (m.hp >> p->sc_l) * (p->depth ? 1 : 2);
-  pthread_barrier_init(&m.bar, NULL, (unsigned)nthreads);
   pthread_mutex_init(&m.mu, NULL);
   pthread_t *th = (pthread_t *)(malloc)(sizeof(pthread_t) * (size_t)nthreads);
+  /* The workers meet at a barrier sized for the threads that really exist: they are created holding the mutex (their first
+   * action is to take it), the barrier is initialised for the number that could be created, then they are let go.  Fewer
+   * threads than asked for is reported through the return value (-1), never by killing the host process. */
+  pthread_mutex_lock(&m.mu);
   int started = 0;
   for (; started < nthreads; ++started) if (pthread_create(&th[started], NULL, dis_many_worker, &m) != 0) break;
-  if (started < nthreads) {                                            /* cannot meet the barrier with fewer threads: give up loudly */
+  if (started < nthreads) {
     fprintf(stderr, "dis_flow_many: only %d of %d threads could be created\n", started, nthreads);
-    abort();
+    m.n_total = 0;                                                     /* the threads that exist run their warm-up pair and leave */
   }
-  for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
+  if (started > 0) pthread_barrier_init(&m.bar, NULL, (unsigned)started);
+  pthread_mutex_unlock(&m.mu);
+  for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+  if (started < nthreads) {
+    (free)(th);
+    if (started > 0) pthread_barrier_destroy(&m.bar);
+    pthread_mutex_destroy(&m.mu);
+    return -1.0;
+  }
   (free)(th);
   pthread_barrier_destroy(&m.bar); pthread_mutex_destroy(&m.mu);
   return (double)(m.t1.tv_sec - m.t0.tv_sec) + 1e-9 * (double)(m.t1.tv_nsec - m.t0.tv_nsec);

@@ -168,7 +168,7 @@ def test_varref_golden_reference_vectors(noc):
         assert np.array_equal(out[..., 0], c["out_x"]) and np.array_equal(out[..., 1], c["out_y"]), name
 
 
-@pytest.mark.parametrize("case,op_point,sor_mode", [("alley", 2, 0), ("alley", 2, 1), ("alley", 2, 2), ("synth_rgb", 2, 2), ("synth_odd", 3, 2), ("alley_rgb", 2, 0),
+@pytest.mark.parametrize("case,op_point,sor_mode", [("alley", 2, 0), ("alley", 2, 1), ("alley", 2, 2), ("synth_rgb", 2, 2), ("synth_odd", 3, 2), ("synth_rgb", 2, 1), ("synth_odd", 3, 1), ("synth_1080p", 2, 1), ("alley_rgb", 2, 0),
                                                     ("synth_odd", 3, 0), ("synth_odd", 1, 0), ("synth_rgb", 2, 0),
                                                     ("synth_rgb_fast", 2, 0), ("synth_rgb_lv3", 1, 0)])
 def test_end_to_end_parity(case, op_point, sor_mode, alley):
@@ -214,6 +214,21 @@ def test_lk_shared_window_variants(shw, alley, monkeypatch):
         assert np.array_equal(out[0], O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (shw, case, op_point)
         assert np.array_equal(out[1], O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0)), (shw, case, op_point)
         ofc.close()
+
+
+def test_redblack_without_the_fused_level_kernel(alley, monkeypatch):
+    """FOTG_SOR_REDBLACK on the launch-per-stage path of every level (FOTG_VR_PATH=2: one launch per half-sweep) == the fused
+    per-level kernel's LDS half-sweeps == the oracle's red-black solver"""
+    F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_PATH", "2")
+    for case, op_point in (("alley", 2), ("synth_rgb", 2)):
+        f0, f1, noc = frames(case, alley)
+        h, w = f0.shape[:2]
+        op = F.operating_point(op_point, w, noc, sor_mode=1)
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        p = oracle_params(O, op)
+        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 1)), case
 
 
 @pytest.mark.parametrize("path", ["1", "2"])
@@ -378,6 +393,24 @@ def test_levels_taller_than_1024_rows(path, monkeypatch):
     ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
     assert out.shape[0] > 1024 and np.array_equal(out, ref)
     assert F.lib().fotg_debug_counter(name) > before
+    assert F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
+
+
+def test_tall_level_with_more_than_four_sweeps():
+    """var_ref_iter = 6 on a level of more than 1024 rows (the reference accepts any tv_solverit): the tile pipeline runs the
+    sweeps as two launches of four and two -- sequential passes over the same system, the oracle's bits"""
+    F, OFClass, _, O = _mods()
+    w, h = 304, 1300
+    f0, f1 = synth_pair(h, w, seed=9)
+    op = F.operating_point(3, w, 1)
+    op.var_ref_iter = 6
+    before = F.lib().fotg_debug_counter(b"sor_tiles")
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+    p = oracle_params(O, op)
+    assert p.tv_solverit == 6
+    assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0))
+    assert F.lib().fotg_debug_counter(b"sor_tiles") >= before + 2
     assert F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
 
 
