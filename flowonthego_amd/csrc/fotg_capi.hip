@@ -450,6 +450,31 @@ static int pyramid_impl(fotg_ctx *c, int n, const T *I0, const T *I1, hipStream_
     LAUNCHCHK();
     return FOTG_OK;
   }
+  if (I0 && I1) {
+    // both frames of the batch per launch: one halving launch per level (they depend on each other), ONE launch for the borders
+    // and gradients of all levels (4K operating point 4: 6 launches instead of 22)
+    for (int l = lv + 1; l <= c->p.sc_f; ++l) {
+      const LevelGeom &gs = c->geom[l - 1], &gd = c->geom[l];
+      const int tot = gd.w * gd.h * NOC;
+      pyr_halve_kernel<NOC><<<dim3((tot + 255) / 256, 2 * n), 256, 0, s>>>(c->im[0][l - 1], c->lev_stride[l - 1], gs.tw, c->im[0][l], c->lev_stride[l], gd.tw,
+                                                                           gd.w, gd.h, ps, c->im[1][l - 1], c->im[1][l], n);
+      LAUNCHCHK();
+    }
+    PyrBorderArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    int nl = 0, maxtot = 0;
+    for (int l = c->p.sc_l; l <= c->p.sc_f; ++l, ++nl) {
+      const LevelGeom &g = c->geom[l];
+      ba.im[0][nl] = c->im[0][l]; ba.im[1][nl] = c->im[1][l]; ba.dx[nl] = c->dx0[l]; ba.dy[nl] = c->dy0[l];
+      ba.stride[nl] = c->lev_stride[l]; ba.w[nl] = g.w; ba.h[nl] = g.h;
+      const int tot = g.tw * g.th * NOC;
+      maxtot = tot > maxtot ? tot : maxtot;
+    }
+    ba.n_a = n; ba.ps = ps;
+    pyr_border_grad_multi_kernel<NOC><<<dim3((maxtot + 255) / 256, 2 * n, nl), 256, 0, s>>>(ba);
+    LAUNCHCHK();
+    return FOTG_OK;
+  }
   for (int which = 0; which < 2; ++which) {
     if (!(which == 0 ? I0 : I1)) continue;
     for (int l = lv + 1; l <= c->p.sc_f; ++l) {

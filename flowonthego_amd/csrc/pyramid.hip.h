@@ -232,10 +232,17 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
 template <int NOC>
 __global__ __launch_bounds__(256) void pyr_halve_kernel(const float *__restrict__ src, long src_stride, int stw,
                                                         float *__restrict__ dst, long dst_stride, int dtw,
-                                                        int dw, int dh, int ps)
+                                                        int dw, int dh, int ps,
+                                                        const float *__restrict__ src_b = nullptr, float *__restrict__ dst_b = nullptr, int n_a = 1 << 30)
 {
+  // images n_a.. of the launch come from / go to a second pair of buffers (the target frames of the batch): both frames' levels
+  // in one launch
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= dw * dh * NOC) return;
+  if ((int)blockIdx.y >= n_a) {
+    src = src_b - (size_t)n_a * src_stride;
+    dst = dst_b - (size_t)n_a * dst_stride;
+  }
   const int c = idx % NOC, x = (idx / NOC) % dw, y = idx / (NOC * dw);
   const float *s = src + (size_t)blockIdx.y * src_stride;
   const float a = s[((size_t)(2 * y + ps) * stw + (2 * x + ps)) * NOC + c];
@@ -268,6 +275,42 @@ __global__ __launch_bounds__(256) void pyr_border_grad_kernel(float *__restrict_
     }
     dx[(size_t)blockIdx.y * stride + idx] = gx;
     dy[(size_t)blockIdx.y * stride + idx] = gy;
+  }
+#undef PIX
+}
+
+// borders + gradients of SEVERAL levels of both frames of a batch in one launch: blockIdx.z = level, blockIdx.y = image (template
+// frames first, then n_b target frames, which get no gradients); the grid is sized for the largest level
+struct PyrBorderArgs {
+  float *im[2][FOTG_MAXLEV], *dx[FOTG_MAXLEV], *dy[FOTG_MAXLEV];
+  long stride[FOTG_MAXLEV];
+  int w[FOTG_MAXLEV], h[FOTG_MAXLEV];
+  int n_a, ps;
+};
+template <int NOC>
+__global__ __launch_bounds__(256) void pyr_border_grad_multi_kernel(PyrBorderArgs a)
+{
+  const int k = blockIdx.z, w = a.w[k], h = a.h[k], ps = a.ps;
+  const int tw = w + 2 * ps, th = h + 2 * ps;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= tw * th * NOC) return;
+  const bool second = (int)blockIdx.y >= a.n_a;
+  const int img = second ? blockIdx.y - a.n_a : blockIdx.y;
+  const long stride = a.stride[k];
+  const int c = idx % NOC, X = (idx / NOC) % tw, Y = idx / (NOC * tw);
+  float *I = a.im[second ? 1 : 0][k] + (size_t)img * stride;
+  const int x = X - ps, y = Y - ps;
+  const bool inside = x >= 0 && x < w && y >= 0 && y < h;
+#define PIX(yy, xx) I[((size_t)((yy) + ps) * tw + ((xx) + ps)) * NOC + c]
+  if (!inside) I[idx] = PIX(clampi(y, h), clampi(x, w));                    // copyMakeBorder REPLICATE (:166)
+  if (!second) {
+    float gx = 0.f, gy = 0.f;                                                 // BORDER_CONSTANT 0 (:171-172)
+    if (inside) {                                                             // Sobel ksize=1, REFLECT_101 (:156-157)
+      gx = PIX(y, reflect101(x + 1, w)) - PIX(y, reflect101(x - 1, w));
+      gy = PIX(reflect101(y + 1, h), x) - PIX(reflect101(y - 1, h), x);
+    }
+    a.dx[k][(size_t)img * stride + idx] = gx;
+    a.dy[k][(size_t)img * stride + idx] = gy;
   }
 #undef PIX
 }

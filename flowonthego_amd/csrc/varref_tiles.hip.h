@@ -189,8 +189,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   // Loads go through buffer resources: address = resource base + per-lane byte offset (VGPR, constant) + row offset (one
   // SGPR per array that advances by the pitch every step) -- no vector and no 64-bit scalar address arithmetic in the loop.
   const unsigned c1o = (unsigned)(r1 < rmaxc ? r1 : rmaxc) * 32u, c1o16 = c1o + 16u;
-  const unsigned i1o = (unsigned)(r1 < rmaxin ? r1 : rmaxin) * 8u;
-  const unsigned ibo = (unsigned)(rb + BR < rmaxin ? rb + BR : rmaxin) * 8u + 0u * lane;      // (wave-uniform values, kept in VGPRs)
+  // (the 16-byte load of rows r, r+1 stays inside the diagonal's row: lanes parked on the last cells are rows beyond the image)
+  const unsigned i1o = (unsigned)(r1 < rmaxin - 1 ? r1 : rmaxin - 1) * 8u;
   const unsigned tpo = (unsigned)(b > 0 ? rb - 1 : 0) * 8u + 0u * lane;
   const unsigned cpitch = (unsigned)RP * 32u, ipitch = (unsigned)pin * 8u, tpitch = (unsigned)pout * 8u;
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)a.Cp(pair), 0, (S + 1) * cpitch, 0x00020000);
@@ -201,6 +201,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   auto ld_c = [&](unsigned vo, unsigned so) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsC, vo, so, 0)); };
   auto ld_x = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) {        // (aux 16 = sc1: agent-coherent like ld_sc1_f2)
     return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 16));
+  };
+
+  auto ld_x2 = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 16));
   };
 
   int seen_own = prog_own ? -1 : 0x3fffffff, seen_bel = prog_bel ? -1 : 0x3fffffff, seen_top = prog_top ? -1 : 0x3fffffff;
@@ -225,13 +229,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       seen = 0x3fffffff;
     }
   };
-  struct Stage { float4 c1[2]; float2 right1, below, top; };
+  struct Stage { float4 c1[2]; float4 rb; float2 top; };        // rb = (du,dv) of diagonal d+1 at rows r, r+1: the right and the bottom neighbour
   // loads of diagonal step d: the row's system cell, the (du,dv) of diagonal d+1 (right neighbour = next step's own value; the
   // cell below the band), the new value above the band of diagonal d-1
   auto load = [&](Stage &st, unsigned oc, unsigned oi, unsigned ot) {
     st.c1[0] = ld_c(c1o, oc); st.c1[1] = ld_c(c1o16, oc);
-    st.right1 = ld_x(rsI, i1o, oi);
-    st.below = ld_x(rsI, ibo, oi);
+    // one 16-byte load per lane: cells (d+1, r) and (d+1, r+1) are neighbours in the row -- lane 63's second cell is the first row
+    // of the band below (what a separate wave-uniform load + two DPP moves delivered before); past the end of the array the
+    // buffer returns 0
+    st.rb = ld_x2(rsI, i1o, oi);
     st.top = ld_x(rsT, tpo, ot);
   };
   auto issue = [&](Stage &st, int d) {
@@ -318,8 +324,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       // new top value: the row above is lane - 1; lane 0 has no source lane and keeps `old` = the value loaded from the band above
       const v2f top1 = {dpp_wave_shr1_old(st.top.x, prev1.x), dpp_wave_shr1_old(st.top.y, prev1.y)};
       // old bottom value: the row below is lane + 1; lane 63 keeps the value loaded from the band below
-      const v2f rg1 = {st.right1.x, st.right1.y};
-      const v2f bot1 = {dpp_wave_shl1_old(st.below.x, rg1.x), dpp_wave_shl1_old(st.below.y, rg1.y)};
+      const v2f rg1 = {st.rb.x, st.rb.y};
+      const v2f bot1 = {st.rb.z, st.rb.w};
       const v2f res1 = relax(own1, st.c1[0], st.c1[1], hl1, prev1, top1, rg1, bot1, o1);
       res_ring[u % RING][lane] = make_float2(res1.x, res1.y);     // -> writer wave (U is a multiple of RING: s % RING == u % RING)
       prev1 = res1; hl1 = st.c1[1].y;
