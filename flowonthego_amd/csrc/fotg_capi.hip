@@ -861,7 +861,7 @@ static void dispatch_sor_point(const VrArgs &a, int n, int sweeps, float omega, 
   }
 }
 
-static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
+static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, float omega, hipStream_t s, bool sync_zeroed = false)
 {
   const int path = c->tune.vr_path;    // 0 = automatic, 1 = single-wave global-memory solver only, 2 = no fused inner loop (tests)
   if (path != 1 && dispatch_sor_pipe(c, a, n, sweeps, omega, s)) return;
@@ -888,7 +888,8 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
     // sweeps = consecutive launches of at most four (one wave per sweep and band, X buffers for four), the same bits
     for (int done = 0; done < sweeps; done += 4) {
       const int sw = sweeps - done < 4 ? sweeps - done : 4;
-      (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n) * sizeof(int), s);
+      // (the data-term launch in front of the call has cleared the words already when the caller arranged that: VrArgs::zsync)
+      if (!(sync_zeroed && done == 0)) (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n) * sizeof(int), s);
       vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sw, 128, 0, s>>>(a, g, sw, omega);
       ++g_tile_launches;
     }
@@ -933,13 +934,18 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     LAUNCHCHK();
     return FOTG_OK;
   }
+  // levels that go through the tile pipeline: the launch in front of every sor_coupled call (data term; set-up with the first data
+  // term) clears the pipeline's sync words
+  VrArgs az = a;
+  const bool tiles = c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->vrX[l] && c->tileSync && c->p.tv_solverit > 0 && c->tune.vr_setup;
+  if (tiles) { az.zsync = c->tileSync; az.zsync_n = (int)tile_sync_words(n); }
   bool merged_first = false;
   if (c->tune.vr_setup) {
     // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
     // (tune.vr_setup = 0: memset + the three plane-at-a-time launches; tests)
     // (the launch also builds the system of the first inner iteration unless tune.vr_first_data = 0)
     merged_first = c->tune.vr_first_data && inner > 0;
-    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
+    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
                                                                                        merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
     LAUNCHCHK();
   } else {
@@ -953,7 +959,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   }
   for (int it = 0; it < inner; ++it) {
     if (!(it == 0 && merged_first)) {
-      vr_data_kernel<NOC><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(a, quarter_alpha, half_delta_over3, half_gamma_over3);
+      vr_data_kernel<NOC><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(az, quarter_alpha, half_delta_over3, half_gamma_over3);
       LAUNCHCHK();
     }
     if (c->p.tv_solverit > 0) {
@@ -966,7 +972,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
           }
       }
       else if (c->p.sor_mode == FOTG_SOR_POINT) dispatch_sor_point(a, n, c->p.tv_solverit, c->p.tv_sor, s);
-      else dispatch_sor(c, a, n, c->p.tv_solverit, c->p.tv_sor, s);
+      else dispatch_sor(c, a, n, c->p.tv_solverit, c->p.tv_sor, s, tiles);
       LAUNCHCHK();
     }
   }

@@ -41,6 +41,8 @@ struct VrArgs {
   long c_pair_stride;    // in float4
   long d_pair_stride;    // in float2
   int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows, band_mode, taps;
+  int *zsync;            // sync words of the tile pipeline the NEXT launch (the level's sor_coupled call) expects zeroed: the data-term
+  int zsync_n;           // launch clears them on its way (a memset launch per call otherwise: 13 per 4K pair)
   int redblack;          // FOTG_SOR_REDBLACK: the fused per-level kernel relaxes with red-black half-sweeps instead of the wavefront solver
   int point;             // FOTG_SOR_POINT: cells hold (A11 + sum psi, A12, b1, b2 | A22 + sum psi, psi_r, psi_b, psi_t), no block inverse
   __host__ __device__ int pix(int i, int j) const { return j * st + i; }
@@ -204,6 +206,8 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
 {
   constexpr int TW_ = 32, TH_ = 8, XW = TW_ + 8, XH = TH_ + 8, YW = TW_ + 4, YH = TH_ + 4;
   __shared__ float Xa[NOC][XH * XW], Xz[NOC][XH * XW], Yx[NOC][YH * YW], Yy[NOC][YH * YW];
+  if (first_data && a.zsync_n > 0)
+    for (long k = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; k < a.zsync_n; k += (long)gridDim.x * gridDim.y * 256) a.zsync[k] = 0;
   const WgId wg = xcd_local_wg();
   const int pair = wg.y, w = a.w, h = a.h;
   const int tiles_x = (w + TW_ - 1) / TW_;
@@ -447,6 +451,8 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_al
   __shared__ float sm[SW * SH];
   const int st = a.st, w = a.w, h = a.h;
   const int tiles_x = (w + FOTG_TW - 1) / FOTG_TW;
+  if (a.zsync_n > 0)
+    for (long k = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; k < a.zsync_n; k += (long)gridDim.x * gridDim.y * 256) a.zsync[k] = 0;
   const WgId wg = xcd_local_wg();                                // all tiles of a pair on the XCD its solver workgroup runs on
   const int pair = wg.y, tile = wg.x;
   const int x0 = (tile % tiles_x) * FOTG_TW, y0 = (tile / tiles_x) * FOTG_TH;
