@@ -227,12 +227,13 @@ def roofline_lk(ofc, batch, stage_ms):
     flops = batch * nop * evals * op.patch_size * op.patch_size * 16
     ms = stage_ms["lk[%d]" % lvl]
     tf = flops / (ms * 1e-3) / 1e12
-    return {"bound": "valu", "kernel": "fotg::lk_kernel<8,1,false> (level %d: %d patches x %d evaluations x 64 px per pair)" % (lvl, nop, evals),
+    return {"bound": "valu", "kernel": "fotg::lk_kernel<8,1,false,true,false> (level %d: %d patches x %d evaluations x 64 px per pair)" % (lvl, nop, evals),
             "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "useful_flops_per_launch": flops,
             "ms_per_launch": ms, "share_of_step": sum(v for k, v in stage_ms.items() if k.startswith("lk[")) / sum(stage_ms.values()),
-            "note": "useful flops only; the instruction stream is ~4x that (profiles/r03_pmc_valu.json: SQ_INSTS_VALU); the launch retires one VALU "
-                    "wave-instruction per ~4.3 cycles and SIMD, where the hardware issues plain f32 / int adds at 2.3 and selects, compares, DPP, "
-                    "conversions, packed f32 at 4.1-4.4 (profiles/r03_valu_issue_probe.json): about three quarters of the issue rate of its mix"}
+            "note": "useful flops only; the instruction stream is ~4x that (profiles/r04_pmc_valu.json: 234 VALU wave-instructions per four-patch "
+                    "iteration); the launch retires one VALU wave-instruction per ~4.3 cycles and SIMD, where the hardware issues plain f32 / int adds "
+                    "at 2.3 and selects, compares, DPP, conversions, packed f32 at 4.1-4.4 (profiles/r03_valu_issue_probe.json): about three quarters "
+                    "of the issue rate of its mix"}
 
 
 def timed(fn, sync, steps, warm=2):
@@ -292,8 +293,9 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr):
     res["rooflines"] = [{"bound": "valu", "kernel": "fotg::lk_kernel<12,1,false,true,false> (level %d: %d patches x %d evaluations x 144 px)" % (lvl, nop, evals),
                          "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "useful_flops_per_launch": flops,
                          "ms_per_launch": ms, "share_of_pair": lk_all / sum(st.values()),
-                         "note": "useful flops only (16 per pixel-evaluation); the kernel is bound by the issue rate of its instruction stream "
-                                 "(~285 VALU wave-instructions per four-patch iteration at ~4 cycles each; more waves per SIMD do not speed it up: docs/EXPERIMENTS.md)"}]
+                         "note": "useful flops only (16 per pixel-evaluation); the kernel is bound by the issue rate of its instruction stream (263 VALU "
+                                 "wave-instructions per four-patch iteration, profiles/r04_pmc_valu.json, retired at one per ~4.8 cycles and SIMD; five instead of "
+                                 "three waves per SIMD do not speed it up: docs/EXPERIMENTS.md)"}]
     # one sor_coupled call of the finest level through the tile pipeline
     try:
         ev = HipEvents()
