@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""pairs/s of the headline workload with D batches in flight, no result checks (A/B timing of experimental builds):
+python tools/inflight_rate.py [depth] [batch] [steps] [windows]"""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+import flowonthego_amd as F
+from flowonthego_amd.pipeline import FlowPipeline
+D, B, K, NW = (int(x) for x in (sys.argv[1:5] + ["4", "64", "100", "9"][len(sys.argv) - 1:]))
+dev = torch.device("cuda", 0)
+op = F.operating_point(2, 1920, 1)
+ip = F.img_params(width=1920, height=1080, padding=op.patch_size)
+pipe = FlowPipeline(op, ip, max_batch=B, depth=D)
+slots = [bench.synth_batch(B, 1234 + 97 * k, dev) + (pipe.new_outflow(B),) for k in range(D)]
+torch.cuda.synchronize()
+def run(n):
+    for i in range(n):
+        f0, f1, o = slots[i % D]
+        pipe.submit(f0, f1, None, o, after_current_stream=False)
+    pipe.synchronize()
+run(2 * D)
+els = []
+for _ in range(NW):
+    t0 = time.perf_counter(); run(K); els.append(time.perf_counter() - t0)
+els.sort()
+print("depth %d batch %d: %.0f pairs/s (median of %d windows of %d steps; %.4f ms per step)" % (D, B, B * K / els[len(els) // 2], NW, K, els[len(els) // 2] / K * 1e3))
