@@ -66,6 +66,8 @@ struct FotgTune {
   int pyr_split;    // FOTG_PYR_SPLIT: launches the base pyramid kernel of a batch is cut into (1 = one launch)
   int vr_fused_nt;  // FOTG_VR_FUSED_NT: threads per workgroup of the fused per-level kernel on gray levels of 1025..2048 pixels (512 / 1024)
   int lk_shw;       // FOTG_LK_SHW: shared LDS window of a wave's four patches: -1 automatic (RGB patches of 8 x 8 and more), 0 off, 1 on; 2 / 3 with FOTG_TEST_TAPS: on + some / all rows on the global-memory path
+  int lk_lpp;       // FOTG_LK_LPP: lanes per patch of the LK kernel: 0 automatic, 8, 16
+  int lk_lpp_min_waves;   // FOTG_LK_LPP_MIN_WAVES: automatic: eight lanes per patch from this many waves per launch on
   int test_taps;    // FOTG_TEST_TAPS: 1 = fotg_ctx_counter(ctx, "inject_stall") is live (tests of the FOTG_ERR_STALL reporting)
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
@@ -246,6 +248,8 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.pyr_split = env_int("FOTG_PYR_SPLIT", 1);
   c->tune.test_taps = env_int("FOTG_TEST_TAPS", 0);
   c->tune.lk_shw = env_int("FOTG_LK_SHW", -1);
+  c->tune.lk_lpp = env_int("FOTG_LK_LPP", 0);
+  c->tune.lk_lpp_min_waves = env_int("FOTG_LK_LPP_MIN_WAVES", 2048);
   if (hipHostMalloc((void **)&c->stall_host, 64, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void **)&c->stall_dev, c->stall_host, 0) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; }
   memset(c->stall_host, 0, 64);
@@ -602,13 +606,19 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
     while (sqrtf(nextafterf(sq, INFINITY)) <= a.outlier) sq = nextafterf(sq, INFINITY);
     a.outlier_sq = sq;
   }
-  // four patches per wave, one wave per workgroup (lk.hip.h)
-  dim3 block(64), grid((g.nop + FOTG_LK_PPW - 1) / FOTG_LK_PPW, n);
+  // four patches per wave, one wave per workgroup (lk.hip.h); eight (eight lanes per patch) for launches of the operating points'
+  // L2 cost with enough waves to stay throughput-bound at three waves per SIMD (FOTG_LK_LPP: 0 automatic, 8, 16)
+  const long waves8 = ((long)g.nop + 7) / 8 * n;
+  const bool lpp8 = !c->p.depth && c->p.costfct == 0 && (c->ps == 8 || c->ps == 12) && c->noc == 1 &&
+                    (c->tune.lk_lpp == 8 || (c->tune.lk_lpp == 0 && c->ps == 8 && waves8 >= c->tune.lk_lpp_min_waves));
+  const int ppw = lpp8 ? 8 : 4;
+  dim3 block(64), grid((g.nop + ppw - 1) / ppw, n);
   // the operating points' L2 cost: specialised kernels, with one shared LDS area per wave where private windows limit occupancy
   // (measured: RGB patches -- two to three waves per SIMD with private windows -- gain 9-19 % per level; gray ones are bound by
   // the issue rate of their instruction stream at any occupancy and lose the time of the packing plan: docs/EXPERIMENTS.md)
   const bool shw = c->tune.lk_shw < 0 ? (c->noc == 3 && c->ps >= 8) : c->tune.lk_shw != 0;
-#define LK(PS_, NOC_) do { if (a.costfct == 0 && shw) lk_kernel<PS_, NOC_, false, true, true><<<grid, block, 0, s>>>(a); \
+#define LK(PS_, NOC_) do { if (lpp8 && (PS_ == 8 || PS_ == 12) && NOC_ == 1) lk_kernel<(PS_ == 8 || PS_ == 12) ? PS_ : 8, 1, false, true, true, 8><<<grid, block, 0, s>>>(a); \
+                           else if (a.costfct == 0 && shw) lk_kernel<PS_, NOC_, false, true, true><<<grid, block, 0, s>>>(a); \
                            else if (a.costfct == 0) lk_kernel<PS_, NOC_, false, true><<<grid, block, 0, s>>>(a); \
                            else lk_kernel<PS_, NOC_, false><<<grid, block, 0, s>>>(a); } while (0)
 #define LKD(PS_, NOC_) lk_kernel<PS_, NOC_, true><<<grid, block, 0, s>>>(a)

@@ -46,7 +46,6 @@ struct LkArgs {
 // DEPTH: stereo depth mode (SELECTMODE 2): the parameter is ONE horizontal displacement per patch -- scalar Hessian
 // sum(Tx^2) (patch.cpp:83-87), one projection (:181), sign clamp after the update (:188-193), pt_iter.y stays at the
 // reference row (:218-220); flow_prev has one channel (patchgrid.cpp:207-208).  p_iter keeps two slots (second = 0).
-#define FOTG_LK_PPW 4                                  // patches per wave = per workgroup (one wave per workgroup)
 
 // x / NV for the element counts NV = ps*ps*noc of the supported patch sizes, correctly rounded in three instructions:
 // q0 = x * RN(1/NV), q = fma(fma(-q0, NV, x), RN(1/NV), q0).  tools/div_const_check.c compares this with x / NV for EVERY
@@ -74,25 +73,55 @@ __device__ __forceinline__ float div_nv(float x)
 // does not fit (starts further apart than the slack in x, or a third group) is not staged: that patch reads its taps from
 // global memory with the same clamping -- same values, only slower, and rare.
 // waves per SIMD the register allocation of the shared-window kernels must leave room for (what their LDS area allows)
-constexpr int lk_min_waves(int nv, bool shw) { return !shw ? 1 : nv == 48 ? 5 : nv <= 64 ? 6 : nv <= 144 ? 5 : nv <= 192 ? 3 : 1; }
-
-template <int PS, int NOC, bool DEPTH = false, bool L2 = false, bool SHW = false>
-__global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kernel(LkArgs a)
+constexpr int lk_min_waves(int nv, bool shw, int lpp)
 {
+  return lpp == 8 ? (nv <= 64 ? 4 : nv <= 144 ? 3 : 1) : !shw ? 1 : nv == 48 ? 5 : nv <= 64 ? 6 : nv <= 144 ? 5 : nv <= 192 ? 3 : 1;
+}
+
+// the tree of dis_sum() below the 16 partials, inside a group of LPP lanes; the result in every lane of the group.
+// LPP = 16: xor 8, 4, 2, 1 as row rotations (see common.h).  LPP = 8 (the lane already holds partial i + partial i + 8): the
+// true xor-4 partner through two bank-masked row shifts, xor 2 and xor 1 as quad permutations.
+template <int LPP>
+__device__ __forceinline__ float group_allsum(float v)
+{
+  if constexpr (LPP == 16) return row_allsum(v);
+  else {
+#define FOTG_DPPM(old_, x, ctrl, bank) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old_), __builtin_bit_cast(int, x), ctrl, 0xF, bank, false))
+    const float lo = FOTG_DPPM(0.f, v, 0x104, 0x5);      // row_shl:4 -> lanes 0-3, 8-11 read lane + 4
+    const float pr = FOTG_DPPM(lo, v, 0x114, 0xA);       // row_shr:4 -> lanes 4-7, 12-15 read lane - 4
+    v = v + pr;
+    v = v + FOTG_DPPM(0.f, v, 0x4E, 0xF);                // quad_perm [2,3,0,1]: xor 2
+    v = v + FOTG_DPPM(0.f, v, 0xB1, 0xF);                // quad_perm [1,0,3,2]: xor 1
+#undef FOTG_DPPM
+    return v;
+  }
+}
+
+// LPP: lanes per patch.  16 (default): four patches per wave.  8: eight patches per wave, every lane carries the pixels of two
+// of the 16 virtual lanes of dis_sum() (j and j + 8: their partials are summed in the lane = the tree's first level), so the
+// per-patch scalar code -- half of an iteration's instructions -- serves twice as many patches; needs the shared LDS area and
+// ~1.6x the registers: for launches with enough waves to stay throughput-bound at three waves per SIMD.
+template <int PS, int NOC, bool DEPTH = false, bool L2 = false, bool SHW = false, int LPP = 16>
+__global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW, LPP)) void lk_kernel(LkArgs a)
+{
+  static_assert(LPP == 16 || (LPP == 8 && SHW), "eight lanes per patch only with the shared LDS area");
+  constexpr int PPW = 64 / LPP;                      // patches per wave
+  constexpr int NVL = 16 / LPP;                      // virtual lanes (of the 16 of dis_sum()) per lane
   constexpr int NPIX = PS * PS;
-  constexpr int NSL = NPIX / 16;                     // pixels per lane
-  constexpr int NE = NSL * NOC;
+  constexpr int NSL = NPIX / 16;                     // pixels per virtual lane
+  constexpr int NE1 = NSL * NOC;                     // elements per virtual lane
+  constexpr int NE = NE1 * NVL;                      // elements per lane: [virtual lane][slot][channel]
   constexpr int NV = NPIX * NOC;
   constexpr int PAD = PS;
   constexpr int WIN = 2 * PS + 4;                    // window edge, see the column bound below
   constexpr int SWW = WIN + 4;                       // SHW: width of the shared area (slack for starts that differ in x)
-  constexpr int RB = 2 * WIN + 8;                    // SHW: rows of the shared area (two groups + 8 rows of vertical spread)
+  constexpr int RB = 2 * WIN + 8 + (PPW - 4) * (PS / 2 + 2);   // SHW: rows of the shared area (two groups + their vertical spread)
   constexpr int WS = SHW ? SWW : WIN;                // row stride of a patch's window, pixels
   static_assert(NPIX % 16 == 0, "a patch fills the 16 lanes of its row");
-  __shared__ float win_all[SHW ? SWW * RB * NOC : FOTG_LK_PPW * WIN * WIN * NOC];
-  const int lane = threadIdx.x & 63, row = lane >> 4, j = lane & 15;
+  __shared__ float win_all[SHW ? SWW * RB * NOC : PPW * WIN * WIN * NOC];
+  const int lane = threadIdx.x & 63, row = lane / LPP, j = lane % LPP;
   const WgId wg = xcd_local_wg();                    // all patches of a pair on the XCD of its refinement workgroup
-  const int ipw = wg.x * FOTG_LK_PPW;                // first patch of this wave
+  const int ipw = wg.x * PPW;                        // first patch of this wave
   const int pair = wg.y;
   const int tw = a.g.tw;
   const float *I0 = a.I0 + (size_t)pair * a.img_stride;
@@ -103,23 +132,36 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
   const int IP = VALID ? ipw + row : a.g.nop - 1;
 
   // per-lane sums over the slots (element order = the oracle's) and the row tree
+  // (with two virtual lanes per lane: one partial each, in element order, then their sum = the tree's xor-8 level)
   auto lane_sum = [&](const float *v) {
-    float acc = v[0];
+    float acc[NVL];
 #pragma unroll
-    for (int k = 1; k < NE; ++k) acc = acc + v[k];
-    return acc;
+    for (int vl = 0; vl < NVL; ++vl) {
+      acc[vl] = v[vl * NE1];
+#pragma unroll
+      for (int k = 1; k < NE1; ++k) acc[vl] = acc[vl] + v[vl * NE1 + k];
+    }
+    return NVL == 2 ? acc[0] + acc[NVL - 1] : acc[0];
   };
   auto lane_sum_abs = [&](const float *v) {
-    float acc = fabsf(v[0]);
+    float acc[NVL];
 #pragma unroll
-    for (int k = 1; k < NE; ++k) acc = acc + fabsf(v[k]);
-    return acc;
+    for (int vl = 0; vl < NVL; ++vl) {
+      acc[vl] = fabsf(v[vl * NE1]);
+#pragma unroll
+      for (int k = 1; k < NE1; ++k) acc[vl] = acc[vl] + fabsf(v[vl * NE1 + k]);
+    }
+    return NVL == 2 ? acc[0] + acc[NVL - 1] : acc[0];
   };
   auto lane_dot = [&](const float *x, const float *y) {
-    float acc = x[0] * y[0];
+    float acc[NVL];
 #pragma unroll
-    for (int k = 1; k < NE; ++k) acc = acc + x[k] * y[k];
-    return acc;
+    for (int vl = 0; vl < NVL; ++vl) {
+      acc[vl] = x[vl * NE1] * y[vl * NE1];
+#pragma unroll
+      for (int k = 1; k < NE1; ++k) acc[vl] = acc[vl] + x[vl * NE1 + k] * y[vl * NE1 + k];
+    }
+    return NVL == 2 ? acc[0] + acc[NVL - 1] : acc[0];
   };
 
   // ---- template + gradients at round(pt_ref)+pad (patch.cpp:287-332), Hessian sums (:74-77), starting flow
@@ -133,21 +175,23 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
   // compile-time row term (an immediate of the LDS read) cover all slots
   constexpr int PER = PS == 12 ? 3 : 1, PROWS = 16 * PER / PS;
   static_assert((16 * PER) % PS == 0 && NSL % PER == 0, "slot period");
-  int pu[PER];
+  int pu[NVL * PER];
   {
     const int px = (int)RX + PAD, py = (int)RY + PAD;              // pt_ref is integer valued: round() is exact
 #pragma unroll
+    for (int vl = 0; vl < NVL; ++vl)
+#pragma unroll
     for (int s = 0; s < NSL; ++s) {
-      const int q = s * 16 + j;
+      const int q = s * 16 + j + vl * LPP;
       const int offy = q / PS - PS / 2, offx = q % PS - PS / 2;
-      if (s < PER) pu[s] = ((offy - 1) * WS + offx - 1) * NOC;      // the upper left tap: the lowest address of the four
+      if (s < PER) pu[vl * PER + s] = ((offy - 1) * WS + offx - 1) * NOC;      // the upper left tap: the lowest address of the four
       const size_t idx = ((size_t)(px + offx) + (size_t)(py + offy) * tw) * NOC;
 #pragma unroll
       for (int c = 0; c < NOC; ++c) {
-        T[s * NOC + c] = I0[idx + c];
-        Tx[s * NOC + c] = I0x[idx + c];
-        Ty[s * NOC + c] = I0y[idx + c];
-        r[s * NOC + c] = 0.f;
+        T[vl * NE1 + s * NOC + c] = I0[idx + c];
+        Tx[vl * NE1 + s * NOC + c] = I0x[idx + c];
+        Ty[vl * NE1 + s * NOC + c] = I0y[idx + c];
+        r[vl * NE1 + s * NOC + c] = 0.f;
       }
     }
   }
@@ -176,15 +220,17 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
     unsigned need;
     {
       const unsigned long long b = __builtin_amdgcn_ballot_w64(START_OK);
-      need = (unsigned)((b & 1) | ((b >> 15) & 2) | ((b >> 30) & 4) | ((b >> 45) & 8));
-      if (a.shw_test == 1) need &= 5u;                   // test tap: rows 1 and 3 take the global-memory path
+      need = 0;
+#pragma unroll
+      for (int r4 = 0; r4 < PPW; ++r4) need |= (unsigned)((b >> (LPP * r4)) & 1) << r4;
+      if (a.shw_test == 1) need &= 0x55u;                // test tap: the odd rows take the global-memory path
       if (a.shw_test == 2) need = 0;                     // test tap: every row takes it
     }
     int xa0 = 0, xa1 = 0, ya0 = 0, ya1 = 0, xb0 = 0, xb1 = 0, yb0 = 0, yb1 = 0, ng = 0;
     unsigned staged = 0, grp1 = 0;                       // bit r: row r is staged / sits in group B
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const int wxr = __builtin_amdgcn_readlane(WX0, 16 * r4), wyr = __builtin_amdgcn_readlane(WY0, 16 * r4);
+    for (int r4 = 0; r4 < PPW; ++r4) {
+      const int wxr = __builtin_amdgcn_readlane(WX0, LPP * r4), wyr = __builtin_amdgcn_readlane(WY0, LPP * r4);
       if (!((need >> r4) & 1)) continue;
       const bool inB = ng == 2;
       const int cx0 = inB ? xb0 : xa0, cx1 = inB ? xb1 : xa1, cy0 = inB ? yb0 : ya0, cy1 = inB ? yb1 : ya1;
@@ -203,8 +249,8 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
     const int base1 = ya1 - ya0;                         // first LDS row of group B
     int woff = 0;
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const int wxr = __builtin_amdgcn_readlane(WX0, 16 * r4), wyr = __builtin_amdgcn_readlane(WY0, 16 * r4);
+    for (int r4 = 0; r4 < PPW; ++r4) {
+      const int wxr = __builtin_amdgcn_readlane(WX0, LPP * r4), wyr = __builtin_amdgcn_readlane(WY0, LPP * r4);
       const bool b = (grp1 >> r4) & 1;
       const int o = (((b ? base1 : 0) + wyr - (b ? yb0 : ya0)) * SWW + (wxr - (b ? xb0 : xa0))) * NOC;
       woff = row == r4 ? o : woff;
@@ -223,7 +269,7 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
     }
   } else if (START_OK) {
     float *const wdst = win_all + row * (WIN * WIN * NOC);
-    for (int t = j; t < WIN * WIN; t += 16) {
+    for (int t = j; t < WIN * WIN; t += LPP) {
       const int wy = t / WIN, wx = t - wy * WIN;
       const size_t src = ((size_t)clampi(WY0 + wy, a.g.th) * tw + clampi(WX0 + wx, tw)) * NOC;
 #pragma unroll
@@ -236,13 +282,13 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
 
   // template mean (patch.cpp:330-331) and Hessian sums (:74-77, depth :84)
   if (a.patnorm > 0) {
-    const float m = div_nv<NV>(row_allsum(lane_sum(T)));
+    const float m = div_nv<NV>(group_allsum<LPP>(lane_sum(T)));
 #pragma unroll
     for (int e = 0; e < NE; ++e) T[e] -= m;
   }
-  float H00 = row_allsum(lane_dot(Tx, Tx));
-  const float H01 = DEPTH ? 0.f : row_allsum(lane_dot(Tx, Ty));
-  float H11 = DEPTH ? 0.f : row_allsum(lane_dot(Ty, Ty));
+  float H00 = group_allsum<LPP>(lane_dot(Tx, Tx));
+  const float H01 = DEPTH ? 0.f : group_allsum<LPP>(lane_dot(Tx, Ty));
+  float H11 = DEPTH ? 0.f : group_allsum<LPP>(lane_dot(Ty, Ty));
   if constexpr (DEPTH) {
     if (H00 == 0.f) H00 = (float)((double)H00 + 1e-10);  // :85-86
   } else if (H00 * H11 - H01 * H01 == 0.f) {             // :78-82  (float += 1e-10 in double, like the reference)
@@ -275,7 +321,7 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
   // RC: the residual does not live across the loop; it is evaluated once more at the final position for the patch weights
   // (the same position gives the same bits).  One evaluation in max_iter + 1 more, nine registers and their copies at the loop
   // head less: for the 128-iteration operating points' 12 x 12 patches.
-  constexpr bool RC = L2 && !SHW && NSL >= 9;
+  constexpr bool RC = L2 && NSL * NVL >= 9 && (!SHW || LPP == 8);
   float B0 = 0.f, B1 = 0.f;
   auto residual = [&](float (&rr)[NE]) {
     const int pos2 = (int)floorf(PTX), pos3 = (int)floorf(PTY);
@@ -287,8 +333,8 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
     if (SHW && USEG) {
       // this row's window is not in LDS (see SHW above): the same four taps from the level image, clamped like the staged copy
 #pragma unroll 1
-      for (int s = 0; s < NSL; ++s) {
-        const int qq = s * 16 + j;
+      for (int sv = 0; sv < NSL * NVL; ++sv) {
+        const int qq = (sv % NSL) * 16 + j + (sv / NSL) * LPP;
         const int ax = pos0 + WX0 + qq % PS - PS / 2, ay = pos1 + WY0 + qq / PS - PS / 2;
         const int x1 = clampi(ax, tw), x0 = clampi(ax - 1, tw), y1 = clampi(ay, a.g.th), y0 = clampi(ay - 1, a.g.th);
 #pragma unroll
@@ -297,29 +343,31 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
           const float vc = I1[((size_t)y0 * tw + x1) * NOC + c], vd = I1[((size_t)y0 * tw + x0) * NOC + c];
           const float v = we0 * va + we1 * vb + we2 * vc + we3 * vd;
 #pragma unroll
-          for (int s2 = 0; s2 < NSL; ++s2) if (s2 == s) q[s2 * NOC + c] = v;      // (register array: constant indices only)
+          for (int s2 = 0; s2 < NSL * NVL; ++s2) if (s2 == sv) q[s2 * NOC + c] = v;      // (register array: constant indices only)
         }
       }
     } else {
       // (the bases are made opaque: the compiler otherwise folds the window-centre constants into every tap's address and then
       // needs one address add per tap -- 18 at ps 12 -- instead of the 8-bit offset fields of the LDS reads)
-      const float *tps[PER];
+      const float *tps[NVL * PER];
 #pragma unroll
-      for (int u = 0; u < PER; ++u) { int ib = iab + pu[u]; asm volatile("" : "+v"(ib)); tps[u] = win + ib; }
+      for (int u = 0; u < NVL * PER; ++u) { int ib = iab + pu[u]; asm volatile("" : "+v"(ib)); tps[u] = win + ib; }
+#pragma unroll
+      for (int vl = 0; vl < NVL; ++vl)
 #pragma unroll
       for (int s = 0; s < NSL; ++s) {
         // taps at non-negative compile-time offsets from one per-lane base per slot class: immediates of the LDS reads
-        const float *tp = tps[s % PER];
+        const float *tp = tps[vl * PER + s % PER];
         const int o = (s / PER) * (PROWS * WS * NOC);
 #pragma unroll
         for (int c = 0; c < NOC; ++c) {
           const float vd = tp[o + c], vc = tp[o + NOC + c], vb = tp[o + WS * NOC + c], va = tp[o + WS * NOC + NOC + c];
-          q[s * NOC + c] = we0 * va + we1 * vb + we2 * vc + we3 * vd;
+          q[vl * NE1 + s * NOC + c] = we0 * va + we1 * vb + we2 * vc + we3 * vd;
         }
       }
     }
     if (a.patnorm > 0) {
-      const float m = div_nv<NV>(row_allsum(lane_sum(q)));
+      const float m = div_nv<NV>(group_allsum<LPP>(lane_sum(q)));
 #pragma unroll
       for (int e = 0; e < NE; ++e) q[e] -= m;
     }
@@ -338,12 +386,12 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
     float rl[NE];
     float (&rr)[NE] = RC ? rl : r;
     residual(rr);
-    B0 = row_allsum(lane_dot(Tx, rr));
-    if constexpr (!DEPTH) B1 = row_allsum(lane_dot(Ty, rr));
+    B0 = group_allsum<LPP>(lane_dot(Tx, rr));
+    if constexpr (!DEPTH) B1 = group_allsum<LPP>(lane_dot(Ty, rr));
     const float dpn = DP0 * DP0 + DP1 * DP1;             // :272
     if (CNT == 1) DPN_INIT = dpn;
     MARES_OLD = MARES;
-    MARES = div_nv<NV>(row_allsum(lane_sum_abs(rr)));    // :278
+    MARES = div_nv<NV>(group_allsum<LPP>(lane_sum_abs(rr)));    // :278
     // :279-282 (the two rate tests only matter once cnt >= min_iter)
     bool go = (CNT < a.max_iter) & (MARES > a.res_thresh);
     if (go && CNT >= a.min_iter) go = (dpn / DPN_INIT >= a.dp_thresh_sq) & (MARES / MARES_OLD <= a.dr_thresh);
@@ -412,12 +460,15 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW)) void lk_kerne
     if (a.cnt) a.cnt[pb] = CNT;
   }
 #pragma unroll
+  for (int vl = 0; vl < NVL; ++vl)
+#pragma unroll
   for (int s = 0; s < NSL; ++s) {
-    const size_t e = pb * NV + (size_t)(s * 16 + jj) * NOC;
+    const size_t e = pb * NV + (size_t)(s * 16 + jj + vl * LPP) * NOC;
+    const int k = vl * NE1 + s * NOC;
 #pragma unroll
     for (int c = 0; c < NOC; ++c) {
-      a.pweight[e + c] = fabsf(r[s * NOC + c]);
-      if (a.tmpl) { a.tmpl[e + c] = T[s * NOC + c]; a.tdx[e + c] = Tx[s * NOC + c]; a.tdy[e + c] = Ty[s * NOC + c]; }
+      a.pweight[e + c] = fabsf(r[k + c]);
+      if (a.tmpl) { a.tmpl[e + c] = T[k + c]; a.tdx[e + c] = Tx[k + c]; a.tdy[e + c] = Ty[k + c]; }
     }
   }
 }

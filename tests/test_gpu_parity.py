@@ -216,6 +216,28 @@ def test_lk_shared_window_variants(shw, alley, monkeypatch):
         ofc.close()
 
 
+@pytest.mark.parametrize("shw", ["-1", "2", "3"])
+def test_lk_eight_lanes_per_patch(shw, alley, natural_images, monkeypatch):
+    """FOTG_LK_LPP=8: the LK kernel with eight lanes per patch (eight patches per wave, two of dis_sum()'s sixteen partials per
+    lane, the shared LDS area for eight windows) -- patch sizes 8 and 12, including the per-iteration traces and the patch
+    state of every scale, with the global-memory path forced for some / all rows: the oracle's bits"""
+    F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_LK_LPP", "8")
+    monkeypatch.setenv("FOTG_LK_SHW", shw)
+    monkeypatch.setenv("FOTG_TEST_TAPS", "1")
+    for case, op_point in (("alley", 2), ("synth_odd", 3), ("synth_odd", 4), ("synth_1080p", 1)):
+        f0, f1, noc = frames(case, alley)
+        h, w = f0.shape[:2]
+        op = F.operating_point(op_point, w, noc)
+        op.grad_descent_iter = min(op.grad_descent_iter, 24)
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+        out = ofc.calc_batch(torch.stack([dev(f0), dev(f1)]), torch.stack([dev(f1), dev(f0)])).cpu().numpy()
+        p = oracle_params(O, op)
+        assert np.array_equal(out[0], O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (shw, case, op_point)
+        assert np.array_equal(out[1], O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0)), (shw, case, op_point)
+        ofc.close()
+
+
 def test_redblack_without_the_fused_level_kernel(alley, monkeypatch):
     """FOTG_SOR_REDBLACK on the launch-per-stage path of every level (FOTG_VR_PATH=2: one launch per half-sweep) == the fused
     per-level kernel's LDS half-sweeps == the oracle's red-black solver"""
