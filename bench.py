@@ -227,11 +227,12 @@ def roofline_lk(ofc, batch, stage_ms):
     flops = batch * nop * evals * op.patch_size * op.patch_size * 16
     ms = stage_ms["lk[%d]" % lvl]
     tf = flops / (ms * 1e-3) / 1e12
-    return {"bound": "valu", "kernel": "fotg::lk_kernel<8,1,false,true,false> (level %d: %d patches x %d evaluations x 64 px per pair)" % (lvl, nop, evals),
+    lpp8 = -(-nop // 8) * batch >= 2048 and op.patch_size == 8           # the library's automatic rule (FOTG_LK_LPP = 0): eight lanes per patch
+    return {"bound": "valu", "kernel": "fotg::lk_kernel<8,1,false,true,%s> (level %d: %d patches x %d evaluations x 64 px per pair)" % ("true,8" if lpp8 else "false,16", lvl, nop, evals),
             "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "useful_flops_per_launch": flops,
             "ms_per_launch": ms, "share_of_step": sum(v for k, v in stage_ms.items() if k.startswith("lk[")) / sum(stage_ms.values()),
-            "note": "useful flops only; the instruction stream is ~4x that (profiles/r04_pmc_valu.json: 234 VALU wave-instructions per four-patch "
-                    "iteration); the launch retires one VALU wave-instruction per ~4.3 cycles and SIMD, where the hardware issues plain f32 / int adds "
+            "note": "useful flops only; the instruction stream is ~3-4x that (profiles/r04_pmc_valu.json: 330 VALU wave-instructions per EIGHT-patch "
+                    "iteration with eight lanes per patch, 234 per four-patch iteration with sixteen); the launch retires one VALU wave-instruction per ~4.3 cycles and SIMD, where the hardware issues plain f32 / int adds "
                     "at 2.3 and selects, compares, DPP, conversions, packed f32 at 4.1-4.4 (profiles/r03_valu_issue_probe.json): about three quarters "
                     "of the issue rate of its mix"}
 

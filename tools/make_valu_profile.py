@@ -35,7 +35,10 @@ for k, v in list(bench.items()) + list(k4.items()):
     if "lk_kernel" in k and v.get("SQ_WAVES_per_launch"):
         # a wave = four patches; every wave runs max_iter + 1 evaluations (12 + 1 at op-pt 2, 128 + 1 at op-pt 4)
         it = 129 if "lk_kernel<12" in k else 13
-        v["valu_per_four_patch_iteration"] = v["SQ_INSTS_VALU_per_launch"] / v["SQ_WAVES_per_launch"] / it
+        ppw = 8 if k.split("[")[0].rstrip().endswith(", 8>") else 4          # lk_kernel<.., LPP = 8>: eight patches per wave
+        v["patches_per_wave"] = ppw
+        v["valu_per_wave_iteration"] = v["SQ_INSTS_VALU_per_launch"] / v["SQ_WAVES_per_launch"] / it
+        v["valu_per_four_patch_iteration"] = v["valu_per_wave_iteration"] * 4 / ppw
 json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -- python3 bench.py --in-flight 1 --steps 3 "
                       "--warmup 1 --windows 1 --no-cpu-baseline --no-breakdown   (and: -- python3 tools/time_4k_op4.py)",
            "units": "wave-instructions per launch (SQ_INSTS_* count per wave); valu_per_four_patch_iteration = SQ_INSTS_VALU / SQ_WAVES / evaluations "
