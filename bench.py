@@ -441,13 +441,13 @@ def cpu_baseline(I0, I1, budget_s=12.0):
             "scaling_vs_single_thread": {"with_pyramid": nall / el / single, "flow_only": nflow / el_flow / (1e3 / flow_ms)},
             "single_thread": single, "single_thread_flow_only": 1e3 / flow_ms,
             "single_thread_stage_ms_per_pair": {k: round(v, 3) for k, v in st.items()}, "time_lines": time_lines,
-            "sample": "%d of the batch's 1080p pairs (cycled), op-pt 2 + refinement, pyramid of all levels included like the "
-                      "reference's driver builds it (kroeger/run_dense.cpp:130-178), oracle/dis_oracle.c built on this host with %s, "
-                      "one pair per thread on %d pthreads (dis_flow_many: per-thread block caches, no allocation per pair) in %.1f s; "
-                      "flow only (pyramids built once per thread): %d pairs in %.1f s; single thread: %d pairs at %.1f pairs/s with the "
-                      "pyramid, %.1f pairs/s flow only (what the reference prints as O.Flow Run-Time, kroeger/oflow.cpp:355-360, excludes the "
-                      "pyramid); the survey's probe of the real kroeger build (Eigen, -O3 -msse4) measured ~130 pairs/s/core flow only on a "
-                      "2.1 GHz Xeon" % (nall, flags, threads, el, nflow, el_flow, n1, single, 1e3 / flow_ms)}
+            "sample": "`value`: %d runs of the flow (kroeger/oflow.cpp:184-337: LK, densification, refinement of the three scales) on pairs of the "
+                      "batch (every thread keeps the pyramids of one pair, built outside the timed region like the reference's O.Flow Run-Time "
+                      "excludes them, kroeger/oflow.cpp:355-360), op-pt 2 + refinement, one pair per thread on %d pthreads in %.1f s (dis_flow_many: "
+                      "per-thread block caches, no allocation per pair), oracle/dis_oracle.c built on this host with %s; beside it: %d pairs with "
+                      "padding + both pyramids in the loop (kroeger/run_dense.cpp:130-178, scalar in the port) in %.1f s; single thread: %d pairs at "
+                      "%.1f pairs/s with the pyramid, %.1f pairs/s flow only; the survey's probe of the real kroeger build (Eigen, -O3 -msse4) "
+                      "measured ~130 pairs/s/core flow only on a 2.1 GHz Xeon" % (nflow, threads, el_flow, flags, nall, el, n1, single, 1e3 / flow_ms)}
 
 
 def _free_port():
