@@ -43,7 +43,10 @@ import time
 # HIP deals its streams to GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream included); two busy streams on one
 # queue run one after the other.  Four batches in flight need a queue each (measured: 134 k pairs/s with 4 queues, 165 k with 8).
 # Read by the runtime when it is loaded, i.e. before torch is imported; an explicit setting of the caller wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (16, not the 5 the headline's four slots need: HIP deals ALL streams a process creates to the queues in turn, so the pipes of the
+# later legs -- node API, 4K pairs in flight -- would otherwise land two busy streams on one queue: 139 k instead of 183 k pairs/s
+# for a pipe created after another one, tools/two_pipes.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -779,6 +782,33 @@ def main():
                                               "algorithmic_bytes_per_launch": alg3, "ms_per_launch": ms3}}
             ofc3.close()
             del R0, R1
+            # the one-process multi-GPU entry (fotg_node_*: one pipe + one issuing host thread per device slot) on this rank's GPU alone:
+            # the same steps through the C-ABI a C++ host would use; must not be slower than the pipe it wraps
+            if pipe:
+                from flowonthego_amd.node import FlowNode
+                node = FlowNode(op, F.img_params(width=W, height=H, padding=op.patch_size), devices=[local], max_batch=a.batch, depth=D)
+                sync()
+                outs_n = [[o] for (_, _, o) in slots]
+                tickets = []
+
+                def node_steps(n):
+                    for i in range(n):
+                        f0, f1, _ = slots[i % D]
+                        tickets.append(node.submit(a.batch, [f0], [f1], outs_n[i % D])[0])
+                        if len(tickets) > 8:
+                            node.wait(tickets.pop(0))
+                    node.synchronize()
+                    tickets.clear()
+                node_steps(2 * D)
+                t1 = time.perf_counter()
+                node_steps(a.steps)
+                tn = (time.perf_counter() - t1) / a.steps
+                ofc.calc_batch(slots[0][0], slots[0][1], None, out)
+                sync()
+                res["node_api"] = {"value": a.batch / tn, "unit": "frame-pairs/s", "ms_per_step": tn * 1e3, "devices": [local], "batches_in_flight": D,
+                                   "same_bits_as_single_context": bool(torch.equal(outs_n[0][0], out)),
+                                   "note": "fotg_node_submit / fotg_node_wait (include/fotg.h) with one device slot: K steps, one window"}
+                node.close()
             # BASELINE configs[3]
             res["config_4k_op4"] = config_4k_op4(F, OFClass, lib, local, dev, stream_ptr)
         if a.extras:

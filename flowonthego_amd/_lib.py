@@ -41,6 +41,7 @@ SYMBOLS = [
     ("fotg_pipe_submit_u8", C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_long)]),
     ("fotg_pipe_wait", C.c_int, [vp, C.c_long, vp, C.c_int]),
     ("fotg_pipe_sync", C.c_int, [vp]),
+    ("fotg_pipe_ticket_event", C.c_int, [vp, C.c_long, C.POINTER(vp)]),
     ("fotg_pipe_context", C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     ("fotg_node_create", C.c_int, [C.POINTER(FotgParams), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     ("fotg_node_destroy", None, [vp]),

@@ -1436,6 +1436,17 @@ int fotg_pipe_wait(fotg_pipe *q, long ticket, void *stream, int host_wait)
   return FOTG_OK;
 }
 
+/* the completion event (hipEvent_t) of batch `ticket`: for callers that wait from another thread than the one that submits, or
+ * on several pipes at once (fotg_node_wait) -- hipEventSynchronize / hipStreamWaitEvent on it touch no state of the pipe.  Valid
+ * for the next 4 * depth submissions; after that it belongs to a later batch of the same slot (waiting for it still covers the
+ * ticket). */
+int fotg_pipe_ticket_event(fotg_pipe *q, long ticket, void **event)
+{
+  if (!q || !event || ticket < 0) return FOTG_ERR_ARG;
+  *event = (void *)q->done[ticket % q->nring];
+  return FOTG_OK;
+}
+
 int fotg_pipe_sync(fotg_pipe *q)
 {
   if (!q) return FOTG_ERR_ARG;

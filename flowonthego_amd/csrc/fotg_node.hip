@@ -9,8 +9,9 @@
 //              t + 1 travels, and push the flows back into the caller's array -- the C++ twin of
 //              flowonthego_amd/shard.py: pipelined_scatter_compute (RCCL send / recv between processes there, peer copies here).
 // The host threads only ISSUE work (a step is 23 launches, ~0.07 ms of host time per device: one thread could not feed eight
-// GPUs at 0.36 ms per step); they never wait for the GPU.  Completion is an event per (job, slot) that fotg_node_wait
-// synchronises with.  gfx950 only.
+// GPUs at 0.36 ms per step); they never wait for the GPU.  fotg_node_wait synchronises with the pipes' own completion events of
+// the job's pieces (no stream of the node's own on the resident path: a stream that only waits still occupies a hardware queue
+// and blocks the slot stream that shares it -- measured: 134 k instead of 187 k pairs/s on one GPU).  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
@@ -37,8 +38,11 @@ struct Slot {
   int device = 0, index = 0;
   fotg_pipe *pipe = nullptr;
   std::thread th;
-  hipStream_t copy = nullptr, join = nullptr;  // peer copies of the scatter mode; the stream the completion event is recorded on
-  hipEvent_t done[RING] = {};                  // completion of job id on this slot: done[id % RING]
+  hipStream_t copy = nullptr;                  // peer copies of the scatter mode (created with the staging buffers)
+  hipEvent_t done[RING] = {};                  // scatter jobs: completion of job id on this slot (recorded on `copy`): done[id % RING]
+  std::vector<hipEvent_t> piece_ev[RING];      // resident jobs: the pipe's own completion events of the job's pieces (no extra stream:
+                                               // a stream that only waits would still occupy -- and block -- a hardware queue)
+  bool on_copy[RING] = {};
   int status[RING] = {};                       // issue status of job id on this slot
   long issued = 0;                             // jobs this slot's thread has issued (guarded by the node's mutex)
   // scatter mode: depth + 1 staging buffers of 2 x chunk frames + chunk flows each
@@ -67,15 +71,19 @@ struct OnDevice {
   ~OnDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-// the completion event of (job, slot): `join` waits on the device for every pipe ticket of the job (and for the copy stream in
-// scatter mode), then the event is recorded there
+// completion of (job, slot): the pipe's own events of the job's pieces (resident frames, the source slot of a scatter) or an
+// event behind the last copy on the slot's copy stream (the pulling slots of a scatter)
 int finish_job(Slot &s, const Job &j, const std::vector<long> &tickets)
 {
+  std::vector<hipEvent_t> &ev = s.piece_ev[j.id % RING];
+  ev.clear();
   for (long t : tickets) {
-    const int st = fotg_pipe_wait(s.pipe, t, s.join, 0);
+    void *e = nullptr;
+    const int st = fotg_pipe_ticket_event(s.pipe, t, &e);
     if (st != FOTG_OK) return st;
+    ev.push_back((hipEvent_t)e);
   }
-  if (hipEventRecord(s.done[j.id % RING], s.join) != hipSuccess) return FOTG_ERR_HIP;
+  s.on_copy[j.id % RING] = false;
   return FOTG_OK;
 }
 
@@ -149,6 +157,8 @@ int issue_scatter(fotg_node *nd, Slot &s, const Job &j)
   for (int q = piece > nbuf ? piece - nbuf : 0; q < piece; ++q) { const int st = push_back_flows(q); if (st != FOTG_OK) return st; }
   // the job's event: behind the last copy on the copy stream (which is behind every compute of the job)
   if (hipEventRecord(s.done[j.id % RING], s.copy) != hipSuccess) return FOTG_ERR_HIP;
+  s.on_copy[j.id % RING] = true;
+  s.piece_ev[j.id % RING].clear();
   return FOTG_OK;
 }
 
@@ -228,13 +238,11 @@ void fotg_node_destroy(fotg_node *nd)
     Slot &s = nd->slot[k];
     OnDevice od(s.device);
     if (s.copy) (void)hipStreamSynchronize(s.copy);
-    if (s.join) (void)hipStreamSynchronize(s.join);
     if (s.pipe) fotg_pipe_destroy(s.pipe);
     for (void *p : s.stage_in) (void)hipFree(p);
     for (float *p : s.stage_out) (void)hipFree(p);
     for (auto &e : s.done) if (e) (void)hipEventDestroy(e);
     if (s.copy) (void)hipStreamDestroy(s.copy);
-    if (s.join) (void)hipStreamDestroy(s.join);
   }
   delete nd;
 }
@@ -255,7 +263,6 @@ int fotg_node_create(const fotg_params *p, int w_org, int h_org, const int *devi
     OnDevice od(s.device);
     int st = fotg_pipe_create(p, w_org, h_org, s.device, max_batch, depth, &s.pipe);
     if (st != FOTG_OK) { fotg_node_destroy(nd); return st; }
-    if (hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s.join, hipStreamNonBlocking) != hipSuccess) { fotg_node_destroy(nd); return FOTG_ERR_HIP; }
     for (auto &e : s.done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { fotg_node_destroy(nd); return FOTG_ERR_HIP; }
     // peer access to the source device of the scatter mode (slot 0's): direct xGMI copies instead of staging through the host
     if (k > 0 && s.device != nd->slot[0].device) {
@@ -293,6 +300,7 @@ int fotg_node_submit_scatter(fotg_node *nd, int n, const float *I0, const float 
     Slot &s = nd->slot[k];
     if (!s.stage_in.empty()) continue;
     OnDevice od(s.device);
+    if (!s.copy && hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking) != hipSuccess) return FOTG_ERR_HIP;
     for (int b = 0; b < nd->depth + 1; ++b) {
       void *in = nullptr; float *o = nullptr;
       if (hipMalloc(&in, 2 * (size_t)nd->max_batch * nd->frame_elems * 4) != hipSuccess || hipMalloc((void **)&o, (size_t)nd->max_batch * nd->flow_elems * 4) != hipSuccess) {
@@ -323,7 +331,8 @@ int fotg_node_wait(fotg_node *nd, long ticket)
       Slot &s = nd->slot[k];
       if (s.status[id % RING] != FOTG_OK) { st = s.status[id % RING]; continue; }
       OnDevice od(s.device);
-      if (hipEventSynchronize(s.done[id % RING]) != hipSuccess) st = FOTG_ERR_HIP;
+      if (s.on_copy[id % RING]) { if (hipEventSynchronize(s.done[id % RING]) != hipSuccess) st = FOTG_ERR_HIP; }
+      else for (hipEvent_t e : s.piece_ev[id % RING]) if (hipEventSynchronize(e) != hipSuccess) st = FOTG_ERR_HIP;
     }
   }
   // a timed-out inter-workgroup wait anywhere on the node since the last wait: the flows of the jobs waited for here are suspect

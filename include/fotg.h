@@ -126,6 +126,9 @@ int fotg_pipe_submit_u8(fotg_pipe *pipe, int n, const unsigned char *I0, const u
 int fotg_pipe_wait(fotg_pipe *pipe, long ticket, void *stream, int host_wait);
 /* the calling thread waits for everything submitted so far */
 int fotg_pipe_sync(fotg_pipe *pipe);
+/* the completion event (a hipEvent_t) of batch `ticket`, for waiting from another thread or on several pipes at once without
+ * touching the pipe: valid for the next 4 * depth submissions (afterwards it belongs to a later batch of the same slot) */
+int fotg_pipe_ticket_event(fotg_pipe *pipe, long ticket, void **event);
 /* the engine context of a slot (geometry queries, taps, counters) */
 int fotg_pipe_context(fotg_pipe *pipe, int slot, fotg_ctx **ctx);
 

@@ -2,7 +2,7 @@
 """pairs/s of the headline workload with D batches in flight, no result checks (A/B timing of experimental builds):
 python tools/inflight_rate.py [depth] [batch] [steps] [windows]"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

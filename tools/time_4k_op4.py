@@ -3,7 +3,7 @@
 (--in-flight: also the throughput of consecutive pairs through a FlowPipeline, 2 and 4 pairs in flight)"""
 import sys, time
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # (a hardware queue per pipeline slot, see bench.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")       # (a hardware queue per pipeline slot, see bench.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
