@@ -780,6 +780,21 @@ def main():
                                  "roofline": {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,3,4,true> (RGB frames -> pyramid level 4)", "achieved": alg3 / (ms3 * 1e-3) / 1e9,
                                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                               "algorithmic_bytes_per_launch": alg3, "ms_per_launch": ms3}}
+            if pipe:
+                from flowonthego_amd.pipeline import FlowPipeline as _FP
+                pipe3 = _FP(op3, F.img_params(width=W, height=H, padding=op3.patch_size), max_batch=a.batch, depth=D, device=local)
+                o3 = [pipe3.new_outflow(a.batch) for _ in range(D)]
+                sync()
+                k3 = [0]
+
+                def sub3():
+                    pipe3.submit(R0, R1, None, o3[k3[0] % D], after_current_stream=False)      # (the same frames for every slot: 3.2 GB per step, far beyond any cache)
+                    k3[0] += 1
+                t3f = timed(sub3, pipe3.synchronize, max(nst, 4 * D), warm=2 * D)
+                res["rgb_frames"]["in_flight"] = {"value": a.batch / t3f, "unit": "frame-pairs/s", "ms_per_step": t3f * 1e3, "batches_in_flight": D,
+                                                  "same_bits_as_one_at_a_time": bool(torch.equal(o3[0], ofc3.calc_batch(R0, R1)))}
+                pipe3.close()
+                del o3
             ofc3.close()
             del R0, R1
             # the one-process multi-GPU entry (fotg_node_*: one pipe + one issuing host thread per device slot) on this rank's GPU alone:
