@@ -477,7 +477,7 @@ def self_launch(gpus, argv, device_count=None, run=None):
     device_count / run: injection points of tests/test_host.py."""
     import subprocess
     have = (device_count or torch.cuda.device_count)()
-    if gpus > have:
+    if gpus > have and not (os.environ.get("FOTG_BENCH_ALLOW_SHARED_GPU") and have >= 1):
         fail("--gpus %d requested, %d GPU(s) visible on this node: refusing to run on fewer GPUs than asked for" % (gpus, have), requested_gpus=gpus, visible_gpus=have)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
@@ -531,6 +531,12 @@ def main():
              "--nproc-per-node %d ... bench.py --gpus %d) or run `python bench.py --gpus %d` and let it launch them" %
              (a.gpus, world, world, a.gpus, a.gpus, a.gpus), rank=rank)
     ndev = torch.cuda.device_count()
+    # FOTG_BENCH_ALLOW_SHARED_GPU=1 (tests on a one-GPU box): the ranks of a multi-rank run share the visible GPUs and talk over gloo
+    # (RCCL refuses two ranks on one device) -- the launcher, the world-size checks, the barriers and the reductions of the N > 1
+    # path run for real, the line is marked "shared_gpu_test" and is NOT a scaling measurement
+    shared = bool(os.environ.get("FOTG_BENCH_ALLOW_SHARED_GPU")) and world > 1
+    if shared and ndev >= 1:
+        local = local % ndev
     if local >= ndev:
         fail("rank %d: LOCAL_RANK %d but %d GPU(s) visible" % (rank, local, ndev), rank=rank)
     dist = world > 1 or bool(os.environ.get("FOTG_BENCH_FORCE_DIST"))      # the switch exercises the RCCL path on a 1-GPU box
@@ -541,9 +547,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if shared:
+            td.init_process_group("gloo")
+        else:
+            td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        rdev = torch.device("cpu") if shared else torch.device("cuda", local)          # where the reduction tensors live
         # how many ranks RCCL really connected (an all-reduce of ones), and which physical GPU each one sits on
-        ones = torch.ones(1, device=torch.device("cuda", local), dtype=torch.float64)
+        ones = torch.ones(1, device=rdev, dtype=torch.float64)
         td.all_reduce(ones)
         rccl_ranks = int(ones.item())
         if rccl_ranks != a.gpus or td.get_world_size() != a.gpus:
@@ -603,7 +613,7 @@ def main():
         if pipelined or D == 1:
             local_els.append(el)
         if dist:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            t = torch.tensor([el], device=rdev, dtype=torch.float64)
             td.all_reduce(t, op=td.ReduceOp.MAX)
             el = float(t.item())
         return el
@@ -639,7 +649,7 @@ def main():
         pipe.synchronize()
     per_rank = None
     if dist:
-        mine = torch.tensor([sorted(local_els)[len(local_els) // 2] / a.steps * 1e3], device=dev, dtype=torch.float64)
+        mine = torch.tensor([sorted(local_els)[len(local_els) // 2] / a.steps * 1e3], device=rdev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         td.all_gather(allr, mine)
         per_rank = [float(t.item()) for t in allr]
@@ -671,6 +681,9 @@ def main():
     if per_rank is not None:
         res["ms_per_step_per_rank"] = per_rank
     res["rccl_ranks"] = rccl_ranks            # ranks an all-reduce of ones counted (None: single process, RCCL not initialised)
+    if dist and shared:
+        res["shared_gpu_test"] = True         # ranks share GPUs and use gloo: exercises the N > 1 entry, NOT a scaling measurement
+        res["metric"] += " [SHARED-GPU TEST RUN: %d ranks on %d GPU(s), gloo]" % (world, ndev)
     res["rank_placement"] = placement
 
     if rank == 0:
@@ -855,7 +868,7 @@ def main():
             res["cpu_baseline"]["parity"] = {"pairs_checked": 2, "mean_epe_px": float(np.sqrt((d ** 2).sum(-1)).mean()),
                                              "max_abs_diff": float(np.abs(d).max()), "bit_identical": bool((d == 0).all())}
         print(json.dumps(res))
-    if dist and a.scatter_gather:
+    if dist and a.scatter_gather and not shared:
         # end to end with the frames starting on rank 0 and the flows ending there (RCCL over xGMI: scatter + gather only)
         # chunked, double-buffered: chunk t+1 travels (grouped ncclSend/ncclRecv) while chunk t is computed; nothing is padded
         from flowonthego_amd.shard import PipeEngine, gather_flows_exact, pipelined_scatter_compute

@@ -236,3 +236,29 @@ def test_cpp_multi_gpu_example(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         assert np.array_equal(np.fromfile(out, np.float32).reshape(ref.shape), ref), mode
         os.remove(out)
+
+
+def test_bench_gpus_2_end_to_end_on_one_gpu():
+    """`python bench.py --gpus 2` exactly as the driver would type it, on a one-GPU box: without FOTG_BENCH_ALLOW_SHARED_GPU it
+    refuses (1 GPU visible); with it the launcher starts two ranks that share the GPU and talk over gloo, so the whole N > 1 entry
+    -- self-launch through torch.distributed.run, WORLD_SIZE == --gpus check, barriers, max-over-ranks reduction, per-rank times,
+    rank placement -- runs for real and prints ONE line with n_gpus = 2, marked as a shared-GPU test run"""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FOTG_BENCH_ALLOW_SHARED_GPU")}
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "16", "--steps", "8", "--warmup", "2", "--windows", "3",
+            "--no-cpu-baseline", "--no-breakdown"]
+    r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
+    r = subprocess.run(args, env=dict(env, FOTG_BENCH_ALLOW_SHARED_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1                                          # rank 0 prints, once
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["shared_gpu_test"] is True and "SHARED-GPU TEST RUN" in d["metric"]
+    assert len(d["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in d["ms_per_step_per_rank"])
+    assert d["config"]["global_batch"] == 32 and d["value"] > 0 and d["pipeline_matches_single_context"]
+    assert [p["rank"] for p in d["rank_placement"]] == [0, 1]
