@@ -754,6 +754,22 @@ def main():
             ofc1.close()
             sync = torch.cuda.synchronize
             nst = max(5, min(a.steps, 20))
+            # the reference's post-processing on the device (kroeger/run_dense.cpp:407-414: x 2^finest, bilinear upsample, crop): the
+            # full-resolution flow of the batch; SURVEY 8d counts 2 W H 4 more bytes per pair for it
+            full = torch.empty((a.batch, H, W, 2), device=dev)
+            sync()
+            ev = HipEvents()
+            from flowonthego_amd._lib import check as _chk
+            msu = ev.time_ms(lambda: _chk(lib.fotg_upsample_crop(ofc._h, a.batch, C.c_void_p(out.data_ptr()), C.c_void_p(full.data_ptr()), stream_ptr)), stream_ptr, 10)
+            algu = a.batch * (2 * W * H * 4 + 2 * 120 * 68 * 4)
+            tfu = timed(lambda: (ofc.calc_batch(I0, I1, None, out), ofc.upsample_crop(out, full)), sync, nst)
+            res["full_resolution_output"] = {"value": a.batch / tfu, "unit": "frame-pairs/s", "ms_per_step": tfu * 1e3,
+                                             "note": "fotg_calc_batch + fotg_upsample_crop (the reference's post-processing on the device), one batch at a time",
+                                             "roofline": {"bound": "hbm", "kernel": "fotg::upsample_crop_kernel (120x68x2 flow -> 1920x1080x2, %d pairs)" % a.batch,
+                                                          "achieved": algu / (msu * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                          "frac": algu / (msu * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                          "algorithmic_bytes_per_launch": algu, "ms_per_launch": msu}}
+            del full
             # video mode (fotg_calc_sequence): batch + 1 consecutive frames -> batch flows, every pyramid built once
             seq = torch.cat([I0, I1[-1:]]).contiguous()
             tsq = timed(lambda: ofc.calc_sequence(seq, None, out), sync, nst)

@@ -1569,9 +1569,20 @@ int fotg_upsample_crop(fotg_ctx *c, int n, const float *flow, float *out, void *
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
   ON_DEVICE(c->device);
   const LevelGeom &g = c->geom[c->p.sc_l];
-  dim3 grid((c->w_org * c->h_org + 255) / 256, n), block(256);
-  upsample_crop_kernel<<<grid, block, 0, (hipStream_t)stream>>>(flow, (long)g.w * g.h * c->nch, g.w, g.h, c->p.sc_l, c->padw / 2, c->padh / 2,
-                                                                 c->w_org, c->h_org, out, (long)c->w_org * c->h_org * c->nch, c->nch);
+  // four pixels per thread on a (columns, row, pair) grid
+  const int tpr = (c->w_org + 3) / 4;                                 // threads per row
+  const int bx = tpr >= 256 ? 256 : ((tpr + 63) / 64) * 64;
+  dim3 grid((tpr + bx - 1) / bx, c->h_org, n), block(bx);
+  if (c->h_org <= 65535 && n <= 65535) {
+    if (c->nch == 2) upsample_crop4_kernel<2><<<grid, block, 0, (hipStream_t)stream>>>(flow, (long)g.w * g.h * 2, g.w, g.h, c->p.sc_l, c->padw / 2, c->padh / 2,
+                                                                                        c->w_org, c->h_org, out, (long)c->w_org * c->h_org * 2);
+    else upsample_crop4_kernel<1><<<grid, block, 0, (hipStream_t)stream>>>(flow, (long)g.w * g.h, g.w, g.h, c->p.sc_l, c->padw / 2, c->padh / 2,
+                                                                            c->w_org, c->h_org, out, (long)c->w_org * c->h_org);
+  } else {
+    dim3 grid1((c->w_org * c->h_org + 255) / 256, n), block1(256);
+    upsample_crop_kernel<<<grid1, block1, 0, (hipStream_t)stream>>>(flow, (long)g.w * g.h * c->nch, g.w, g.h, c->p.sc_l, c->padw / 2, c->padh / 2,
+                                                                     c->w_org, c->h_org, out, (long)c->w_org * c->h_org * c->nch, c->nch);
+  }
   LAUNCHCHK();
   return FOTG_OK;
 }
