@@ -262,3 +262,29 @@ def test_bench_gpus_2_end_to_end_on_one_gpu():
     assert len(d["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in d["ms_per_step_per_rank"])
     assert d["config"]["global_batch"] == 32 and d["value"] > 0 and d["pipeline_matches_single_context"]
     assert [p["rank"] for p in d["rank_placement"]] == [0, 1]
+
+
+def test_node_reports_a_stalled_wait(monkeypatch):
+    """a timed-out inter-workgroup wait in any context of any slot surfaces at fotg_node_wait as FOTG_ERR_STALL, once"""
+    import ctypes as C
+    import torch
+    from flowonthego_amd.node import FlowNode
+    monkeypatch.setenv("FOTG_TEST_TAPS", "1")
+    F, op, ip, G0, G1, want = _node_setup(4, seed=600)
+    L = F.lib()
+    node = FlowNode(op, ip, devices=[0, 0], max_batch=2, depth=2)
+    I0 = [G0[:2].contiguous(), G0[2:].contiguous()]; I1 = [G1[:2].contiguous(), G1[2:].contiguous()]
+    torch.cuda.synchronize()
+    t, o = node.submit(4, I0, I1)
+    node.wait(t)
+    assert torch.equal(torch.cat(o), want)
+    pipe, ctx = C.c_void_p(), C.c_void_p()
+    assert L.fotg_node_pipe(node._h, 1, pipe) == 0 and L.fotg_pipe_context(pipe, 0, ctx) == 0
+    assert L.fotg_ctx_counter(ctx, b"inject_stall") == 0
+    t, o = node.submit(4, I0, I1)
+    with pytest.raises(F.FotgError):
+        node.wait(t)                                               # FOTG_ERR_STALL
+    t, o = node.submit(4, I0, I1)
+    node.wait(t)                                                   # reported once; the node is usable again
+    assert torch.equal(torch.cat(o), want)
+    node.close()
