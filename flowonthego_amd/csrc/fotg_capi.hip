@@ -900,7 +900,7 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
       const int sw = sweeps - done < 4 ? sweeps - done : 4;
       // (the data-term launch in front of the call has cleared the words already when the caller arranged that: VrArgs::zsync)
       if (!(sync_zeroed && done == 0)) (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n) * sizeof(int), s);
-      vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sw, 128, 0, s>>>(a, g, sw, omega);
+      vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sw, FOTG_TILE_THREADS, 0, s>>>(a, g, sw, omega);
       ++g_tile_launches;
     }
     return;

@@ -4,7 +4,7 @@
 // solvers; round 1 relaxed them with one workgroup per pair (vr_sor_wide_kernel), i.e. on ONE CU, bound by that CU's L2 path
 // (three sweeps x 544 cells x 48 B per diagonal): 1.0 .. 1.5 ms per call, 57 % of a 4K operating-point-4 pair.
 //
-// Here the call is cut into TILES = (sweep n, band b of 64 rows), one workgroup (solver wave + writer wave) each, all running at once:
+// Here the call is cut into TILES = (sweep n, band b of 64 rows), one workgroup (solver, writer and poller wave) each, all running at once:
 //   tile (b, n) relaxes the cells of its rows diagonal by diagonal (the anti-diagonal wavefront of the lexicographic order) and
 //   needs   the NEW values of the row above its band        from tile (b-1, n)    one diagonal back,
 //           the OLD values (= sweep n-1) of its own rows     from tile (b,   n-1)  one diagonal ahead,
@@ -12,15 +12,17 @@
 // Every dependency points to a smaller b + 2n, so the tiles form a pipeline: each follows its producers at the distance the
 // hand-over needs (prefetch depth + publication granularity + latency, ~22 diagonals) and a call takes
 // (w + h) + ~22 (bands - 1 + 2 (sweeps - 1)) single-wave steps of ~0.13 us instead of (w + h + 12) steps of 0.7 .. 1 us
-// (measured: 75 / 135 / 238 us per call at 240x136 / 480x272 / 960x544; DESIGN.md section 5, "Tile pipeline").
+// (measured: 66 / 113 / 204 us per call at 240x136 / 480x272 / 960x544; DESIGN.md section 5, "Tile pipeline").
 // Same cell updates in the same order as the row-major loop, hence the same bits.
 //
 // Hand-over through global memory (MI355X_MICROARCH.md, inter-workgroup visibility): sweep n writes the skewed array X[n]
 // (sweep 0 reads the level's D, the last sweep also stores its results there), every access of a handed-over cell is a relaxed agent-scope
-// 8-byte atomic (global_load / global_store ... sc1).  A tile is TWO waves: the solver wave only loads (a wave's vector-memory
+// 8-byte atomic (global_load / global_store ... sc1).  A tile is THREE waves: the solver wave only loads data (a wave's vector-memory
 // operations complete in order, so a load issued behind a write-through store is not back before that store is acknowledged --
-// microseconds), hands its results to the WRITER wave through a small LDS ring, one barrier per G diagonals; the writer
-// stores them, and publishes a chunk's progress two chunks later, when a counted vmcnt says those stores have completed
+// microseconds -- and a data load issued behind a poll of a word another CU keeps writing waits for that poll), hands its
+// results to the WRITER wave through a small LDS ring, one barrier per G diagonals, and learns how far its producers are from
+// LDS words the POLLER wave keeps fresh with direct-to-LDS loads of the progress words; the writer
+// stores the results, and publishes a chunk's progress two chunks later, when a counted vmcnt says those stores have completed
 // (stores that have no cell to go to land in a dump area used round robin: write-through stores to ONE line queue up);
 // X rows are a whole number of 128-byte lines, bands start on a line, one store instruction writes a band's 64 consecutive
 // cells = four whole lines.  Roles come from a ticket counter in the order of b + 2n: a tile
@@ -56,6 +58,10 @@ __host__ __device__ inline long tile_sync_words(int npairs) { return 32L * (1 + 
 #ifndef FOTG_TILE_U
 #define FOTG_TILE_U 32         // steps per loop trip
 #endif
+#define FOTG_TILE_THREADS 192  // solver wave, writer wave, poller wave
+#ifndef FOTG_TILE_DBG
+#define FOTG_TILE_DBG 0        // timing-only elimination builds (wrong results): 1 no polls, 2 no writer / barriers, 4 no loads in the loop
+#endif
 
 __device__ __forceinline__ float2 ld_sc1_f2(const float2 *p)
 {
@@ -83,12 +89,13 @@ __device__ __forceinline__ float dpp_wave_shl1_old(float old, float src)
 }
 
 template <int P>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void vr_sor_tile_kernel(VrArgs a, TileArgs g, int nsweeps, float omega)
+__global__ __launch_bounds__(FOTG_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) void vr_sor_tile_kernel(VrArgs a, TileArgs g, int nsweeps, float omega)
 {
   constexpr int G = FOTG_TILE_G, BR = FOTG_TILE_ROWS, U = FOTG_TILE_U, RING = 2 * G, W = FOTG_TILE_W;
   static_assert(U % P == 0 && P % G == 0 && U % G == 0 && U % RING == 0, "ring slots and barrier phase are compile-time");
   __shared__ float2 res_ring[RING][BR];
   __shared__ int role_s;
+  __shared__ int seen_lds[4];                                     // the producers' progress words as the poller wave last saw them (own, below, top)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int S = a.S, RP = a.RP, RPD = a.RPD, h = a.h;
   // ---- role: ticket -> (pair, tile), tiles in the order of b + 2n
@@ -122,9 +129,37 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                                                                   // nothing in this launch reads them there)
   const int rb = b * BR, r1 = rb + lane;
   const int T = ((S + U - 1) / U) * U;                             // solver steps (those past S-1 run on the zero row with omega = 0)
-  const int NBAR = T / G + 1;                                     // barriers both waves execute
+  const int NBAR = T / G + 1;                                     // barriers every wave executes
+
+  // the producers' progress as last seen by the poller wave ("everything" for producers a tile does not have)
+  if (threadIdx.x < 3) seen_lds[threadIdx.x] = (threadIdx.x == 0 ? prog_own : threadIdx.x == 1 ? prog_bel : prog_top) ? -1 : 0x3fffffff;
+  __syncthreads();
+
+  // ======================================== poller wave ========================================
+  // Behind every barrier it asks for the three progress words with direct-to-LDS loads (no registers, nothing to wait for):
+  // they land in seen_lds whenever they land, and the solver wave reads them there with an LDS load.  The polls used to be
+  // vector-memory loads of the solver wave itself: a wave's loads return in issue order, so every poll of a line another CU keeps
+  // writing through held back the data loads behind it, and a wait on a poll was a wait on a full memory round trip (a third
+  // of the solver's time at 4K).  Only a solver that has caught up with a producer polls itself (a blocking load, below).
+  if (wv == 2) {
+    if (FOTG_TILE_DBG & (1 | 8)) return;
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    for (int k = 0; k < NBAR; ++k) {
+      asm volatile("s_barrier" ::: "memory");
+      if (lane == 0) {
+        if (prog_own) __builtin_amdgcn_global_load_lds((gvoid *)prog_own, (lvoid *)&seen_lds[0], 4, 0, 16);      // (aux 16 = sc1)
+        if (prog_bel) __builtin_amdgcn_global_load_lds((gvoid *)prog_bel, (lvoid *)&seen_lds[1], 4, 0, 16);
+        if (prog_top) __builtin_amdgcn_global_load_lds((gvoid *)prog_top, (lvoid *)&seen_lds[2], 4, 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");            // at most three intervals' polls in flight
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may land after the workgroup's LDS is released
+    return;
+  }
 
   // ======================================== writer wave ========================================
+  if ((FOTG_TILE_DBG & 2) && wv == 1) return;
   if (wv == 1) {
     // interval k (behind barrier #k): the results of chunk k-1 (diagonals (k-1) G .. k G - 1) are in the LDS ring.  Every row store
     // is issued by every lane (lanes whose row does not exist in the array store into the spare row S+1 of X, which nobody
@@ -213,11 +248,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   const long long st_t0 = wall_clock64();
   int st_which = 0;
 #endif
-  auto wait_for = [&](const int *p, int &seen, int need) {
+  // The solver's own (blocking) polls are hand-placed loads and waits in inline assembly: a load the compiler can see inside the
+  // conditional poll code makes it give up its exact vmcnt bookkeeping for the whole step loop -- every interval then waited for
+  // all but the data loads it had just issued instead of those of two intervals ago.
+  auto poll_now = [&](const int *p) __attribute__((always_inline)) {
+    int v;
+    asm volatile("global_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(0), "s"(p) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);                     // (every lane read the same word: keep the control flow scalar)
+  };
+  auto wait_for = [&](const int *p, int &seen, int need) __attribute__((always_inline)) {
     if (seen >= need) return;
     int spins = 0;
     do {
-      seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      seen = poll_now(p);
       if (seen >= need) break;
       __builtin_amdgcn_s_sleep(2);
     } while (++spins < (1 << 20));
@@ -225,7 +268,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     st_spins[st_which] += spins + 1;
 #endif
     if (seen < need) {                                            // bounded wait: report and go on (the result is wrong, nothing hangs)
-      if (lane == 0) { atomicAdd(g.timeouts, 1); __hip_atomic_store(g.stall_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+      if (lane == 0) {
+        asm volatile("global_atomic_add %0, %1, %2\n\tglobal_store_dword %0, %1, %3 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     :: "v"(0), "v"(1), "s"(g.timeouts), "s"(g.stall_flag) : "memory");
+      }
       seen = 0x3fffffff;
     }
   };
@@ -251,36 +297,48 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   unsigned rc = (unsigned)P * cpitch, ri = (unsigned)(P + 1) * ipitch;           // rows of diagonal d = s + P at s = 0
   unsigned rt = b > 0 ? (unsigned)(P - 1) * tpitch : (unsigned)S * tpitch;
   const unsigned tstep = b > 0 ? tpitch : 0;
-  // Before the loads of diagonals d .. d + G - 1 are issued their producers must have published them.  The progress words are
-  // polled ASYNCHRONOUSLY: every check issues the loads whose values the next check (G steps later) consumes, so in the steady
-  // state -- a tile follows its producers at their pace -- nothing waits here; only a tile that has caught up polls in a loop.
-  int fut_own = seen_own, fut_bel = seen_bel, fut_top = seen_top;
-  auto ensure = [&](int d) {
-    const int dmax = d + G - 1;
-    const int need_in = dmax + 1 < S - 1 ? dmax + 1 : S - 1, need_top = dmax - 1 < S - 1 ? dmax - 1 : S - 1;
+  // Before the loads of diagonals d .. d + G - 1 are issued their producers must have published them: the check behind every
+  // barrier reads the poller wave's latest view from LDS; in the steady state -- a tile follows its producers at their pace --
+  // that is enough, and only a tile that has caught up polls the words itself (the words of producers it does not have read
+  // "everything" from the start; the poll addresses are then its own word, never used).
+  const int *const pw_own = prog_own ? prog_own : prog, *const pw_bel = prog_bel ? prog_bel : prog, *const pw_top = prog_top ? prog_top : prog;
+  auto need_in_of = [&](int d) { const int dmax = d + G - 1; return dmax + 1 < S - 1 ? dmax + 1 : S - 1; };
+  auto need_top_of = [&](int d) { const int dmax = d + G - 1; return dmax - 1 < S - 1 ? dmax - 1 : S - 1; };
+  auto ensure_blocking = [&](int d) __attribute__((always_inline)) {
+    if (FOTG_TILE_DBG & 1) return;
 #ifdef FOTG_TILE_STATS
     st_which = 0;
 #endif
-    if (prog_own) { seen_own = fut_own > seen_own ? fut_own : seen_own; wait_for(prog_own, seen_own, need_in); fut_own = __hip_atomic_load(prog_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    wait_for(pw_own, seen_own, need_in_of(d));
 #ifdef FOTG_TILE_STATS
     st_which = 1;
 #endif
-    if (prog_bel) { seen_bel = fut_bel > seen_bel ? fut_bel : seen_bel; wait_for(prog_bel, seen_bel, need_in); fut_bel = __hip_atomic_load(prog_bel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    wait_for(pw_bel, seen_bel, need_in_of(d));
 #ifdef FOTG_TILE_STATS
     st_which = 2;
 #endif
-    if (prog_top) { seen_top = fut_top > seen_top ? fut_top : seen_top; wait_for(prog_top, seen_top, need_top); fut_top = __hip_atomic_load(prog_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    // the data loads below must stay behind the polls in program order (the hardware issues a wave's loads in order and the
-    // branch on the polled value is a control dependency; this keeps the COMPILER from moving them up)
-    asm volatile("" ::: "memory");
+    wait_for(pw_top, seen_top, need_top_of(d));
+  };
+  auto ensure = [&](int d) __attribute__((always_inline)) {
+    if (FOTG_TILE_DBG & 1) return;
+    if (!(FOTG_TILE_DBG & 8)) {
+      const int h0 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&seen_lds[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
+                h1 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&seen_lds[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
+                h2 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&seen_lds[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      seen_own = h0 > seen_own ? h0 : seen_own;
+      seen_bel = h1 > seen_bel ? h1 : seen_bel;
+      seen_top = h2 > seen_top ? h2 : seen_top;
+    }
+    if (seen_own < need_in_of(d) || seen_bel < need_in_of(d) || seen_top < need_top_of(d)) ensure_blocking(d);
   };
   Stage ring[P];
 #pragma unroll
   for (int d0 = 0; d0 < P; d0 += G) {
-    ensure(d0);
+    ensure_blocking(d0);
 #pragma unroll
     for (int k = 0; k < G; ++k) issue(ring[(d0 + k) % P], d0 + k);
   }
+
   // own value of diagonal 0
   const float2 o1_ = ld_x(rsI, i1o, 0);
   v2f own1 = {o1_.x, o1_.y};
@@ -313,7 +371,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #ifdef FOTG_TILE_STATS
         const long long tb0 = clock64();
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the writer may take the previous G diagonals
+        if (!(FOTG_TILE_DBG & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the writer may take the previous G diagonals
 #ifdef FOTG_TILE_STATS
         const long long tb1 = clock64();
         st_bar += tb1 - tb0;
@@ -330,7 +388,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       res_ring[u % RING][lane] = make_float2(res1.x, res1.y);     // -> writer wave (U is a multiple of RING: s % RING == u % RING)
       prev1 = res1; hl1 = st.c1[1].y;
       own1 = rg1;
-      if (fast) { load(st, rc, ri, rt); rc += cpitch; ri += ipitch; rt += tstep; }
+      if (fast && (FOTG_TILE_DBG & 4)) { asm volatile("" : "+v"(st.rb.x), "+v"(st.rb.y), "+v"(st.rb.z), "+v"(st.rb.w), "+v"(st.c1[0].x), "+v"(st.c1[0].y), "+v"(st.c1[0].z), "+v"(st.c1[0].w), "+v"(st.c1[1].x), "+v"(st.c1[1].y), "+v"(st.c1[1].z), "+v"(st.c1[1].w), "+v"(st.top.x), "+v"(st.top.y)); }
+      else if (fast) { load(st, rc, ri, rt); rc += cpitch; ri += ipitch; rt += tstep; }
       else issue(st, s + P);
     }
   };
@@ -338,7 +397,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   int s0 = 0;
   for (; s0 + U - 1 + P <= S - 2; s0 += U) trip(s0, std::true_type());
   for (; s0 < T; s0 += U) trip(s0, std::false_type());
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // barrier #T/G: the last chunk goes to the writer
+  if (!(FOTG_TILE_DBG & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // barrier #T/G: the last chunk goes to the writer
 #ifdef FOTG_TILE_STATS
   if (lane == 0) {
     long long *o = g.stats + t * 32;
