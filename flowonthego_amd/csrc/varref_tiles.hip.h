@@ -60,7 +60,7 @@ __host__ __device__ inline long tile_sync_words(int npairs) { return 32L * (1 + 
 #endif
 #define FOTG_TILE_THREADS 192  // solver wave, writer wave, poller wave
 #ifndef FOTG_TILE_DBG
-#define FOTG_TILE_DBG 0        // timing-only elimination builds (wrong results): 1 no polls, 2 no writer / barriers, 4 no loads in the loop
+#define FOTG_TILE_DBG 0        // timing-only elimination builds (wrong results): 1 no polls, 2 no writer / barriers, 4 no loads in the loop, 8 blocking polls only, 16 writer without stores
 #endif
 
 __device__ __forceinline__ float2 ld_sc1_f2(const float2 *p)
@@ -165,7 +165,17 @@ __global__ __launch_bounds__(FOTG_TILE_THREADS) __attribute__((amdgpu_waves_per_
     // is issued by every lane (lanes whose row does not exist in the array store into the spare row S+1 of X, which nobody
     // reads), so a chunk is exactly NST instructions and "all but the newest NST + 1 have completed" = the chunk before the
     // previous one is in memory: its progress is published now.
-    const bool x1 = r1 < pout, l1 = r1 < RPD;
+    // A store instruction writes TWO diagonals, 16 bytes (two rows' cells) per lane: lanes 0..31 the first, lanes 32..63 the
+    // second -- half the instructions and half the fabric writes of one 8-byte cell per lane (a write-through store is one
+    // fabric write per lane), and the writer, not the solver, was what a step waited for (a chunk's stores are only
+    // acknowledged after a memory round trip and at most W chunks are in flight).  The pitches are even: a pair of rows never
+    // straddles the end of an array.
+    static_assert(G % 2 == 0, "two diagonals per store instruction");
+    const int hi = lane >> 5, q2 = (lane & 31) * 2;
+    const bool x1 = rb + q2 < pout, l1 = rb + q2 < RPD;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)Xout, 0, (S + 1 + FOTG_TILE_DUMP) * pout * 8, 0x00020000);
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    constexpr int NST = G / 2;                                    // X stores per chunk (and as many plain stores into the level's D)
 #ifdef FOTG_TILE_STATS
     long long wstall = 0;
 #endif
@@ -176,8 +186,8 @@ __global__ __launch_bounds__(FOTG_TILE_THREADS) __attribute__((amdgpu_waves_per_
 #ifdef FOTG_TILE_STATS
       const long long tw0 = clock64();
 #endif
-      if (to_level) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W * (2 * G + 1)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W * (G + 1)) : "memory");
+      if (to_level) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W * (2 * NST + 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W * (NST + 1)) : "memory");
 #ifdef FOTG_TILE_STATS
       wstall += clock64() - tw0;
 #endif
@@ -186,22 +196,22 @@ __global__ __launch_bounds__(FOTG_TILE_THREADS) __attribute__((amdgpu_waves_per_
         const int pub = kc < 0 ? -1 : (kc * G + G - 1 < S - 1 ? kc * G + G - 1 : S - 1);
         __hip_atomic_store(prog, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (k == 0) continue;
+      if (k == 0 || (FOTG_TILE_DBG & 16)) continue;
       const int d0 = (k - 1) * G;
 #pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const int d = d0 + j;
-        const float2 v1 = res_ring[d % RING][lane];
+      for (int j = 0; j < G; j += 2) {
+        const int d = d0 + j + hi;
+        const float4 v = *reinterpret_cast<const float4 *>(&res_ring[d % RING][q2]);
         const bool live = d < S;
-        float2 *row = Xout + (size_t)(live ? d : S + 1) * pout;
         // (stores that have no cell to go to -- diagonals past the end, rows beyond the level's own array -- land in a dump
         // area of FOTG_TILE_DUMP rows used round robin: write-through stores to one and the same line would queue up behind
         // each other)
-        float2 *const dump = Xout + (size_t)(S + 1 + (d & (FOTG_TILE_DUMP - 1))) * pout + lane;
-        st_sc1_f2((live && x1) ? row + r1 : dump, v1);
+        const unsigned dumpo = (unsigned)((S + 1 + (d & (FOTG_TILE_DUMP - 1))) * pout + q2) * 8u;
+        const unsigned xo = (live && x1) ? (unsigned)(d * pout + rb + q2) * 8u : dumpo;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rsW, xo, 0, 16);       // (aux 16 = sc1, like st_sc1_f2)
         if (to_level) {
-          float2 *lrow = Dlev + (size_t)(live ? d : 0) * RPD;
-          *((live && l1) ? lrow + r1 : dump) = v1;
+          float2 *const dst = (live && l1) ? Dlev + (size_t)d * RPD + rb + q2 : Xout + (size_t)(S + 1 + (d & (FOTG_TILE_DUMP - 1))) * pout + q2;
+          *reinterpret_cast<float4 *>(dst) = v;
         }
       }
     }
