@@ -359,12 +359,21 @@ __global__ __launch_bounds__(FOTG_TILE_THREADS) __attribute__((amdgpu_waves_per_
     const v2f a1 = {c0.x, c0.y}, bb = {c0.z, c0.w};
     const float a22 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
     v2f sv = hr * right;
-    sv = sv + vt * top;
+    // vt * top with vt read in place (the high half of the register pair the cell was loaded into: the compiler copies it to a
+    // pair of its own first)
+    const v2f vbt = {vb, vt};
+    v2f vtt;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(vtt) : "v"(top), "v"(vbt));
+    sv = sv + vtt;
     sv = sv + vb * bottom;
     sv = sv + bb;
     const v2f B = hl * left + sv;
     const v2f pa = a1 * B;
-    v2f tt = {pa.x + pa.y, c0.y * B.x + a22 * B.y};
+    // two scalar additions (as one packed addition the operands have to be shuffled into pairs first: two copies more)
+    float t0 = pa.x + pa.y, t1 = c0.y * B.x + a22 * B.y;
+    asm("" : "+v"(t0));
+    asm("" : "+v"(t1));
+    v2f tt = {t0, t1};
     tt = tt - own;
     return own + om * tt;
   };
