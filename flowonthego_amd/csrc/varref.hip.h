@@ -879,6 +879,9 @@ __global__ __launch_bounds__(1024) void vr_sor_pipe_kernel(VrArgs a, float omega
 // rows per lane, packed f32; 115 ns per diagonal) against 35.5 us for vr_sor_pipe_kernel (six solver waves on four SIMDs)
 // and 34 us for K = 1 here.  The LDS footprint does not grow with the level's width.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef FOTG_STREAM_DBG
+#define FOTG_STREAM_DBG 0      // timing-only elimination builds (wrong results): 1 loaders issue nothing in the loop, 2 writer without stores, 4 solver waves without arithmetic
+#endif
 template <int RD, int RCW>
 struct StreamGeom {
   static constexpr int DB = RD * 8, CB = RCW * 16, CSLOT = 2 * CB;         // bytes
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
     __syncthreads();
     for (int I = 0; I < NI; ++I) {
       asm volatile("s_barrier" ::: "memory");
-      issue_chunk(role_tag);
+      if (!(FOTG_STREAM_DBG & 1)) issue_chunk(role_tag);
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NG) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may land after the workgroup's LDS is released
@@ -986,7 +989,7 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
       if (I >= WO) {
 #pragma unroll
         for (int k = 0; k < M; ++k) {
-          if (wd < S && lane < RPD / 2) *reinterpret_cast<float4 *>(Dg + ((size_t)wd * RPD) * 8 + lane * 16) = ld_f4(DBASE + wslot + lane * 16);
+          if (!(FOTG_STREAM_DBG & 2) && wd < S && lane < RPD / 2) *reinterpret_cast<float4 *>(Dg + ((size_t)wd * RPD) * 8 + lane * 16) = ld_f4(DBASE + wslot + lane * 16);
           ++wd; wslot += DB; if (wslot == DRING) wslot = 0;
         }
       }
@@ -1045,8 +1048,8 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
         const float2 nnb = ld_f2(d2 + vD + 16);
         const float4 na0 = ld_f4(c1o + vC), nb0 = ld_f4(c1o + vC + 16), na1 = ld_f4(c1o + vC + CB), nb1 = ld_f4(c1o + vC + CB + 16);
         const v2f own0 = {ow.x, ow.y}, own1 = {ow.z, ow.w}, r0 = {nx.x, nx.y}, r1 = {nx.z, nx.w}, bt1 = {nb.x, nb.y};
-        const v2f q0 = relax(own0, ca0, ca1, hl0, p0, top0, r0, r1, o0);
-        const v2f q1 = relax(own1, cb0, cb1, hl1, p1, p0, r1, bt1, o1);      // its top (s-1, 2L) is this lane's previous row-0 result
+        const v2f q0 = (FOTG_STREAM_DBG & 4) ? own0 + top0 : relax(own0, ca0, ca1, hl0, p0, top0, r0, r1, o0);
+        const v2f q1 = (FOTG_STREAM_DBG & 4) ? own1 + p0 : relax(own1, cb0, cb1, hl1, p1, p0, r1, bt1, o1);      // its top (s-1, 2L) is this lane's previous row-0 result
         *reinterpret_cast<float4 *>(lds_bytes() + ((!TAIL || s < S) ? d0 + vD : DUMP + (unsigned)lane * 16)) = make_float4(q0.x, q0.y, q1.x, q1.y);
         hl0 = ca1.y; hl1 = cb1.y;
         p0 = q0; p1 = q1; ow = nx; nx = nnx; nb = nnb; ca0 = na0; cb0 = nb0; ca1 = na1; cb1 = nb1;
