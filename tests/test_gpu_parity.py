@@ -341,6 +341,30 @@ def test_tile_solver_pipeline():
     assert F.lib().fotg_debug_counter(b"sor_tiles") > before
 
 
+def test_tile_solver_more_tiles_than_the_chip_holds():
+    """a batch whose tall levels make more tiles than the chip has room for at once (40 pairs x 5 bands x 3 sweeps = 600 workgroups
+    of three waves at the 480x272 level): the later tiles are only dispatched when earlier ones have ended, the ticket order keeps
+    every wait bounded, and every pair equals the result of the same pair computed alone.  No wait timed out."""
+    F, OFClass, _, O = _mods()
+    pairs = [synth_pair(1080, 1920, seed=20 + k) for k in range(4)]
+    op = F.operating_point(3, 1920, 1)
+    op.grad_descent_iter = 4
+    ip = F.img_params(width=1920, height=1080, padding=op.patch_size)
+    one = OFClass(op, ip, max_batch=1)
+    ref = [one.calc(dev(a), dev(b)).clone() for a, b in pairs]
+    one.close()
+    n = 40
+    ofc = OFClass(op, ip, max_batch=n)
+    f0 = dev(np.stack([pairs[k % 4][0] for k in range(n)])); f1 = dev(np.stack([pairs[k % 4][1] for k in range(n)]))
+    for _ in range(2):
+        out = ofc.calc_batch(f0, f1)
+        torch.cuda.synchronize()
+        for k in range(n):
+            assert torch.equal(out[k], ref[k % 4]), k
+    assert F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
+    ofc.close()
+
+
 def test_flow_pipeline_batches_in_flight():
     """FlowPipeline (fotg_pipe_*): consecutive batches go to `depth` engine contexts on internal streams in turn and overlap;
     every batch has the bits of OFClass.calc_batch -- different inputs and batch sizes per submit, more submits than slots,
