@@ -341,6 +341,23 @@ def test_tile_solver_pipeline():
     assert F.lib().fotg_debug_counter(b"sor_tiles") > before
 
 
+def test_tile_solver_rgb_frames():
+    """the tile pipeline under a three-channel data term (op-pt 3, 640 x 528 RGB: levels of 132 and 264 rows), batch of two:
+    bit-identical to the oracle, no wait timed out"""
+    F, OFClass, _, O = _mods()
+    f0, f1 = synth_pair(528, 640, seed=31, noc=3)
+    op = F.operating_point(3, 640, 3)
+    op.grad_descent_iter = 6
+    ofc = OFClass(op, F.img_params(width=640, height=528, padding=op.patch_size), max_batch=2)
+    before = F.lib().fotg_debug_counter(b"sor_tiles")
+    out = ofc.calc_batch(dev(np.stack([f0, f1])), dev(np.stack([f1, f0]))).cpu().numpy()
+    p = oracle_params(O, op)
+    a, b = O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f)
+    assert np.array_equal(out[0], O.flow(a, b, p, 0)) and np.array_equal(out[1], O.flow(b, a, p, 0))
+    assert F.lib().fotg_debug_counter(b"sor_tiles") > before and F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
+    ofc.close()
+
+
 def test_tile_solver_more_tiles_than_the_chip_holds():
     """a batch whose tall levels make more tiles than the chip has room for at once (40 pairs x 5 bands x 3 sweeps = 600 workgroups
     of three waves at the 480x272 level): the later tiles are only dispatched when earlier ones have ended, the ticket order keeps
