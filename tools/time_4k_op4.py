@@ -23,7 +23,7 @@ torch.cuda.synchronize()
 print("4K op-pt 4 (scales %d..%d): %.2f ms per pair" % (op.coarsest_scale, op.finest_scale, (time.perf_counter() - t) / 5 * 1e3))
 # consecutive pairs of a 4K video through a FlowPipeline (one pair per submit, several in flight)
 from flowonthego_amd.pipeline import FlowPipeline
-for depth in ((2, 4) if "--in-flight" in sys.argv else ()):
+for depth in ((2, 4, 6, 8) if "--in-flight" in sys.argv else ()):
     pipe = FlowPipeline(op, F.img_params(width=3840, height=2160, padding=op.patch_size), max_batch=1, depth=depth)
     outs = [pipe.new_outflow(1) for _ in range(depth)]
     for k in range(2 * depth):
