@@ -308,10 +308,21 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr):
         alg = lw * lh * 48 * op.var_ref_iter
         gbs = alg / (mss * 1e-3) / 1e9
         inner = lvl + 1
+        traffic4k, src4k = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r04_4k_pmc_traffic.json")) as f:
+                tk = json.load(f)["kernels"]
+            cand = [v["hbm_bytes_per_launch_corrected"] for k, v in tk.items() if "vr_sor_tile_kernel" in k]
+            if cand:
+                traffic4k = int(max(cand))                       # (the largest tile launch = the finest level)
+                src4k = ("HBM bytes per launch from profiles/r04_4k_pmc_traffic.json (separate rocprofv3 --pmc passes of tools/time_4k_op4.py; "
+                         "bytes = 2 x FETCH_SIZE + WRITE_SIZE) -- NOT measured in this run")
+        except Exception:
+            pass
         res["rooflines"].append({"bound": "hbm", "bound_note": "nearest roof the contract names; the kernel is a pipeline of dependency chains (bound_by)",
                                  "kernel": "fotg::vr_sor_tile_kernel<8> (one sor_coupled call = %d lexicographic sweeps of the %dx%d level as tiles of 64 rows "
                                            "x one sweep on %d workgroups; %d launches per pair at this level)" % (op.var_ref_iter, lw, lh, -(-lh // 64) * op.var_ref_iter, inner),
-                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic4k, "traffic_source": src4k,
                                  "algorithmic_bytes_per_launch": alg, "ms_per_launch": mss, "launches_per_pair": inner,
                                  "share_of_pair": sum(v for k, v in st.items() if k.startswith("varref[")) / sum(st.values()),
                                  "bound_by": "%d anti-diagonal steps of one wave per tile (~%.0f ns each) + the pipeline lag between tiles" %
