@@ -760,6 +760,44 @@ def main():
                 res["u8_frames"]["in_flight"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s", "batches_in_flight": D,
                                                  "note": "fotg_pipe_submit_u8: the product mode for 8-bit video (SURVEY 8f row 2), %d batches in flight" % D}
                 del u8
+            # three-channel 8-bit frames of a GRAY context (fotg_params::u8_color = 1: B,G,R as cv::imread delivers; SURVEY 8f row 2
+            # "RGB -> gray on device", kroeger/run_dense.cpp:199-209): OpenCV's fixed-point BGR2GRAY on load in the pyramid kernel
+            opc = F.operating_point(OP_POINT, W, 1, sor_mode=a.sor_mode)
+            opc.u8_color = 1
+            C0 = torch.stack([I0.to(torch.uint8), torch.roll(I0, 1, 2).to(torch.uint8), torch.roll(I0, 2, 1).to(torch.uint8)], -1).contiguous()
+            C1 = torch.stack([I1.to(torch.uint8), torch.roll(I1, 1, 2).to(torch.uint8), torch.roll(I1, 2, 1).to(torch.uint8)], -1).contiguous()
+            ofcc = OFClass(opc, F.img_params(width=W, height=H, padding=opc.patch_size), max_batch=a.batch, device=local)
+            outc = ofcc.new_outflow(a.batch)
+            G0 = ((C0[..., 0].to(torch.int32) * 1868 + C0[..., 1].to(torch.int32) * 9617 + C0[..., 2].to(torch.int32) * 4899 + 8192) >> 14).to(torch.uint8)
+            G1 = ((C1[..., 0].to(torch.int32) * 1868 + C1[..., 1].to(torch.int32) * 9617 + C1[..., 2].to(torch.int32) * 4899 + 8192) >> 14).to(torch.uint8)
+            same_c = torch.equal(ofcc.calc_batch_u8(C0, C1, None, outc), ofc.calc_batch_u8(G0, G1))
+            del G0, G1
+            tcg = timed(lambda: ofcc.calc_batch_u8(C0, C1, None, outc), torch.cuda.synchronize, a.steps)
+            evc = HipEvents()
+            from flowonthego_amd._lib import check as _chkc
+            msc = evc.time_ms(lambda: _chkc(lib.fotg_pyramid_pair_u8(ofcc._h, a.batch, C.c_void_p(C0.data_ptr()), C.c_void_p(C1.data_ptr()), 1, stream_ptr)), stream_ptr, 10)
+            algc = a.batch * (2 * W * H * 3 + 2 * 120 * 68 * 4)
+            res["u8_bgr_gray"] = {"value": a.batch / tcg, "unit": "frame-pairs/s", "equals_gray_u8_path": bool(same_c),
+                                  "note": "uint8 B,G,R frames (n x 1080 x 1920 x 3), gray on load like cv::imread(IMREAD_GRAYSCALE) (kroeger/run_dense.cpp:199-209), one batch at a time; informational",
+                                  "roofline": {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<unsigned char,1,4,true,3> (both frames of %d pairs)" % a.batch,
+                                               "achieved": algc / (msc * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algc / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "traffic": None, "algorithmic_bytes_per_launch": algc, "ms_per_launch": msc}}
+            if pipe:
+                pipec = FlowPipeline(opc, F.img_params(width=W, height=H, padding=opc.patch_size), max_batch=a.batch, depth=D, device=local)
+                outs_c = [ofcc.new_outflow(a.batch) for _ in range(D)]
+                torch.cuda.synchronize()
+                for i in range(2 * D):
+                    pipec.submit(C0, C1, None, outs_c[i % D], after_current_stream=False)
+                pipec.synchronize()
+                t1 = time.perf_counter()
+                for i in range(a.steps):
+                    pipec.submit(C0, C1, None, outs_c[i % D], after_current_stream=False)
+                pipec.synchronize()
+                res["u8_bgr_gray"]["in_flight"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s", "batches_in_flight": D}
+                pipec.close()
+                del outs_c
+            ofcc.close()
+            del C0, C1, outc
             # BASELINE configs[1]: ONE 1080p pair, op-pt 2's patch parameters (ps 8, stride 4, 3 scales), no variational refinement:
             # the latency of a single call (informational; the headline value is configs[2])
             op1 = F.operating_point(OP_POINT, W, 1)

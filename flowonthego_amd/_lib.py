@@ -18,7 +18,7 @@ class FotgParams(C.Structure):
                 ("usetvref", C.c_int), ("tv_alpha", C.c_float), ("tv_gamma", C.c_float),
                 ("tv_delta", C.c_float), ("tv_innerit", C.c_int), ("tv_solverit", C.c_int),
                 ("tv_sor", C.c_float), ("sor_mode", C.c_int), ("costfct", C.c_int), ("normoutlier", C.c_float), ("usefbcon", C.c_int),
-                ("depth", C.c_int)]
+                ("depth", C.c_int), ("u8_color", C.c_int)]
 
 
 # every symbol include/fotg.h declares: (name, restype, argtypes)
@@ -62,6 +62,7 @@ SYMBOLS = [
     ("fotg_num_patches", C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("fotg_pyramid", C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     ("fotg_pyramid_pair", C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp]),
+    ("fotg_pyramid_pair_u8", C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp]),
     ("fotg_level_ptr", C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_long)]),
     ("fotg_grid_init", C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_long, vp]),
     ("fotg_grid_set_target", C.c_int, [vp, C.c_int, vp, C.c_long]),

@@ -232,7 +232,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   if (p->max_iter < 0 || p->tv_solverit < 0 || p->tv_innerit < 0) return FOTG_ERR_ARG;
   if (p->costfct < 0 || p->costfct > 2 || (p->costfct == 2 && !(p->normoutlier > 0))) return FOTG_ERR_ARG;
   if (p->depth && p->usetvref && p->sor_mode != FOTG_SOR_LEXICOGRAPHIC) return FOTG_ERR_UNSUPPORTED;
-  if (p->sor_mode < FOTG_SOR_LEXICOGRAPHIC || p->sor_mode > FOTG_SOR_POINT) return FOTG_ERR_ARG;
+  if (p->u8_color < 0 || p->u8_color > 2 || (p->u8_color && p->noc != 1)) return FOTG_ERR_ARG;
   ON_DEVICE(device);
   fotg_ctx *c = new (std::nothrow) fotg_ctx();
   if (!c) return FOTG_ERR_ARG;
@@ -389,22 +389,24 @@ int fotg_num_patches(const fotg_ctx *c, int l, int *nopw, int *noph)
 /* ------------------------------------------------------------------------------------------------ */
 }  // extern "C"
 // I0 and/or I1 may be given; both frames of a batch share the launches
-template <int NOC, typename T = float>
+// SRCC: channels of the source frames (3 with NOC = 1: 8-bit colour frames, gray on load -- fotg_params::u8_color)
+template <int NOC, typename T = float, int SRCC = NOC>
 static int pyramid_impl(fotg_ctx *c, int n, const T *I0, const T *I1, hipStream_t s, int stages = 3)
 {
   const int lv = c->base_lv, ps = c->ps;
   const LevelGeom &g0 = c->geom[lv];
   const int strips = (c->Wp + 255) >> 8, tiles = strips * (c->Hp >> lv);
-  const long fstride = (long)c->w_org * c->h_org * NOC;
+  const long fstride = (long)c->w_org * c->h_org * SRCC;
+  const int coef0 = c->p.u8_color == 2 ? 4899 : 1868, coef2 = c->p.u8_color == 2 ? 1868 : 4899;      // first / third byte of a pixel: B, R (cv::imread order) or R, B
   const T *A = I0 ? I0 : I1, *B = (I0 && I1) ? I1 : nullptr;
   float *dA = c->im[I0 ? 0 : 1][lv], *dB = c->im[1][lv];
   const int nimg = B ? 2 * n : n;
   // fast path: no horizontal padding, rows and frames aligned for the wide loads (16 B for f32, 4 B for u8)
   const uintptr_t amask = sizeof(T) == 4 ? 15 : 3;
-  const int fast = (c->padw == 0) && ((c->w_org * NOC) % 4 == 0) && (((uintptr_t)A & amask) == 0) && (!B || ((uintptr_t)B & amask) == 0) && ((fstride % 4) == 0);
+  const int fast = (c->padw == 0) && ((c->w_org * SRCC) % 4 == 0) && (((uintptr_t)A & amask) == 0) && (!B || ((uintptr_t)B & amask) == 0) && ((fstride % 4) == 0);
   dim3 grid((tiles + 3) / 4, nimg), block(256);
-#define BASE(LV) do { if (fast) pyr_base_kernel<T, NOC, LV, true><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps); \
-    else pyr_base_kernel<T, NOC, LV, false><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps); } while (0)
+#define BASE(LV) do { if (fast) pyr_base_kernel<T, NOC, LV, true, SRCC><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, coef0, coef2); \
+    else pyr_base_kernel<T, NOC, LV, false, SRCC><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, coef0, coef2); } while (0)
   if (stages & 1) {
     // FOTG_PYR_SPLIT > 1: the batch's images in that many launches, one after the other.  The launch is the path's only HBM-bound
     // kernel and fills every wave slot of the chip for its whole duration; with several batches in flight the kernels of the
@@ -499,6 +501,14 @@ static int pyramid_impl(fotg_ctx *c, int n, const T *I0, const T *I1, hipStream_
   return FOTG_OK;
 }
 
+// the pyramid of a flow call: channels of the context; 8-bit colour frames of a gray context (u8_color) are converted on load
+template <typename T>
+static int pyramid_any(fotg_ctx *c, int n, const T *I0, const T *I1, hipStream_t s)
+{
+  if constexpr (sizeof(T) == 1) { if (c->p.u8_color) return pyramid_impl<1, T, 3>(c, n, I0, I1, s); }
+  return c->noc == 1 ? pyramid_impl<1, T>(c, n, I0, I1, s) : pyramid_impl<3, T>(c, n, I0, I1, s);
+}
+
 extern "C" {
 int fotg_pyramid(fotg_ctx *c, int n, const float *I, int which, void *stream)
 {
@@ -515,6 +525,15 @@ int fotg_pyramid_pair(fotg_ctx *c, int n, const float *I0, const float *I1, int 
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
   ON_DEVICE(c->device);
   return c->noc == 1 ? pyramid_impl<1>(c, n, I0, I1, (hipStream_t)stream, stages) : pyramid_impl<3>(c, n, I0, I1, (hipStream_t)stream, stages);
+}
+
+int fotg_pyramid_pair_u8(fotg_ctx *c, int n, const unsigned char *I0, const unsigned char *I1, int stages, void *stream)
+{
+  if (!c || !I0 || !I1 || !(stages & 3)) return FOTG_ERR_ARG;
+  if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
+  ON_DEVICE(c->device);
+  if (c->p.u8_color) return pyramid_impl<1, unsigned char, 3>(c, n, I0, I1, (hipStream_t)stream, stages);
+  return c->noc == 1 ? pyramid_impl<1, unsigned char>(c, n, I0, I1, (hipStream_t)stream, stages) : pyramid_impl<3, unsigned char>(c, n, I0, I1, (hipStream_t)stream, stages);
 }
 
 int fotg_level_ptr(fotg_ctx *c, int which, int l, int kind, float **ptr, long *pair_stride)
@@ -1211,15 +1230,15 @@ static int calc_range(fotg_ctx *c, int n, const T *I0, const T *I1, const float 
   }
   if (fb && !seq) {
     // both frames need gradients: two template-type pyramids (the second one into the frame-1 buffers)
-    if ((st = c->noc == 1 ? pyramid_impl<1, T>(c, n, I0, (const T *)nullptr, stream) : pyramid_impl<3, T>(c, n, I0, (const T *)nullptr, stream))) return st;
+    if ((st = pyramid_any<T>(c, n, I0, (const T *)nullptr, stream))) return st;
     fotg_ctx *v1 = (fotg_ctx *)malloc(sizeof(fotg_ctx));
     if (!v1) return FOTG_ERR_ARG;
     memcpy((void *)v1, (const void *)c, sizeof(fotg_ctx));
     for (int l = c->base_lv; l <= c->p.sc_f; ++l) { v1->im[0][l] = c->im[1][l]; v1->dx0[l] = c->dx1[l]; v1->dy0[l] = c->dy1[l]; }
-    st = c->noc == 1 ? pyramid_impl<1, T>(v1, n, I1, (const T *)nullptr, stream) : pyramid_impl<3, T>(v1, n, I1, (const T *)nullptr, stream);
+    st = pyramid_any<T>(v1, n, I1, (const T *)nullptr, stream);
     free(v1);
     if (st) return st;
-  } else if ((st = c->noc == 1 ? pyramid_impl<1, T>(c, nimg, I0, I1, stream) : pyramid_impl<3, T>(c, nimg, I0, I1, stream))) return st;
+  } else if ((st = pyramid_any<T>(c, nimg, I0, I1, stream))) return st;
   mark();
   for (int l = c->p.sc_f; l >= c->p.sc_l; --l) {
     const long ls = c->lev_stride[l];

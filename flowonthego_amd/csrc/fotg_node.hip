@@ -53,7 +53,7 @@ struct Slot {
 }  // namespace
 
 struct fotg_node {
-  int ndev = 0, depth = 0, max_batch = 0, w = 0, h = 0, noc = 1, nch = 2, ow = 0, oh = 0;
+  int ndev = 0, depth = 0, max_batch = 0, w = 0, h = 0, noc = 1, nch = 2, ow = 0, oh = 0, u8_color = 0;
   size_t frame_elems = 0, flow_elems = 0;
   Slot slot[FOTG_NODE_MAX_DEV];
   std::mutex mu;
@@ -92,7 +92,7 @@ int issue_resident(fotg_node *nd, Slot &s, const Job &j)
   int b = 0, cnt = 0;
   fotg_node_shard(j.n, nd->ndev, s.index, &b, &cnt);
   std::vector<long> tickets;
-  const size_t esz = j.u8 ? 1 : 4;
+  const size_t esz = j.u8 ? (nd->u8_color ? 3 : 1) : 4;       // (8-bit colour frames of a gray context: three bytes per pixel)
   // the shard in pieces of at most max_batch pairs, consecutive pieces on consecutive slots of the pipe
   for (int o = 0; o < cnt; o += nd->max_batch) {
     const int m = cnt - o < nd->max_batch ? cnt - o : nd->max_batch;
@@ -255,7 +255,7 @@ int fotg_node_create(const fotg_params *p, int w_org, int h_org, const int *devi
   for (int k = 0; k < ndev; ++k) if (devices[k] < 0 || devices[k] >= have) return FOTG_ERR_ARG;
   fotg_node *nd = new (std::nothrow) fotg_node();
   if (!nd) return FOTG_ERR_ARG;
-  nd->ndev = ndev; nd->depth = depth; nd->max_batch = max_batch; nd->w = w_org; nd->h = h_org; nd->noc = p->noc; nd->nch = p->depth ? 1 : 2;
+  nd->ndev = ndev; nd->depth = depth; nd->max_batch = max_batch; nd->w = w_org; nd->h = h_org; nd->noc = p->noc; nd->nch = p->depth ? 1 : 2; nd->u8_color = p->u8_color;
   nd->frame_elems = (size_t)w_org * h_org * p->noc;
   for (int k = 0; k < ndev; ++k) {
     Slot &s = nd->slot[k];

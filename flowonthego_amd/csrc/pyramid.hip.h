@@ -14,14 +14,24 @@
 
 namespace fotg {
 
-template <typename T, int NOC, int LV, bool FAST>
+// SRCC != NOC (8-bit frames only, SRCC = 3, NOC = 1): the frames are 3-channel 8-bit colour and the flow is computed on their gray
+// value -- what cv::imread(.., IMREAD_GRAYSCALE) hands kroeger/run_dense.cpp:199-209 for a colour file: OpenCV's fixed-point
+// BGR2GRAY, (1868 B + 9617 G + 4899 R + 8192) >> 14, here on load (integer arithmetic: exact by construction).  coef0 / coef2 are
+// the weights of the first and third byte of a pixel (BGR order: 1868, 4899; RGB order: 4899, 1868).
+template <typename T, int NOC, int LV, bool FAST, int SRCC = NOC>
 __global__ __launch_bounds__(256) void pyr_base_kernel(
-    const T *__restrict__ frames0, const T *__restrict__ frames1, int n_per_src, long frame_stride,  // 2 x n frames, h_org x w_org x NOC
+    const T *__restrict__ frames0, const T *__restrict__ frames1, int n_per_src, long frame_stride,  // 2 x n frames, h_org x w_org x SRCC
     int w_org, int h_org, int left, int top,               // padding offsets (floor(pad/2))
     int Wp, int Hp,                                        // padded frame size
-    float *__restrict__ dst0, float *__restrict__ dst1, long dst_stride, int tw, int ps)  // level LV padded buffers
+    float *__restrict__ dst0, float *__restrict__ dst1, long dst_stride, int tw, int ps,  // level LV padded buffers
+    int coef0 = 0, int coef2 = 0)
     // FAST: 16-B loads legal (no horizontal pad, 16-B aligned rows)
 {
+  constexpr bool C2G = SRCC != NOC;
+  static_assert(!C2G || (SRCC == 3 && NOC == 1 && sizeof(T) == 1), "colour -> gray on load: 8-bit, three channels");
+  auto gray3 = [&](unsigned b0, unsigned b1, unsigned b2) {
+    return (float)((b0 * (unsigned)coef0 + b1 * 9617u + b2 * (unsigned)coef2 + 8192u) >> 14);
+  };
   constexpr int R = 1 << LV;                 // source rows per output row
   constexpr int C = 4 * NOC;                 // floats per lane per row
   const int lane = threadIdx.x & 63;
@@ -40,8 +50,24 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
   // one source row (clamped: replicate padding) -> 4 pixels x NOC floats of this lane
   auto load_row = [&](int r, float (&dstv)[C]) {
     const int sy = clampi(oy * R + r - top, h_org);
-    const T *row = src + (size_t)sy * w_org * NOC;
-    if constexpr (FAST && sizeof(T) == 1) {
+    const T *row = src + (size_t)sy * w_org * SRCC;
+    if constexpr (C2G) {
+      if constexpr (FAST) {
+        // 4 pixels x 3 bytes = three dwords per lane and row
+        const unsigned *p32 = reinterpret_cast<const unsigned *>(row + (size_t)x0 * 3);
+        const unsigned t0 = p32[0], t1 = p32[1], t2 = p32[2];
+        dstv[0] = gray3(t0 & 0xffu, (t0 >> 8) & 0xffu, (t0 >> 16) & 0xffu);
+        dstv[1] = gray3(t0 >> 24, t1 & 0xffu, (t1 >> 8) & 0xffu);
+        dstv[2] = gray3((t1 >> 16) & 0xffu, t1 >> 24, t2 & 0xffu);
+        dstv[3] = gray3((t2 >> 8) & 0xffu, (t2 >> 16) & 0xffu, t2 >> 24);
+      } else {
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          const int sx = clampi(x0 + px - left, w_org);
+          dstv[px] = gray3(row[(size_t)sx * 3], row[(size_t)sx * 3 + 1], row[(size_t)sx * 3 + 2]);
+        }
+      }
+    } else if constexpr (FAST && sizeof(T) == 1) {
       // 8-bit frames ("next" row f2 of SURVEY 8f): 4 pixels x NOC bytes = NOC dwords per lane and row; u8 -> f32 is exact
       const unsigned *p32 = reinterpret_cast<const unsigned *>(row + (size_t)x0 * NOC);
 #pragma unroll
@@ -98,12 +124,33 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
     // 8-bit gray frames: a lane's 4 pixels are one dword, 256 bytes per wave and row.  Where the rows are 16-byte aligned the
     // wave instead fetches FOUR rows with one 16-byte load per lane (lane L: row L/16, bytes 16 (L%16)..) and hands the dwords
     // out through a wave-private 1 KB LDS slab -- a quarter of the memory instructions for the same bytes.
-    constexpr bool XPOSE8 = FAST && NOC == 1 && sizeof(T) == 1 && R >= 4;
+    constexpr bool XPOSE8 = FAST && NOC == 1 && sizeof(T) == 1 && R >= 4 && !C2G;
     typedef unsigned vu4 __attribute__((ext_vector_type(4)));
     __shared__ vu4 xpose8[XPOSE8 ? 4 : 1][XPOSE8 ? 64 : 1];
     const bool x8 = XPOSE8 && (w_org & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    // 8-bit colour -> gray: a row segment of the wave is 768 bytes, four rows 3072 = three fully coalesced 16-byte loads per lane
+    // (piece i = 64 k + lane: row i / 48, bytes 16 (i % 48)..), handed out through a wave-private 3 KB slab: lane L reads its
+    // 12 bytes of row r at 768 r + 12 L (a 3-dword lane stride: no bank conflicts)
+    constexpr bool XPOSEC = FAST && C2G && R >= 4;
+    __shared__ vu4 xposec[XPOSEC ? 4 : 1][XPOSEC ? 192 : 1];
+    const bool xc = XPOSEC && (w_org & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
     float l1[R / 2][2 * NOC];
     vu4 t8[XPOSE8 ? NGRP : 1];
+    vu4 tc[XPOSEC ? NGRP : 1][3];
+    if constexpr (XPOSEC) {
+      if (xc) {
+        const int segb = (Wp - strip * 256 < 256 ? Wp - strip * 256 : 256) * 3;        // bytes of this strip's row segment
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int i = k * 64 + lane, rr = i / 48, c16 = i - rr * 48;
+            const int sy = clampi(oy * R + g * RG + rr - top, h_org);
+            const vu4 *p = reinterpret_cast<const vu4 *>(reinterpret_cast<const unsigned char *>(src) + ((size_t)sy * w_org + strip * 256) * 3) + c16;
+            tc[g][k] = (c16 * 16 < segb) ? __builtin_nontemporal_load(p) : vu4{0u, 0u, 0u, 0u};
+          }
+      }
+    }
     if constexpr (XPOSE8) {
       if (x8) {
         const int segb = Wp - strip * 256 < 256 ? Wp - strip * 256 : 256;              // bytes of this strip's row segment
@@ -146,6 +193,23 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
             v[r][4 * k] = q.x; v[r][4 * k + 1] = q.y; v[r][4 * k + 2] = q.z; v[r][4 * k + 3] = q.w;
           }
         asm volatile("" ::: "memory");
+      } else if (XPOSEC && xc) {
+        if constexpr (XPOSEC) {
+          asm volatile("" ::: "memory");               // same lane-to-lane hand-over as above
+#pragma unroll
+          for (int k = 0; k < 3; ++k) xposec[wave][k * 64 + lane] = tc[g][k];
+          asm volatile("" ::: "memory");
+          const unsigned *slab = reinterpret_cast<const unsigned *>(&xposec[wave][0]);
+#pragma unroll
+          for (int r = 0; r < RG; ++r) {
+            const unsigned t0 = slab[r * 192 + lane * 3], t1 = slab[r * 192 + lane * 3 + 1], t2 = slab[r * 192 + lane * 3 + 2];
+            v[r][0] = gray3(t0 & 0xffu, (t0 >> 8) & 0xffu, (t0 >> 16) & 0xffu);
+            v[r][1] = gray3(t0 >> 24, t1 & 0xffu, (t1 >> 8) & 0xffu);
+            v[r][2] = gray3((t1 >> 16) & 0xffu, t1 >> 24, t2 & 0xffu);
+            v[r][3] = gray3((t2 >> 8) & 0xffu, (t2 >> 16) & 0xffu, t2 >> 24);
+          }
+          asm volatile("" ::: "memory");
+        }
       } else if (XPOSE8 && x8) {
         if constexpr (XPOSE8) {
           asm volatile("" ::: "memory");               // same lane-to-lane hand-over as above

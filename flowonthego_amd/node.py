@@ -39,8 +39,8 @@ class FlowNode:
     def shard(self, n, d):
         return node_shard(n, self.ndev, d)
 
-    def _frame_shape(self, n):
-        return (n, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
+    def _frame_shape(self, n, u8=False):
+        return (n, self.height_org, self.width_org) + ((3,) if u8 and self.op.u8_color else (self.op.channels,) if self.op.channels > 1 else ())
 
     def submit(self, n, I0, I1, outflow=None):
         """resident frames: I0[d], I1[d] = slot d's shard (its node_shard range of the n pairs) on device devices[d], float32 or
@@ -56,8 +56,8 @@ class FlowNode:
             dev = torch.device("cuda", self.devices[d])
             for t, nm in ((I0[d], "I0[%d]" % d), (I1[d], "I1[%d]" % d)):
                 _dev_f32(t, nm, dev, dtype=torch.uint8 if u8 else torch.float32)
-                if tuple(t.shape) != self._frame_shape(e - b) and tuple(t.shape) != self._frame_shape(e - b) + (1,):
-                    raise FotgError("%s has shape %s, slot %d's shard is %s" % (nm, tuple(t.shape), d, self._frame_shape(e - b)))
+                if tuple(t.shape) != self._frame_shape(e - b, u8) and tuple(t.shape) != self._frame_shape(e - b, u8) + (1,):
+                    raise FotgError("%s has shape %s, slot %d's shard is %s" % (nm, tuple(t.shape), d, self._frame_shape(e - b, u8)))
             if outs[d] is None:
                 outs[d] = torch.empty((e - b, h, w, self.nch), dtype=torch.float32, device=dev)
                 torch.cuda.current_stream(dev).synchronize()        # (the allocator may hand out memory with work still enqueued on a torch stream)

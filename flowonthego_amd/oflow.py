@@ -148,12 +148,16 @@ class OFClass:
         for t, nm in ((I0, "I0"), (I1, "I1")):
             _dev_f32(t, nm, self.device, dtype=torch.uint8)
         n = I0.shape[0]
-        exp = (n, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
+        exp = (n, self.height_org, self.width_org) + self._u8_channels()
         if tuple(I0.shape) != exp or I1.shape != I0.shape:
             raise FotgError("frame shape %s does not match the configured %s" % (tuple(I0.shape), exp))
         outflow, initflow = self._flow_args(n, outflow, initflow)
         check(lib().fotg_calc_batch_u8(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(outflow), _stream(self.device)))
         return outflow
+
+    def _u8_channels(self):
+        """trailing shape of an 8-bit frame: (3,) for colour frames converted to gray on load (op.u8_color)"""
+        return (3,) if self.op.u8_color else ((self.op.channels,) if self.op.channels > 1 else ())
 
     def calc_sequence(self, frames, initflow=None, outflow=None):
         """video mode: frames (n+1, h, w[, channels]) float32 or uint8 on the device -> the n flows frame k -> k+1; every
@@ -163,7 +167,7 @@ class OFClass:
         if frames.device != self.device:
             raise FotgError("frames live on %s, the context on %s" % (frames.device, self.device))
         n = frames.shape[0] - 1
-        exp = (n + 1, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
+        exp = (n + 1, self.height_org, self.width_org) + (self._u8_channels() if frames.dtype == torch.uint8 else ((self.op.channels,) if self.op.channels > 1 else ()))
         if n < 1 or tuple(frames.shape) != exp:
             raise FotgError("frame shape %s does not match the configured %s" % (tuple(frames.shape), exp))
         outflow, initflow = self._flow_args(n, outflow, initflow)

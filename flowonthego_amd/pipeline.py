@@ -45,7 +45,7 @@ class FlowPipeline:
         for t, nm in ((I0, "I0"), (I1, "I1")):
             _dev_f32(t, nm, self.device, dtype=torch.uint8 if u8 else torch.float32)
         n = I0.shape[0]
-        exp = (n, self.height_org, self.width_org) + ((self.op.channels,) if self.op.channels > 1 else ())
+        exp = (n, self.height_org, self.width_org) + ((3,) if u8 and self.op.u8_color else (self.op.channels,) if self.op.channels > 1 else ())
         if (tuple(I0.shape) != exp and tuple(I0.shape) != exp + (1,)) or I1.shape != I0.shape:
             raise FotgError("frame shape %s does not match the configured %s" % (tuple(I0.shape), exp))
         if n < 1 or n > self.max_batch:

@@ -65,6 +65,12 @@ typedef struct fotg_params {
                           per-stage flow arguments, fotg_upsample_crop) has 1 channel instead of 2; forward grid /
                           refinement clamp the displacement to <= 0, the backward ones (usefbcon) to >= 0
                           (kroeger/oflow.cpp:76-80,153-157, patch.cpp:188-193, refine_variational.cpp:243-330) */
+  int u8_color;        /* 0: 8-bit frames have `noc` channels.  1 / 2 (noc = 1 only): the 8-bit entry points (fotg_calc_batch_u8,
+                          fotg_calc_sequence_u8, fotg_pipe_submit_u8, fotg_node_submit_u8) take THREE-channel frames (n x h_org x
+                          w_org x 3 uint8), B,G,R byte order as cv::imread delivers (1) or R,G,B (2), and the flow is computed on
+                          their gray value, converted on load with OpenCV's fixed-point formula (1868 B + 9617 G + 4899 R + 8192)
+                          >> 14 -- what cv::imread(file, IMREAD_GRAYSCALE) feeds kroeger/run_dense.cpp:199-209 for a colour file.
+                          Bit-identical to the gray 8-bit path on the converted frames; the float entry points still take gray. */
 } fotg_params;
 
 typedef struct fotg_ctx fotg_ctx;
@@ -198,6 +204,8 @@ int fotg_pyramid(fotg_ctx *ctx, int n, const float *I, int which, void *stream);
 /* both frames of n pairs in shared launches (what fotg_calc_batch does).  stages: bit 0 = the HBM-streaming base
  * kernel (frames -> level min(sc_l,4)), bit 1 = coarser levels + borders + gradients; 3 = everything. */
 int fotg_pyramid_pair(fotg_ctx *ctx, int n, const float *I0, const float *I1, int stages, void *stream);
+/* the same from 8-bit frames (noc channels, or three with fotg_params::u8_color): what the 8-bit flow entry points run first */
+int fotg_pyramid_pair_u8(fotg_ctx *ctx, int n, const unsigned char *I0, const unsigned char *I1, int stages, void *stream);
 /* device pointer of a pyramid plane of pair 0 (pairs are `*pair_stride` floats apart).
  * kind: 0 image, 1 dx, 2 dy.  Layout (h_l+2ps) x (w_l+2ps) x noc, like the reference's padded levels. */
 int fotg_level_ptr(fotg_ctx *ctx, int which, int level, int kind, float **ptr, long *pair_stride);

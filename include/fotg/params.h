@@ -51,11 +51,13 @@ typedef struct {
   bool use_fbcon = false; // kroeger/oflow.h:44 usefbcon: forward-backward merge in the densification
   bool depth_mode = false; // kroeger SELECTMODE=2 build (run_DE_*): stereo depth, flow arrays have ONE channel
   int min_iter = -1; // kroeger optparam.min_iter (oflow.h:38); < 0: = grad_descent_iter (src/ and the operating points)
+  int u8_color = 0;  // channels = 1 only: the 8-bit entry points take 3-channel frames (1: B,G,R as cv::imread delivers, 2: R,G,B) and
+                     // convert to gray on load like cv::imread(IMREAD_GRAYSCALE) (kroeger/run_dense.cpp:199-209); fotg_params::u8_color
 } opt_params;
 
 inline fotg_params to_fotg(const opt_params &op)
 {
-  fotg_params p;
+  fotg_params p = fotg_params();
   p.sc_f = op.coarsest_scale; p.sc_l = op.finest_scale; p.ps = op.patch_size;
   p.max_iter = p.min_iter = op.grad_descent_iter;          // src/kernels/optimize.cu:225-229
   if (op.min_iter >= 0 && op.min_iter <= op.grad_descent_iter) p.min_iter = op.min_iter;   // kroeger early termination (patch.cpp:279-282)
@@ -66,6 +68,7 @@ inline fotg_params to_fotg(const opt_params &op)
   p.usetvref = op.use_var_ref; p.tv_alpha = op.var_ref_alpha; p.tv_gamma = op.var_ref_gamma; p.tv_delta = op.var_ref_delta;
   p.tv_innerit = 1; p.tv_solverit = op.var_ref_iter; p.tv_sor = op.var_ref_sor_weight; p.sor_mode = op.sor_mode;
   p.costfct = op.cost_func; p.normoutlier = op.norm_outlier; p.usefbcon = op.use_fbcon; p.depth = op.depth_mode;
+  p.u8_color = op.u8_color;
   return p;
 }
 

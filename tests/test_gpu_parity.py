@@ -599,6 +599,75 @@ def test_uint8_frames(alley):
         ofc.close()
 
 
+def gray_cv(a, first=1868, third=4899):
+    """OpenCV's fixed-point BGR2GRAY on (.., 3) uint8 in B,G,R byte order (first / third = the weights of byte 0 / byte 2)"""
+    a = a.astype(np.int64)
+    return ((a[..., 0] * first + a[..., 1] * 9617 + a[..., 2] * third + 8192) >> 14).astype(np.uint8)
+
+
+def test_uint8_colour_frames_to_gray_on_load(alley):
+    """SURVEY 8f row 2 "RGB -> gray on device" (kroeger/run_dense.cpp:199-209: cv::imread(.., IMREAD_GRAYSCALE) of a colour
+    file): three-channel 8-bit frames through every 8-bit entry point of a GRAY context (op.u8_color = 1: B,G,R like cv::imread,
+    2: R,G,B) == the gray 8-bit path on frames converted with OpenCV's fixed-point formula == the oracle on those gray frames.
+    Sizes: the alley_1 colour crop (256 x 128, 16-byte aligned rows: coalesced 16-byte loads + LDS slab, base level 3), a width
+    that is only 4-byte aligned (dword loads), one that needs padding (per-pixel loads) and 1080p (base level 4, partial last
+    strip)."""
+    F, OFClass, _, O = _mods()
+    from flowonthego_amd.pipeline import FlowPipeline
+    rng = np.random.default_rng(5)
+
+    def colour_pair(h, w, seed):
+        g0, g1 = synth_pair(h, w, seed=seed, noc=3)
+        return g0.astype(np.uint8), g1.astype(np.uint8)
+
+    cases = [("alley_crop", alley["rgb_crop_0001"][..., ::-1].copy(), alley["rgb_crop_0002"][..., ::-1].copy())]       # B,G,R
+    cases += [("w340", *colour_pair(200, 340, 21)), ("w331_padded", *colour_pair(203, 331, 22)), ("1080p", *colour_pair(1080, 1920, 23))]
+    for name, c0, c1 in cases:
+        h, w = c0.shape[:2]
+        for order, (first, third) in ((1, (1868, 4899)), (2, (4899, 1868))):
+            g0, g1 = gray_cv(c0, first, third), gray_cv(c1, first, third)
+            op = F.operating_point(2, w, 1)
+            ofg = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+            ref = ofg.calc_batch_u8(torch.from_numpy(g0).cuda()[None].contiguous(), torch.from_numpy(g1).cuda()[None].contiguous())
+            if name != "1080p":
+                p = oracle_params(O, op)
+                f0, f1 = g0.astype(np.float32), g1.astype(np.float32)
+                assert np.array_equal(ref[0].cpu().numpy(), O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), name
+            opc = F.operating_point(2, w, 1)
+            opc.u8_color = order
+            ofc = OFClass(opc, F.img_params(width=w, height=h, padding=opc.patch_size))
+            u0, u1 = torch.from_numpy(c0).cuda()[None].contiguous(), torch.from_numpy(c1).cuda()[None].contiguous()
+            assert torch.equal(ofc.calc_batch_u8(u0, u1), ref), (name, order)
+            # the float entry point of the same context still takes gray frames
+            assert torch.equal(ofc.calc_batch(dev(g0)[None], dev(g1)[None]), ref), (name, order)
+            with pytest.raises(F.FotgError):
+                ofc.calc_batch_u8(torch.from_numpy(g0).cuda()[None].contiguous(), torch.from_numpy(g1).cuda()[None].contiguous())      # gray bytes: wrong shape
+            ofc.close(); ofg.close()
+    # sequence mode and the pipe: three colour frames -> two flows
+    c = [np.ascontiguousarray(alley["rgb_crop_000%d" % k][..., ::-1]) for k in (1, 2)]
+    c.append(np.ascontiguousarray(np.roll(c[1], 3, axis=1)))
+    g = [gray_cv(x) for x in c]
+    h, w = g[0].shape
+    op = F.operating_point(2, w, 1)
+    ofg = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+    ref = ofg.calc_sequence(torch.from_numpy(np.stack(g)).cuda())
+    opc = F.operating_point(2, w, 1)
+    opc.u8_color = 1
+    ofc = OFClass(opc, F.img_params(width=w, height=h, padding=opc.patch_size), max_batch=2)
+    cs = torch.from_numpy(np.stack(c)).cuda()
+    assert torch.equal(ofc.calc_sequence(cs), ref)
+    pipe = FlowPipeline(opc, F.img_params(width=w, height=h, padding=opc.patch_size), max_batch=2, depth=2)
+    t, out = pipe.submit(cs[:2].contiguous(), cs[1:].contiguous())
+    pipe.wait(t, host=True)
+    assert torch.equal(out, ref)
+    pipe.close()
+    # a colour context must be gray
+    bad = F.operating_point(2, w, 3)
+    bad.u8_color = 1
+    with pytest.raises(F.FotgError):
+        OFClass(bad, F.img_params(width=w, height=h, padding=bad.patch_size))
+
+
 @pytest.mark.parametrize("cost_func", [1, 2])
 def test_patch_cost_functions(cost_func, alley):
     """L1 and pseudo-Huber patch costs (kroeger/patch.cpp:238-261; the operating points use L2):
