@@ -18,7 +18,7 @@ class FotgParams(C.Structure):
                 ("usetvref", C.c_int), ("tv_alpha", C.c_float), ("tv_gamma", C.c_float),
                 ("tv_delta", C.c_float), ("tv_innerit", C.c_int), ("tv_solverit", C.c_int),
                 ("tv_sor", C.c_float), ("sor_mode", C.c_int), ("costfct", C.c_int), ("normoutlier", C.c_float), ("usefbcon", C.c_int),
-                ("depth", C.c_int), ("u8_color", C.c_int)]
+                ("depth", C.c_int), ("u8_color", C.c_int), ("fast_math", C.c_int)]
 
 
 # every symbol include/fotg.h declares: (name, restype, argtypes)

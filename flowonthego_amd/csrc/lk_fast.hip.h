@@ -1,0 +1,281 @@
+// lk_fast.hip.h -- the tolerance mode of the patch loop (fotg_params::fast_math): the same inverse-compositional Lucas-Kanade
+// iteration as lk.hip.h (kroeger/patch.cpp:120-212, 264-284, 335-402), evaluated with a third of the instructions.  NOT
+// bit-identical to the oracle: algebraically the same update, rounded differently (measured against the oracle by the tests;
+// the north star's bound is a mean endpoint error of 1e-3 px).  The default (parity) mode never runs this file's kernel.
+//
+// What changes against lk.hip.h (one row of LPP lanes per patch there and here; everything per-patch is carried redundantly by
+// the patch's lanes, the reductions leave their result in every lane):
+//  * the projections do not need the residual.  With r = (q - mean q) - (T - mean T)  (patch.cpp:230-236, 278, 330-331):
+//        sum Tx r  =  sum (Tx - mean Tx) q  -  sum (Tx - mean Tx) (T - mean T)
+//    -- the second term is a constant of the patch and the first needs neither the mean of the query patch nor the template:
+//    one bilinear sample and one fused multiply-add per pixel and projection, two reductions per iteration instead of four,
+//    no subtraction pass.  The L1 residual (`mares`) only feeds termination tests that cannot fire when min_iter == max_iter and
+//    res_thresh <= 0 (patch.cpp:279-282; every operating point): it is not evaluated in the loop.  The residual itself -- the patch
+//    weights of the densification are |r| -- is evaluated ONCE, at the final position.  (Configurations with min_iter < max_iter,
+//    res_thresh > 0, another cost function or depth mode run the exact kernel also with fast_math set.)
+//  * the 2x2 Cholesky solve (patch.cpp:184) becomes a multiplication with the inverse H^-1 = L^-T L^-1 computed once from the same
+//    factor, the constant term folded in: dp = H^-1 S + k, four fused multiply-adds, no division in the loop.
+//  * a lane owns a BH x BW BLOCK of the patch (3 x 3 at ps 12, 4 x 2 at ps 8 with eight lanes per patch) instead of every 16th
+//    pixel: the block's bilinear taps are a (BH+1) x (BW+1) window of the staged I1 -- 16 LDS values for 9 pixels instead of 36,
+//    all at compile-time offsets from ONE per-lane address.
+//  * the window in LDS holds I1 - mean T: the constant does not change the projections (the centred gradients sum to zero) and
+//    keeps the products small (less cancellation against the constant term).
+//  * fused multiply-adds throughout, the two projections as one packed-f32 accumulator, reductions in DPP order.
+// Same semantics kept exactly: start test, window placement, the ceil(x + 1e-5) / floor corner pair, outlier / border / non-finite
+// reset (patch.cpp:199-208, oracle definition D3), iteration count, p_iter / pweight layout.
+#pragma once
+#include "lk.hip.h"
+
+namespace fotg {
+
+typedef float lkf_v2f __attribute__((ext_vector_type(2)));
+
+template <int LPP>
+__device__ __forceinline__ float lkf_allsum(float v)
+{
+  if constexpr (LPP == 4) {
+#define FOTG_DPPQ(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, false))
+    v = v + FOTG_DPPQ(v, 0x4E);                          // quad_perm [2,3,0,1]
+    v = v + FOTG_DPPQ(v, 0xB1);                          // quad_perm [1,0,3,2]
+#undef FOTG_DPPQ
+    return v;
+  } else return group_allsum<LPP>(v);
+}
+
+// two sums at once, each left in every lane of its group of LPP lanes.  Hand-placed DPP adds (v = v + rotate(v)): the compiler
+// turns two interleaved reduction chains into packed adds fed by v_mov_dpp copies, 20 instructions instead of 8.  A DPP read of a
+// register a VALU instruction has just written needs two wait states (the assembler does not see into this block: s_nop).
+template <int LPP>
+__device__ __forceinline__ void lkf_allsum2(float &a, float &b)
+{
+  if constexpr (LPP == 16) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(a), "+v"(b));
+  } else {
+    a = lkf_allsum<LPP>(a);
+    asm volatile("" : "+v"(b));
+    b = lkf_allsum<LPP>(b);
+  }
+}
+
+constexpr int lkf_min_waves(int ps, int noc, int lpp)
+{
+  // what the private windows leave room for in the CU's 160 KB of LDS (waves per SIMD)
+  const int bytes = (64 / lpp) * (2 * ps + 4) * (2 * ps + 4) * noc * 4;
+  const int per_cu = 160 * 1024 / bytes;
+  return per_cu >= 16 ? 4 : per_cu >= 12 ? 3 : per_cu >= 8 ? 2 : 1;
+}
+
+template <int PS, int NOC, int LPP>
+__global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kernel(LkArgs a)
+{
+  constexpr int PPW = 64 / LPP;                      // patches per wave
+  constexpr int LC = LPP == 16 ? 4 : 2, LR = LPP / LC;   // lanes of a patch as LR x LC blocks: 16 = 4 x 4, 8 = 4 x 2, 4 = 2 x 2
+  constexpr int BH = PS / LR, BW = PS / LC;          // block of one lane
+  static_assert(PS % LR == 0 && PS % LC == 0, "blocks tile the patch");
+  constexpr int NE = BH * BW * NOC;
+  constexpr int NV = PS * PS * NOC;
+  constexpr int PAD = PS;
+  constexpr int WIN = 2 * PS + 4;                    // window edge (lk.hip.h)
+  constexpr int WROW = WIN * NOC;                    // floats per window row
+  __shared__ float win_all[PPW * WIN * WIN * NOC];
+  const int lane = threadIdx.x & 63, row = lane / LPP, j = lane % LPP;
+  const int by = (j / LC) * BH, bx = (j % LC) * BW;  // the lane's block inside the patch
+  const WgId wg = xcd_local_wg();
+  const int ipw = wg.x * PPW;
+  const int pair = wg.y;
+  const int tw = a.g.tw;
+  const float *I0 = a.I0 + (size_t)pair * a.img_stride;
+  const float *I0x = a.I0x + (size_t)pair * a.img_stride;
+  const float *I0y = a.I0y + (size_t)pair * a.img_stride;
+  const float *I1 = a.I1 + (size_t)pair * a.img_stride;
+  const bool VALID = ipw + row < a.g.nop;
+  const int IP = VALID ? ipw + row : a.g.nop - 1;
+  const int gx = IP / a.g.noph, gy = IP % a.g.noph;    // patchgrid.cpp:57-66
+  const float RX = (float)(gx * a.g.steps + a.g.offw), RY = (float)(gy * a.g.steps + a.g.offh);
+  const bool PN = a.patnorm > 0;
+
+  // ---- template block: centred gradients (Tx - mean Tx, Ty - mean Ty) as pairs, Hessian of the raw gradients (patch.cpp:74-77),
+  //      constant terms C = sum (Tx - mean Tx)(T - mean T), inverse Hessian, K = -H^-1 C
+  const size_t tbase = ((size_t)((int)RX + PAD + bx - PS / 2) + (size_t)((int)RY + PAD + by - PS / 2) * tw) * NOC;
+  lkf_v2f G[NE];
+  float MT = 0.f, IH00, IH01, IH11, K0, K1;
+  {
+    float t[NE];
+    float sT = 0.f, sX = 0.f, sY = 0.f, hxx = 0.f, hxy = 0.f, hyy = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < BH; ++dy)
+#pragma unroll
+      for (int k = 0; k < BW * NOC; ++k) {
+        const size_t idx = tbase + (size_t)dy * tw * NOC + k;
+        const int e = dy * BW * NOC + k;
+        const float tv = I0[idx], gxv = I0x[idx], gyv = I0y[idx];
+        t[e] = tv; G[e].x = gxv; G[e].y = gyv;
+        sT += tv; sX += gxv; sY += gyv;
+        hxx = __builtin_fmaf(gxv, gxv, hxx); hxy = __builtin_fmaf(gxv, gyv, hxy); hyy = __builtin_fmaf(gyv, gyv, hyy);
+      }
+    float H00 = lkf_allsum<LPP>(hxx), H01 = lkf_allsum<LPP>(hxy), H11 = lkf_allsum<LPP>(hyy);
+    float mX = 0.f, mY = 0.f;
+    if (PN) {
+      constexpr float inv = 1.0f / (float)NV;
+      MT = lkf_allsum<LPP>(sT) * inv; mX = lkf_allsum<LPP>(sX) * inv; mY = lkf_allsum<LPP>(sY) * inv;
+    }
+    float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      G[e].x -= mX; G[e].y -= mY;
+      const float tc = t[e] - MT;
+      c0 = __builtin_fmaf(G[e].x, tc, c0); c1 = __builtin_fmaf(G[e].y, tc, c1);
+    }
+    const float C0 = lkf_allsum<LPP>(c0), C1 = lkf_allsum<LPP>(c1);
+    // :78-82  (float += 1e-10 in double, like the reference and lk.hip.h)
+    if (H00 * H11 - H01 * H01 == 0.f) { H00 = (float)((double)H00 + 1e-10); H11 = (float)((double)H11 + 1e-10); }
+    if (a.hes && VALID && j == 0) {
+      float *hp = a.hes + ((size_t)pair * a.g.nop + IP) * 3;
+      hp[0] = H00; hp[1] = H01; hp[2] = H11;
+    }
+    // H^-1 = L^-T L^-1 from the Cholesky factor the reference solves with (patch.cpp:184); a singular / indefinite H gives
+    // non-finite entries, i.e. a non-finite update: the patch is reset at its first iteration, as in the exact kernel
+    const float L00 = sqrtf(H00), L10 = H01 / L00, L11 = sqrtf(H11 - L10 * L10);
+    const float ia = 1.0f / L00, ib = 1.0f / L11, m = -L10 * ia * ib;
+    IH00 = ia * ia + m * m; IH01 = m * ib; IH11 = ib * ib;
+    K0 = -(IH00 * C0 + IH01 * C1); K1 = -(IH01 * C0 + IH11 * C1);          // dp = H^-1 (S - C) = H^-1 S + K
+  }
+
+  // ---- starting flow (patchgrid.cpp:195-211), OptimizeStart (patch.cpp:120-156): as lk.hip.h
+  float PIN0 = 0.f, PIN1 = 0.f;
+  if (a.flow_prev) {
+    int fx = (int)floorf(RX / 2), fy = (int)floorf(RY / 2);
+    fx = fx > a.g.w / 2 - 1 ? a.g.w / 2 - 1 : fx;        // oracle definition D5
+    fy = fy > a.g.h / 2 - 1 ? a.g.h / 2 - 1 : fy;
+    const float *fp = a.flow_prev + (size_t)pair * a.flow_prev_stride + 2 * (size_t)(fy * (a.g.w / 2) + fx);
+    PIN0 = fp[0] * 2; PIN1 = fp[1] * 2;
+  }
+  float P0 = PIN0, P1 = PIN1, PTX = RX + P0, PTY = RY + P1;
+  const float STX = PTX, STY = PTY;
+  const bool START_OK = VALID && !(PTX < a.g.lb || PTY < a.g.lb || PTX > a.g.ubw || PTY > a.g.ubh);
+  const int WX0 = (int)floorf(STX) + PAD - PS - 1, WY0 = (int)floorf(STY) + PAD - PS - 1;
+  if (START_OK) {
+    // the reachable window of I1 (lk.hip.h), minus the template mean
+    float *const wdst = win_all + row * (WIN * WIN * NOC);
+    for (int t = j; t < WIN * WIN; t += LPP) {
+      const int wy = t / WIN, wx = t - wy * WIN;
+      const size_t src = ((size_t)clampi(WY0 + wy, a.g.th) * tw + clampi(WX0 + wx, tw)) * NOC;
+#pragma unroll
+      for (int c = 0; c < NOC; ++c) wdst[t * NOC + c] = I1[src + c] - MT;
+    }
+  }
+  asm volatile("" ::: "memory");      // (the window is filled by the lanes of the row and read by all of them; LDS accesses of a wave execute in order)
+  // per-lane window offset of the block's first upper-left tap at position (0, 0): pixel (by, bx) sits at patch offset
+  // (by - PS/2, bx - PS/2), its upper-left tap one up and one left; window coordinates = padded coordinates - (WX0, WY0)
+  const int laneoff = row * (WIN * WIN * NOC) + ((by - PS / 2 - 1 + PAD - WY0) * WIN + (bx - PS / 2 - 1 + PAD - WX0)) * NOC;
+
+  // bilinear query block at (PTX, PTY) (patch.cpp:335-402), centred by mean T
+  auto sample = [&](float (&q)[NE]) {
+    const float fx = floorf(PTX), fy = floorf(PTY);
+    const float r0 = PTX - fx, r1 = PTY - fy;
+    const int pos0 = (int)ceilf(PTX + .00001f), pos1 = (int)ceilf(PTY + .00001f);
+    const float we0 = r0 * r1, we1 = __builtin_fmaf(-r0, r1, r1), we2 = __builtin_fmaf(-r0, r1, r0), we3 = (1.0f - r0) - we1;
+    int ib = (pos1 * WIN + pos0) * NOC + laneoff;
+    asm volatile("" : "+v"(ib));                          // (one address register, the taps are immediates of the LDS reads)
+    const float *tp = win_all + ib;
+    float W[BH + 1][(BW + 1) * NOC];
+#pragma unroll
+    for (int dy = 0; dy <= BH; ++dy)
+#pragma unroll
+      for (int k = 0; k < (BW + 1) * NOC; ++k) W[dy][k] = tp[dy * WROW + k];
+#pragma unroll
+    for (int dy = 0; dy < BH; ++dy)
+#pragma unroll
+      for (int k = 0; k < BW * NOC; ++k)
+        q[dy * BW * NOC + k] = __builtin_fmaf(we0, W[dy + 1][k + NOC], __builtin_fmaf(we1, W[dy + 1][k], __builtin_fmaf(we2, W[dy][k + NOC], we3 * W[dy][k])));
+  };
+  // S = sum (Tx - mean Tx, Ty - mean Ty) q over the patch
+  float S0 = 0.f, S1 = 0.f;
+  auto project = [&]() {
+    float q[NE];
+    sample(q);
+    lkf_v2f sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const lkf_v2f qq = {q[e], q[e]};
+      if (e & 1) sb = __builtin_elementwise_fma(G[e], qq, sb);
+      else sa = __builtin_elementwise_fma(G[e], qq, sa);
+    }
+    if constexpr (NE > 1) sa = sa + sb;
+    S0 = sa.x; S1 = sa.y;
+    lkf_allsum2<LPP>(S0, S1);
+  };
+
+  // The loop is free of divergent branches: every lane evaluates every iteration (a masked-out row costs the wave the same
+  // instructions), the rows that are still running take the results; a row that never started or has been reset reads
+  // whatever its position selects in LDS (out-of-range LDS reads return zeros) and drops it.
+  bool ACT = START_OK && a.max_iter > 0;
+  int CNT = 0;
+  project();                                             // OptimizeStart's first error image (:154)
+  for (int it = 1; it <= a.max_iter; ++it) {
+    if (__builtin_amdgcn_ballot_w64(ACT) == 0) break;
+    const float x0 = __builtin_fmaf(IH00, S0, __builtin_fmaf(IH01, S1, K0));
+    const float x1 = __builtin_fmaf(IH01, S0, __builtin_fmaf(IH11, S1, K1));
+    const float nP0 = P0 - x0, nP1 = P1 - x1;            // :186
+    const float nPTX = RX + nP0, nPTY = RY + nP1;
+    const float ddx = STX - nPTX, ddy = STY - nPTY;
+    // :199-208 and oracle definition D3 (a non-finite update resets the patch): the comparisons are false for NaN, so `keep`
+    // is false for every non-finite position as well
+    const bool keep = (__builtin_fmaf(ddx, ddx, ddy * ddy) <= a.outlier_sq) & (nPTX >= a.g.lb) & (nPTY >= a.g.lb) & (nPTX <= a.g.ubw) & (nPTY <= a.g.ubh);
+    P0 = ACT ? (keep ? nP0 : PIN0) : P0;
+    P1 = ACT ? (keep ? nP1 : PIN1) : P1;
+    CNT += ACT ? 1 : 0;
+    ACT = ACT & keep & (it < a.max_iter);
+    PTX = RX + P0; PTY = RY + P1;
+    if (it < a.max_iter) project();                      // (wave-uniform)
+  }
+
+  // ---- results: the residual at the final position = the patch weights of the densification (patchgrid.cpp:213-275)
+  float r[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) r[e] = 0.f;               // patches that never started: oracle definition D2
+  if (START_OK) {
+    float q[NE];
+    sample(q);
+    float mq = 0.f;
+    if (PN) {
+      float s = q[0];
+#pragma unroll
+      for (int e = 1; e < NE; ++e) s += q[e];
+      mq = lkf_allsum<LPP>(s) * (1.0f / (float)NV);
+    }
+#pragma unroll
+    for (int dy = 0; dy < BH; ++dy)
+#pragma unroll
+      for (int k = 0; k < BW * NOC; ++k) {
+        const int e = dy * BW * NOC + k;
+        r[e] = (q[e] - mq) - (I0[tbase + (size_t)dy * tw * NOC + k] - MT);
+      }
+  }
+  if (!VALID) return;
+  const size_t pb = (size_t)pair * a.g.nop + IP;
+  if (j == 0) {
+    a.p_iter[pb * 2] = P0;
+    a.p_iter[pb * 2 + 1] = P1;
+    if (a.cnt) a.cnt[pb] = CNT;
+  }
+#pragma unroll
+  for (int dy = 0; dy < BH; ++dy)
+#pragma unroll
+    for (int k = 0; k < BW * NOC; ++k)
+      a.pweight[pb * NV + (size_t)((by + dy) * PS + bx) * NOC + k] = fabsf(r[dy * BW * NOC + k]);
+}
+
+}  // namespace fotg

@@ -71,6 +71,13 @@ typedef struct fotg_params {
                           their gray value, converted on load with OpenCV's fixed-point formula (1868 B + 9617 G + 4899 R + 8192)
                           >> 14 -- what cv::imread(file, IMREAD_GRAYSCALE) feeds kroeger/run_dense.cpp:199-209 for a colour file.
                           Bit-identical to the gray 8-bit path on the converted frames; the float entry points still take gray. */
+  int fast_math;       /* 0 (default): parity mode -- every kernel evaluates the reference's f32 expressions in the reference's order,
+                          no fused multiply-add: results bit-identical to the CPU oracle.  1: tolerance mode -- the patch loop
+                          (PatClass::OptimizeIter, kroeger/patch.cpp:159-212) runs an algebraically equivalent form with fused
+                          multiply-adds, free reduction order and a precomputed inverse Hessian (csrc/lk_fast.hip.h): about a third
+                          of the instructions, flows within the north star's 1e-3 px mean endpoint error of the parity mode (the
+                          tests state the measured distances).  Applies to L2 cost, min_iter == max_iter, res_thresh <= 0, optical
+                          flow -- every operating point; other configurations run the exact kernel regardless. */
 } fotg_params;
 
 typedef struct fotg_ctx fotg_ctx;

@@ -1,0 +1,170 @@
+"""fast_math (fotg_params::fast_math, csrc/lk_fast.hip.h): the tolerance mode of the patch loop.  NOT bit-identical to the oracle by
+design -- the north star's bound is a mean endpoint error of 1e-3 px against the kroeger CPU result.  These tests state the bound
+(mean EPE <= 1e-3 px on the full-resolution flow) on BASELINE configs[0]-[3] and print mean / p99 / max; the parity mode
+(tests/test_gpu_parity.py, ==) is untouched by the switch."""
+import numpy as np
+import pytest
+
+from conftest import synth_pair
+from test_gpu_parity import _mods, dev, epe, frames, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TOL_MEAN = 1e-3          # px, full-resolution flow: BASELINE.json north_star "EPE within 1e-3 of kroeger CPU"
+
+
+def stats(a, b):
+    e = epe(a, b)
+    return float(e.mean()), float(np.percentile(e, 99)), float(e.max())
+
+
+def fast_and_exact(F, OFClass, f0, f1, op_point, noc=1, refine=None, n=1, **kw):
+    h, w = f0.shape[1:3] if n > 1 else f0.shape[:2]
+    outs = []
+    for fast in (False, True):
+        op = F.operating_point(op_point, w, noc)
+        if refine is not None:
+            op.use_var_ref = refine
+        for k, v in kw.items():
+            setattr(op, k, v)
+        op.fast_math = fast
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=n)
+        a, b = (dev(f0), dev(f1)) if n > 1 else (dev(f0)[None], dev(f1)[None])
+        lo = ofc.calc_batch(a, b)
+        outs.append((lo.cpu().numpy(), ofc.upsample_crop(lo).cpu().numpy()))
+        ofc.close()
+    return outs
+
+
+def test_fast_math_alley_against_the_oracle(alley, alley_golden_flow):
+    """configs[0]: Sintel alley_1, op-pt 2 -- fast mode against the ORACLE itself (full-resolution flow), and the two-sided bound
+    against the reference's golden alley_0001.flo still holds"""
+    F, OFClass, _, O = _mods()
+    f0, f1, _ = frames("alley", alley)
+    h, w = f0.shape
+    (ex_lo, ex_full), (fa_lo, fa_full) = fast_and_exact(F, OFClass, f0, f1, 2)
+    p = O.op_point(2, w, 1)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    assert np.array_equal(ex_lo[0], ref)                       # (the parity mode, for reference)
+    wp, hp, padw, padh = O.padded_size(w, h, p.sc_f)
+    ref_full = O.upsample_crop(ref, p.sc_l, padw, padh, w, h)
+    mean, p99, mx = stats(fa_full[0], ref_full)
+    print("alley_1 op-pt 2, fast_math vs oracle, full resolution: mean %.3g  p99 %.3g  max %.3g px" % (mean, p99, mx))
+    assert mean <= TOL_MEAN
+    g_mean, g_p99, g_max = stats(fa_full[0], alley_golden_flow)
+    assert 0.0250 <= g_mean <= 0.0270 and 0.165 <= g_p99 <= 0.183, (g_mean, g_p99, g_max)
+
+
+@pytest.mark.parametrize("refine", [False, True])
+def test_fast_math_single_1080p_pair(refine, natural_images):
+    """configs[1] (one 1080p pair, no refinement) and the same with refinement: road_HD + a shifted copy, and a synthetic pair"""
+    F, OFClass, _, O = _mods()
+    a = natural_images["road_HD"].astype(np.float32)
+    b = np.roll(a, (2, 5), axis=(0, 1))
+    for name, (f0, f1) in (("road_HD", (a, b)), ("synthetic", synth_pair(1080, 1920, seed=1234))):
+        (ex_lo, ex_full), (fa_lo, fa_full) = fast_and_exact(F, OFClass, f0, f1, 2, refine=refine)
+        mean, p99, mx = stats(fa_full[0], ex_full[0])
+        print("1080p %s op-pt 2 refine=%s, fast_math vs parity mode (== oracle), full resolution: mean %.3g  p99 %.3g  max %.3g px" % (name, refine, mean, p99, mx))
+        assert mean <= TOL_MEAN, name
+
+
+def test_fast_math_batch_1080p():
+    """configs[2] in small: a batch of 8 synthetic 1080p pairs, op-pt 2 + refinement (the eight-lanes-per-patch kernel is chosen by
+    the launch size: forced here through a batch that reaches the automatic threshold at level 4)"""
+    F, OFClass, _, O = _mods()
+    pairs = [synth_pair(1080, 1920, seed=300 + k) for k in range(8)]
+    f0, f1 = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    (ex_lo, ex_full), (fa_lo, fa_full) = fast_and_exact(F, OFClass, f0, f1, 2, n=8)
+    worst = 0.0
+    for k in range(8):
+        mean, p99, mx = stats(fa_full[k], ex_full[k])
+        worst = max(worst, mean)
+        assert mean <= TOL_MEAN, k
+    print("batch of 8 x 1080p op-pt 2, fast_math vs parity mode: worst mean %.3g px" % worst)
+    # every pair of the batch = the same pair alone (independence)
+    (_, _), (one_lo, _) = fast_and_exact(F, OFClass, f0[3], f1[3], 2)
+    assert np.array_equal(one_lo[0], fa_lo[3])
+
+
+def test_fast_math_4k_quality_preset(natural_images):
+    """configs[3]: yosemite_4k + a shifted copy, op-pt 4 (ps 12, 128 iterations, six scales)"""
+    F, OFClass, _, O = _mods()
+    a = natural_images["yosemite_4k"].astype(np.float32)
+    b = np.roll(a, (3, -4), axis=(0, 1))
+    (ex_lo, ex_full), (fa_lo, fa_full) = fast_and_exact(F, OFClass, a, b, 4)
+    mean, p99, mx = stats(fa_full[0], ex_full[0])
+    print("yosemite_4k op-pt 4, fast_math vs parity mode (== oracle), full resolution: mean %.3g  p99 %.3g  max %.3g px" % (mean, p99, mx))
+    assert mean <= TOL_MEAN
+
+
+@pytest.mark.parametrize("case,op_point", [("alley", 2), ("synth_odd", 3), ("alley", 1)])
+def test_fast_math_patch_stage_against_the_oracle(case, op_point, alley):
+    """the patch stage alone, level by level on the ORACLE's inputs: p_iter and patch weights of the fast kernel against the
+    oracle's (no refinement in between: the levels' errors are not damped)"""
+    F, OFClass, _, O = _mods()
+    f0, f1, noc = frames(case, alley)
+    h, w = f0.shape[:2]
+    op = F.operating_point(op_point, w, noc)
+    op.use_var_ref = False
+    op.fast_math = True
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    p = oracle_params(O, op)
+    P0 = O.Pyramid(O.pad_frame(f0, op.coarsest_scale), op.coarsest_scale, op.patch_size)
+    P1 = O.Pyramid(O.pad_frame(f1, op.coarsest_scale), op.coarsest_scale, op.patch_size)
+    prev_o = None
+    for sl in range(op.coarsest_scale, op.finest_scale - 1, -1):
+        g = ofc.grid[sl - op.finest_scale]
+        lw, lh = P0.level_wh(sl)
+        og = O.Grid(lw, lh, sl, p)
+        og.init(P0.im[sl], P0.dx[sl], P0.dy[sl])
+        g.InitializeGrid(dev(P0.im[sl])[None], dev(P0.dx[sl])[None], dev(P0.dy[sl])[None])
+        g.SetTargetImage(dev(P1.im[sl])[None])
+        if prev_o is not None:
+            og.init_from_coarser(prev_o)
+            g.InitializeFromCoarserOF(dev(prev_o)[None])
+        og.optimize(P1.im[sl])
+        g.Optimize()
+        st = g.read_state(0)
+        d = np.sqrt(((st["p_iter"] - og.p_iter) ** 2).sum(-1))
+        dw = np.abs(st["pweight"] - og.pweight)
+        print("%s op-pt %d scale %d: |p - p_oracle| mean %.3g max %.3g px; |w - w_oracle| mean %.3g max %.3g" % (case, op_point, sl, d.mean(), d.max(), dw.mean(), dw.max()))
+        assert d.mean() <= 2e-4 and np.percentile(d, 99) <= 2e-3, sl
+        assert dw.mean() <= 1e-3, sl
+        prev_o = og.aggregate()
+
+
+def test_fast_math_falls_back_to_the_exact_kernel(alley):
+    """configurations the fast kernel does not cover run the exact one with fast_math set: other cost functions, early termination
+    (min_iter < max_iter), depth mode -- bit-identical to the parity mode"""
+    F, OFClass, _, O = _mods()
+    f0, f1, _ = frames("alley", alley)
+    for kw in ({"cost_func": 1}, {"min_iter": 3}):
+        (ex_lo, _), (fa_lo, _) = fast_and_exact(F, OFClass, f0, f1, 2, **kw)
+        assert np.array_equal(ex_lo, fa_lo), kw
+
+
+@pytest.mark.parametrize("case,op_point,kw", [("alley_rgb", 2, {}), ("synth_rgb", 3, {}), ("alley", 2, {"patch_size": 4, "patch_stride": 0.5}),
+                                               ("alley", 2, {"patch_size": 16, "patch_stride": 0.5}), ("alley", 2, {"use_mean_normalization": False}),
+                                               ("alley", 2, {"use_fbcon": True})])
+def test_fast_math_other_configurations(case, op_point, kw, alley):
+    """RGB patches, patch sizes 4 and 16, no mean normalisation, the forward-backward merge"""
+    F, OFClass, _, O = _mods()
+    f0, f1, noc = frames(case, alley)
+    (ex_lo, ex_full), (fa_lo, fa_full) = fast_and_exact(F, OFClass, f0, f1, op_point, noc=noc, **kw)
+    mean, p99, mx = stats(fa_full[0], ex_full[0])
+    print("%s op-pt %d %s, fast_math vs parity mode: mean %.3g  p99 %.3g  max %.3g px" % (case, op_point, kw, mean, p99, mx))
+    assert mean <= TOL_MEAN
+
+
+@pytest.mark.parametrize("lpp", ["8", "16"])
+def test_fast_math_lanes_per_patch(lpp, alley, monkeypatch):
+    """both layouts of the 8 x 8 gray kernel (FOTG_LK_LPP forces what the launch size selects)"""
+    monkeypatch.setenv("FOTG_LK_LPP", lpp)
+    F, OFClass, _, O = _mods()
+    f0, f1, _ = frames("alley", alley)
+    (ex_lo, ex_full), (fa_lo, fa_full) = fast_and_exact(F, OFClass, f0, f1, 2)
+    mean, p99, mx = stats(fa_full[0], ex_full[0])
+    print("alley op-pt 2, %s lanes per patch: mean %.3g  p99 %.3g  max %.3g px" % (lpp, mean, p99, mx))
+    assert mean <= TOL_MEAN
