@@ -264,13 +264,14 @@ def synth_frame_pair(h, w, seed, device):
     return f0, f1
 
 
-def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr):
+def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=None):
     """BASELINE configs[3]: ONE 3840x2160 pair at operating point 4 (ps 12, stride 3, scales 7..2, 128 LK iterations, refinement on
     every level up to 960x544): ms per pair one at a time and with four pairs in flight, and the rooflines of its two dominant
     kernels, each timed alone with HIP events on the launch stream."""
     from flowonthego_amd.pipeline import FlowPipeline
     w4, h4 = 3840, 2160
     op = F.operating_point(4, w4, 1)
+    op.fast_math = bool(fast)
     ip = F.img_params(width=w4, height=h4, padding=op.patch_size)
     ofc = OFClass(op, ip, max_batch=1, device=local)
     f0, f1 = synth_frame_pair(h4, w4, 77, dev)
@@ -294,12 +295,14 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr):
     ms = st["lk[%d]" % lvl]
     tf = flops / (ms * 1e-3) / 1e12
     lk_all = sum(v for k, v in st.items() if k.startswith("lk["))
-    res["rooflines"] = [{"bound": "valu", "kernel": "fotg::lk_kernel<12,1,false,true,false> (level %d: %d patches x %d evaluations x 144 px)" % (lvl, nop, evals),
+    res["rooflines"] = [{"bound": "valu", "kernel": "fotg::%s (level %d: %d patches x %d evaluations x 144 px)" % ("lk_fast_kernel<12,1,16>" if fast else "lk_kernel<12,1,false,true,false>", lvl, nop, evals),
                          "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "useful_flops_per_launch": flops,
                          "ms_per_launch": ms, "share_of_pair": lk_all / sum(st.values()),
-                         "note": "useful flops only (16 per pixel-evaluation); the kernel is bound by the issue rate of its instruction stream (263 VALU "
-                                 "wave-instructions per four-patch iteration, profiles/r04_pmc_valu.json, retired at one per ~4.8 cycles and SIMD; five instead of "
-                                 "three waves per SIMD do not speed it up: docs/EXPERIMENTS.md)"}]
+                         "note": ("useful flops only (16 per pixel-evaluation); tolerance mode: 91 VALU wave-instructions per four-patch iteration "
+                                  "(profiles/r05_pmc_valu.json), VALU busy 87 %") if fast else
+                                 ("useful flops only (16 per pixel-evaluation); the kernel is bound by the issue rate of its instruction stream (263 VALU "
+                                  "wave-instructions per four-patch iteration, profiles/r04_pmc_valu.json, retired at one per ~4.8 cycles and SIMD; five instead of "
+                                  "three waves per SIMD do not speed it up: docs/EXPERIMENTS.md)")}]
     # one sor_coupled call of the finest level through the tile pipeline
     try:
         ev = HipEvents()
@@ -341,6 +344,14 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr):
         k[0] += 1
     msD = timed(sub, pipe.synchronize, 8 * D, warm=2 * D) * 1e3          # (the window starts with an empty pipe and ends with a drain)
     one = ofc.calc_batch(f0, f1).clone()
+    res["fast_math"] = bool(fast)
+    if ref_flow is not None:
+        # endpoint error of this mode's full-resolution flow against the parity mode's (which is == the oracle: tests)
+        e = torch.sqrt(((ofc.upsample_crop(one) - ref_flow) ** 2).sum(-1)).flatten()
+        res["epe_vs_parity_mode_px"] = {"mean": float(e.mean()), "p99": float(torch.quantile(e[::4], 0.99)), "max": float(e.max()),
+                                        "note": "full-resolution flow (3840x2160) of this mode against the parity mode's, which is bit-identical to the CPU oracle"}
+    else:
+        res["_full_flow"] = ofc.upsample_crop(one).clone()
     res["in_flight"] = {"batches_in_flight": D, "ms_per_pair": msD, "value": 1e3 / msD, "unit": "frame-pairs/s",
                         "same_bits_as_one_at_a_time": bool(torch.equal(outs[0], one))}
     pipe.close(); ofc.close()
@@ -735,6 +746,38 @@ def main():
             # the whole path against the same roof: pairs/s x 16 654 080 B / 8 TB/s
             res["whole_path_hbm_frac"] = value / world * (2 * W * H * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS
             res["time_dominant_stage"] = max(st, key=st.get)
+            # the tolerance mode of the patch loop (fotg_params::fast_math, csrc/lk_fast.hip.h) on the headline workload -- NOT `value`
+            # (the default / parity mode): same steps, one batch at a time and in flight, with the endpoint error against the parity
+            # mode's flows (which are bit-identical to the CPU oracle)
+            opf = F.operating_point(OP_POINT, W, 1, sor_mode=a.sor_mode)
+            opf.fast_math = True
+            ofcf = OFClass(opf, F.img_params(width=W, height=H, padding=opf.patch_size), max_batch=a.batch, device=local)
+            outf = ofcf.new_outflow(a.batch)
+            tff = timed(lambda: ofcf.calc_batch(I0, I1, None, outf), torch.cuda.synchronize, a.steps)
+            stf = stage_breakdown(ofcf, I0, I1, outf, lib, stream_ptr)
+            ofc.calc_batch(I0, I1, None, out); ofcf.calc_batch(I0, I1, None, outf)
+            ef = torch.cat([torch.sqrt(((ofcf.upsample_crop(outf[k:k + 8]) - ofc.upsample_crop(out[k:k + 8])) ** 2).sum(-1)).flatten() for k in range(0, a.batch, 8)])
+            res["fast_math"] = {"value": a.batch / tff, "unit": "frame-pairs/s", "ms_per_step": tff * 1e3,
+                                "note": "fotg_params::fast_math = 1 (tolerance mode of the patch loop), one batch at a time; `value` above is the parity mode",
+                                "lk_stage_ms": {k: round(v, 4) for k, v in stf.items() if k.startswith("lk[")},
+                                "lk_stage_ms_parity_mode": {k: round(v, 4) for k, v in st.items() if k.startswith("lk[")},
+                                "epe_vs_parity_mode_px": {"mean": float(ef.mean()), "p99": float(torch.quantile(ef[::64], 0.99)), "max": float(ef.max()),
+                                                          "note": "full-resolution flows (1920x1080) of all %d pairs against the parity mode's (== the CPU oracle)" % a.batch}}
+            del ef
+            if pipe:
+                pipef = FlowPipeline(opf, F.img_params(width=W, height=H, padding=opf.patch_size), max_batch=a.batch, depth=D, device=local)
+                torch.cuda.synchronize()
+                k = [0]
+
+                def subf():
+                    f0, f1, o = slots[k[0] % D]
+                    pipef.submit(f0, f1, None, o, after_current_stream=False)
+                    k[0] += 1
+                tfi = timed(subf, pipef.synchronize, a.steps, warm=2 * D)
+                res["fast_math"]["in_flight"] = {"value": a.batch / tfi, "unit": "frame-pairs/s", "ms_per_step": tfi * 1e3, "batches_in_flight": D}
+                pipef.close()
+            ofcf.close()
+            del outf
             # the same batch handed over as 8-bit frames (fotg_calc_batch_u8) -- NOT the headline value:
             # the reference's API takes float32 frames (src/run_dense.cpp:144-162)
             U0, U1 = I0.to(torch.uint8), I1.to(torch.uint8)
@@ -923,6 +966,9 @@ def main():
                 node.close()
             # BASELINE configs[3]
             res["config_4k_op4"] = config_4k_op4(F, OFClass, lib, local, dev, stream_ptr)
+            ref4k = res["config_4k_op4"].pop("_full_flow")
+            res["config_4k_op4_fast_math"] = config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=True, ref_flow=ref4k)
+            del ref4k
         if a.extras:
             # stereo depth mode (kroeger SELECTMODE=2): same frames as a rectified pair, one displacement channel
             opd = F.operating_point(OP_POINT, W, 1, sor_mode=0)

@@ -640,7 +640,7 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   // fotg_params::fast_math: the tolerance-mode kernel (lk_fast.hip.h) for what every operating point runs -- L2 cost, optical
   // flow, min_iter == max_iter, res_thresh <= 0; anything else (and the per-iteration trace tap) stays on the exact kernel
   if (c->p.fast_math && !c->p.depth && c->p.costfct == 0 && c->p.min_iter == c->p.max_iter && !(c->p.res_thresh > 0.0f) && !gs.trace_host) {
-    const int lppf = (c->ps == 8 && c->noc == 1 && (c->tune.lk_lpp == 8 || (c->tune.lk_lpp == 0 && waves8 >= c->tune.lk_lpp_min_waves))) ? 8 : 16;
+    const int lppf = ((c->ps == 8 || c->ps == 12) && c->noc == 1 && (c->tune.lk_lpp == 8 || (c->tune.lk_lpp == 0 && c->ps == 8 && waves8 >= c->tune.lk_lpp_min_waves))) ? 8 : 16;
     const int ppwf = 64 / lppf;
     dim3 gridf((g.nop + ppwf - 1) / ppwf, n);
 #define LKF(PS_, NOC_, LPP_) lk_fast_kernel<PS_, NOC_, LPP_><<<gridf, block, 0, s>>>(a)
@@ -648,7 +648,8 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
       case 41: LKF(4, 1, 16); break;   case 43: LKF(4, 3, 16); break;
       case 81: if (lppf == 8) LKF(8, 1, 8); else LKF(8, 1, 16); break;
       case 83: LKF(8, 3, 16); break;
-      case 121: LKF(12, 1, 16); break; case 123: LKF(12, 3, 16); break;
+      case 121: if (lppf == 8) LKF(12, 1, 8); else LKF(12, 1, 16); break;
+      case 123: LKF(12, 3, 16); break;
       case 161: LKF(16, 1, 16); break; default: LKF(16, 3, 16); break;
     }
 #undef LKF

@@ -181,25 +181,42 @@ __global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kerne
   // (by - PS/2, bx - PS/2), its upper-left tap one up and one left; window coordinates = padded coordinates - (WX0, WY0)
   const int laneoff = row * (WIN * WIN * NOC) + ((by - PS / 2 - 1 + PAD - WY0) * WIN + (bx - PS / 2 - 1 + PAD - WX0)) * NOC;
 
-  // bilinear query block at (PTX, PTY) (patch.cpp:335-402), centred by mean T
+  // bilinear query block at (PTX, PTY) (patch.cpp:335-402), centred by mean T.  Two neighbouring values of a block row as one
+  // packed-f32 operation: the pair (W[k], W[k+1]) and the pair one pixel to the right come from LDS as two 8-byte reads (every
+  // value is read twice, no register shuffling), the four weights are broadcast operands.
+  constexpr int RW = BW * NOC;                           // values per block row
+  constexpr int NPR = RW / 2;                            // pairs per block row (+ one single value when RW is odd)
+  typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));
   auto sample = [&](float (&q)[NE]) {
-    const float fx = floorf(PTX), fy = floorf(PTY);
-    const float r0 = PTX - fx, r1 = PTY - fy;
-    const int pos0 = (int)ceilf(PTX + .00001f), pos1 = (int)ceilf(PTY + .00001f);
+    const float r0 = __builtin_amdgcn_fractf(PTX), r1 = __builtin_amdgcn_fractf(PTY);      // x - floor(x) (:344-345) in one instruction
+    // ceil(x + 1e-5) keeps the reference's corner pair (:340-343); the window index is formed in floating point (exact: small integers)
+    const float cx = ceilf(PTX + .00001f), cy = ceilf(PTY + .00001f);
     const float we0 = r0 * r1, we1 = __builtin_fmaf(-r0, r1, r1), we2 = __builtin_fmaf(-r0, r1, r0), we3 = (1.0f - r0) - we1;
-    int ib = (pos1 * WIN + pos0) * NOC + laneoff;
+    int ib = (int)__builtin_fmaf(cy, (float)WROW, cx * (float)NOC) + laneoff;
     asm volatile("" : "+v"(ib));                          // (one address register, the taps are immediates of the LDS reads)
     const float *tp = win_all + ib;
-    float W[BH + 1][(BW + 1) * NOC];
+    const lkf_v2f w0 = {we0, we0}, w1 = {we1, we1}, w2 = {we2, we2}, w3 = {we3, we3};
+    lkf_v2f A[BH + 1][NPR > 0 ? NPR : 1], Cc[BH + 1][NPR > 0 ? NPR : 1];
+    float sA[BH + 1], sC[BH + 1];
 #pragma unroll
-    for (int dy = 0; dy <= BH; ++dy)
+    for (int dy = 0; dy <= BH; ++dy) {
 #pragma unroll
-      for (int k = 0; k < (BW + 1) * NOC; ++k) W[dy][k] = tp[dy * WROW + k];
+      for (int m = 0; m < NPR; ++m) {
+        A[dy][m] = *reinterpret_cast<const v2u *>(tp + dy * WROW + 2 * m);
+        Cc[dy][m] = *reinterpret_cast<const v2u *>(tp + dy * WROW + 2 * m + NOC);
+      }
+      if constexpr (RW & 1) { sA[dy] = tp[dy * WROW + RW - 1]; sC[dy] = tp[dy * WROW + RW - 1 + NOC]; }
+    }
 #pragma unroll
-    for (int dy = 0; dy < BH; ++dy)
+    for (int dy = 0; dy < BH; ++dy) {
 #pragma unroll
-      for (int k = 0; k < BW * NOC; ++k)
-        q[dy * BW * NOC + k] = __builtin_fmaf(we0, W[dy + 1][k + NOC], __builtin_fmaf(we1, W[dy + 1][k], __builtin_fmaf(we2, W[dy][k + NOC], we3 * W[dy][k])));
+      for (int m = 0; m < NPR; ++m) {
+        const lkf_v2f v = __builtin_elementwise_fma(w0, Cc[dy + 1][m], __builtin_elementwise_fma(w1, A[dy + 1][m], __builtin_elementwise_fma(w2, Cc[dy][m], w3 * A[dy][m])));
+        q[dy * RW + 2 * m] = v.x; q[dy * RW + 2 * m + 1] = v.y;
+      }
+      if constexpr (RW & 1)
+        q[dy * RW + RW - 1] = __builtin_fmaf(we0, sC[dy + 1], __builtin_fmaf(we1, sA[dy + 1], __builtin_fmaf(we2, sC[dy], we3 * sA[dy])));
+    }
   };
   // S = sum (Tx - mean Tx, Ty - mean Ty) q over the patch
   float S0 = 0.f, S1 = 0.f;
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kerne
     const float x1 = __builtin_fmaf(IH01, S0, __builtin_fmaf(IH11, S1, K1));
     const float nP0 = P0 - x0, nP1 = P1 - x1;            // :186
     const float nPTX = RX + nP0, nPTY = RY + nP1;
-    const float ddx = STX - nPTX, ddy = STY - nPTY;
+    const float ddx = PIN0 - nP0, ddy = PIN1 - nP1;      // = pt_st - pt_iter (:199) without waiting for the new position
     // :199-208 and oracle definition D3 (a non-finite update resets the patch): the comparisons are false for NaN, so `keep`
     // is false for every non-finite position as well
     const bool keep = (__builtin_fmaf(ddx, ddx, ddy * ddy) <= a.outlier_sq) & (nPTX >= a.g.lb) & (nPTY >= a.g.lb) & (nPTX <= a.g.ubw) & (nPTY <= a.g.ubh);

@@ -1,9 +1,9 @@
 #!/bin/bash
-# instruction counters of the 4K op-pt 4 kernels (run on the GPU box): tools/pmc_4k.sh "SQ_WAVES SQ_INSTS_VALU ..." tag
+# instruction counters of the 4K op-pt 4 kernels (run on the GPU box): tools/pmc_4k.sh "SQ_WAVES SQ_INSTS_VALU ..." tag [--fast]
 OUT=$PWD/gpurun_out/pmc4k_${2:-a}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/tools/time_4k_op4.py > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/tools/time_4k_op4.py $3 > $OUT/log.txt 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
 import csv, collections

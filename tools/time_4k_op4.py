@@ -12,6 +12,7 @@ import flowonthego_amd as F
 from flowonthego_amd.oflow import OFClass
 f0, f1 = synth_pair(2160, 3840, seed=5)
 op = F.operating_point(4, 3840, 1)
+op.fast_math = "--fast" in sys.argv              # the tolerance mode of the patch loop (csrc/lk_fast.hip.h)
 ofc = OFClass(op, F.img_params(width=3840, height=2160, padding=op.patch_size))
 a, b = torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda()
 for _ in range(2):
