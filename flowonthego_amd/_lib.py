@@ -51,6 +51,7 @@ SYMBOLS = [
     ("fotg_node_submit_scatter", C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_long)]),
     ("fotg_node_wait", C.c_int, [vp, C.c_long]),
     ("fotg_node_sync", C.c_int, [vp]),
+    ("fotg_node_last_hip_error", C.c_int, [vp]),
     ("fotg_node_info", C.c_int, [vp] + [C.POINTER(C.c_int)] * 4),
     ("fotg_node_pipe", C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     ("fotg_calc", C.c_int, [vp, vp, vp, vp, vp]),

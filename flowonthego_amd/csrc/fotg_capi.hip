@@ -1371,6 +1371,15 @@ struct fotg_pipe {
   hipEvent_t done[4 * FOTG_PIPE_MAX_DEPTH];
   int nring;
   long submitted;
+  // Self-healing host waits.  The tile solver's bounded waits (varref_tiles.hip.h) raise ONE word per context; a host wait that finds
+  // it set cannot tell which of the context's batches raised it, so it recomputes every batch of that context that has not been
+  // verified yet -- on the solver path without inter-workgroup waits (FOTG_VR_PATH=1's) -- from the arguments kept here.  The caller's
+  // contract (frames and outflow untouched until the ticket has been waited for) is what makes that legal.
+  struct Args { int n, u8; const void *I0, *I1; const float *initflow; float *out; } args[4 * FOTG_PIPE_MAX_DEPTH];
+  signed char tstatus[4 * FOTG_PIPE_MAX_DEPTH];      // per ticket (of the last nring): 0 unknown, 1 good, 2 stalled and not recomputed
+  long verified[FOTG_PIPE_MAX_DEPTH];                // per slot: tickets below this one are known good (or have their status in tstatus)
+  long healed;                                       // batches recomputed so far
+  std::mutex *mu;                                    // submit / verification (fotg_node waits from another thread than the one that submits)
 };
 
 void fotg_pipe_destroy(fotg_pipe *q)
@@ -1384,6 +1393,7 @@ void fotg_pipe_destroy(fotg_pipe *q)
     if (q->stream[k]) (void)hipStreamDestroy(q->stream[k]);
   }
   for (auto &e : q->done) if (e) (void)hipEventDestroy(e);
+  delete q->mu;
   delete q;
 }
 
@@ -1405,6 +1415,8 @@ int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int
   if (!q) return FOTG_ERR_ARG;
   memset((void *)q, 0, sizeof(*q));
   q->device = device; q->depth = depth; q->nring = 4 * depth;
+  q->mu = new (std::nothrow) std::mutex();
+  if (!q->mu) { delete q; return FOTG_ERR_ARG; }
   // the slots' streams first and back to back, so that the runtime spreads them over its hardware queues
   for (int k = 0; k < depth; ++k)
     if (hipStreamCreateWithFlags(&q->stream[k], hipStreamNonBlocking) != hipSuccess ||
@@ -1431,10 +1443,67 @@ int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int
 }
 
 extern "C++" {
+// one batch again on context c, synchronously, on the solver path that has no inter-workgroup waits (single-wave solver; levels of
+// more than 1024 rows have only the tile pipeline: those are simply tried again); FOTG_OK = the flow is in place and valid
+template <typename T>
+static int recompute_safe(fotg_ctx *c, int n, const T *I0, const T *I1, const float *initflow, float *outflow, hipStream_t s)
+{
+  const int keep = c->tune.vr_path;
+  int st = FOTG_ERR_STALL;
+  for (int attempt = 0; attempt < 3 && st == FOTG_ERR_STALL; ++attempt) {
+    c->tune.vr_path = 1;
+    st = calc_range<T>(c, n, I0, I1, initflow, outflow, s);
+    c->tune.vr_path = keep;
+    if (st != FOTG_OK) return st;
+    HIPCHK(hipStreamSynchronize(s));
+    st = (c->stall_host && *(volatile int *)c->stall_host) ? FOTG_ERR_STALL : FOTG_OK;
+    if (c->stall_host) *(volatile int *)c->stall_host = 0;
+  }
+  return st;
+}
+
+// After the host has synchronised with ticket t (slot k): classify the unverified tickets of the slot.  heal = recompute the
+// suspects (1) or only mark them (0).  Called with the pipe's mutex held.
+static int pipe_verify(fotg_pipe *q, long t, int heal, int *newly_stalled = nullptr)
+{
+  const int k = (int)(t % q->depth);
+  fotg_ctx *c = q->ctx[k];
+  auto known = [&](long u) { return u >= q->submitted - q->nring; };       // (the ring still describes ticket u)
+  if (t < q->verified[k]) return known(t) && q->tstatus[t % q->nring] == 2 ? FOTG_ERR_STALL : FOTG_OK;
+  const bool flagged = c->stall_host && *(volatile int *)c->stall_host != 0;
+  if (!flagged) {
+    // everything of this slot that has completed so far is good: at least the tickets up to t
+    for (long u = q->verified[k]; u <= t; u += 1) if (u % q->depth == k && known(u)) q->tstatus[u % q->nring] = 1;
+    q->verified[k] = t + 1;
+    return FOTG_OK;
+  }
+  // the word does not say which batch of this context raised it: all of them that are not verified yet are suspects
+  HIPCHK(hipStreamSynchronize(q->stream[k]));
+  *(volatile int *)c->stall_host = 0;
+  ++c->stalls;
+  for (long u = q->verified[k]; u < q->submitted; ++u) {
+    if (u % q->depth != k) continue;
+    if (!known(u)) continue;                                              // (more than 4 * depth submissions ago: nothing is known about it any more)
+    int st = FOTG_ERR_STALL;
+    if (heal) {
+      const fotg_pipe::Args &ar = q->args[u % q->nring];
+      st = ar.u8 ? recompute_safe<unsigned char>(c, ar.n, (const unsigned char *)ar.I0, (const unsigned char *)ar.I1, ar.initflow, ar.out, q->stream[k])
+                 : recompute_safe<float>(c, ar.n, (const float *)ar.I0, (const float *)ar.I1, ar.initflow, ar.out, q->stream[k]);
+      if (st == FOTG_OK) ++q->healed;
+      else if (st != FOTG_ERR_STALL) return st;
+    }
+    q->tstatus[u % q->nring] = st == FOTG_OK ? 1 : 2;
+    if (st != FOTG_OK && newly_stalled) ++*newly_stalled;
+  }
+  q->verified[k] = q->submitted;
+  return known(t) && q->tstatus[t % q->nring] == 2 ? FOTG_ERR_STALL : FOTG_OK;
+}
+
 template <typename T>
 static int pipe_submit(fotg_pipe *q, int n, const T *I0, const T *I1, const float *initflow, float *outflow, void *after_stream, long *ticket)
 {
   if (!q || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
+  std::lock_guard<std::mutex> lock(*q->mu);
   const int k = (int)(q->submitted % q->depth);
   fotg_ctx *c = q->ctx[k];
   if (n < 1 || n > c->max_batch) return FOTG_ERR_BATCH;
@@ -1447,6 +1516,11 @@ static int pipe_submit(fotg_pipe *q, int n, const T *I0, const T *I1, const floa
   const int st = calc_range<T>(c, n, I0, I1, initflow, outflow, q->stream[k]);
   if (st != FOTG_OK) return st;
   HIPCHK(hipEventRecord(q->done[q->submitted % q->nring], q->stream[k]));
+  {
+    fotg_pipe::Args &ar = q->args[q->submitted % q->nring];
+    ar.n = n; ar.u8 = sizeof(T) == 1; ar.I0 = I0; ar.I1 = I1; ar.initflow = initflow; ar.out = outflow;
+    q->tstatus[q->submitted % q->nring] = 0;
+  }
   if (ticket) *ticket = q->submitted;
   ++q->submitted;
   return FOTG_OK;
@@ -1465,12 +1539,17 @@ int fotg_pipe_submit_u8(fotg_pipe *q, int n, const unsigned char *I0, const unsi
 
 int fotg_pipe_wait(fotg_pipe *q, long ticket, void *stream, int host_wait)
 {
-  if (!q || ticket < 0 || ticket >= q->submitted) return FOTG_ERR_ARG;
+  if (!q || ticket < 0) return FOTG_ERR_ARG;
+  { std::lock_guard<std::mutex> lock(*q->mu); if (ticket >= q->submitted) return FOTG_ERR_ARG; }
   ON_DEVICE(q->device);
   // (an event re-recorded since -- more than 4 * depth tickets ago -- belongs to a later batch of the same slot's stream: waiting for
   // that one covers the ticket)
-  const int k = (int)(ticket % q->depth), e = (int)(ticket % q->nring);
-  if (host_wait) { HIPCHK(hipEventSynchronize(q->done[e])); return stall_status(q->ctx[k]); }
+  const int e = (int)(ticket % q->nring);
+  if (host_wait) {
+    HIPCHK(hipEventSynchronize(q->done[e]));           // (not under the mutex: submits go on while this thread waits)
+    std::lock_guard<std::mutex> lock(*q->mu);
+    return pipe_verify(q, ticket, host_wait != 2);
+  }
   HIPCHK(hipStreamWaitEvent((hipStream_t)stream, q->done[e], 0));
   return FOTG_OK;
 }
@@ -1482,6 +1561,8 @@ int fotg_pipe_wait(fotg_pipe *q, long ticket, void *stream, int host_wait)
 int fotg_pipe_ticket_event(fotg_pipe *q, long ticket, void **event)
 {
   if (!q || !event || ticket < 0) return FOTG_ERR_ARG;
+  std::lock_guard<std::mutex> lock(*q->mu);
+  if (ticket >= q->submitted) return FOTG_ERR_ARG;      // (an event of the ring that was never recorded, or belongs to an older batch)
   *event = (void *)q->done[ticket % q->nring];
   return FOTG_OK;
 }
@@ -1491,8 +1572,19 @@ int fotg_pipe_sync(fotg_pipe *q)
   if (!q) return FOTG_ERR_ARG;
   ON_DEVICE(q->device);
   for (int k = 0; k < q->depth; ++k) HIPCHK(hipStreamSynchronize(q->stream[k]));
+  std::lock_guard<std::mutex> lock(*q->mu);
   int st = FOTG_OK;
-  for (int k = 0; k < q->depth; ++k) if (stall_status(q->ctx[k]) != FOTG_OK) st = FOTG_ERR_STALL;
+  for (int k = 0; k < q->depth; ++k) {
+    // the last ticket of slot k (if any): verifying it covers every earlier one of the slot
+    long last = q->submitted - 1;
+    while (last >= 0 && last % q->depth != k) --last;
+    if (last < 0) continue;
+    if (last < q->verified[k]) continue;                  // (all verified; a ticket that could not be recomputed keeps its status for whoever waits for it)
+    int bad = 0;
+    const int sk = pipe_verify(q, last, 1, &bad);
+    if (sk != FOTG_OK) st = sk;
+    else if (bad) st = FOTG_ERR_STALL;
+  }
   return st;
 }
 
@@ -1598,8 +1690,14 @@ int fotg_calc(fotg_ctx *c, const float *I0, const float *I1, const float *initfl
   if (st) return st;
   ON_DEVICE(c->device);
   HIPCHK(hipStreamSynchronize(nullptr));
+  if (stall_status(c) == FOTG_ERR_STALL) {
+    // a bounded inter-workgroup wait of the tile solver gave up: this call knows its result is wrong and its inputs are still in
+    // place -- compute it again on the solver path that has no such waits instead of handing an error to a valid call
+    st = recompute_safe<float>(c, 1, I0, I1, initflow, c->flow[c->p.sc_l], nullptr);
+    if (st != FOTG_OK) return st;
+  }
   HIPCHK(hipMemcpy(outflow_host, c->flow[c->p.sc_l], (size_t)g.w * g.h * c->nch * sizeof(float), hipMemcpyDeviceToHost));
-  return stall_status(c);
+  return FOTG_OK;
 }
 
 int fotg_upsample_crop(fotg_ctx *c, int n, const float *flow, float *out, void *stream)

@@ -1,6 +1,6 @@
 // fotg_node.hip -- one process, several GPUs ("one process per node with one host thread + stream set per GPU").
 // Built on the public C-ABI only (fotg_pipe_* of include/fotg.h): a node owns one pipe and one host thread per device slot.
-// Frame pairs are independent, so a batch of n pairs is cut into contiguous shards (pair k -> slot k*ndev/n, fotg_node_shard)
+// Frame pairs are independent, so a batch of n pairs is cut into contiguous shards (fotg_node_shard: the first n % ndev slots get one pair more)
 // and every slot runs its shard through its own pipe; there is no data-path exchange between the GPUs.  Two ways in:
 //   resident   the caller's frames of shard d already live on device d (per-slot pointers) -- what a server with per-GPU
 //              decoders does, and what the scaling bench measures;
@@ -40,10 +40,12 @@ struct Slot {
   std::thread th;
   hipStream_t copy = nullptr;                  // peer copies of the scatter mode (created with the staging buffers)
   hipEvent_t done[RING] = {};                  // scatter jobs: completion of job id on this slot (recorded on `copy`): done[id % RING]
-  std::vector<hipEvent_t> piece_ev[RING];      // resident jobs: the pipe's own completion events of the job's pieces (no extra stream:
-                                               // a stream that only waits would still occupy -- and block -- a hardware queue)
+  std::vector<long> piece_tk[RING];            // the pipe tickets of the job's pieces: fotg_node_wait waits for them through the pipe (its own
+                                               // completion events -- no extra stream: a stream that only waits would still occupy, and
+                                               // block, a hardware queue), which also verifies / recomputes a stalled piece
   bool on_copy[RING] = {};
   int status[RING] = {};                       // issue status of job id on this slot
+  int hip_err[RING] = {};                      // fotg_last_hip_error() of the issuing thread when status is FOTG_ERR_HIP
   long issued = 0;                             // jobs this slot's thread has issued (guarded by the node's mutex)
   // scatter mode: depth + 1 staging buffers of 2 x chunk frames + chunk flows each
   std::vector<void *> stage_in;
@@ -60,6 +62,10 @@ struct fotg_node {
   std::condition_variable cv_job, cv_issued;
   Job ring[RING];
   long submitted = 0, waited = 0;              // jobs handed in; jobs [0, waited) have been waited for (their ring entries are free)
+  int jstatus[RING] = {};                      // final status of job id (id % RING), valid for ids in [waited - RING, waited): a repeated or
+  long jstatus_id[RING];                       // out-of-order wait reports the job's OWN status
+  int last_hip = 0;                            // HIP error code behind the last FOTG_ERR_HIP a wait returned (raised on a worker thread)
+  std::mutex wait_mu;                          // one waiting thread at a time
   bool stop = false;
 };
 
@@ -71,18 +77,11 @@ struct OnDevice {
   ~OnDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-// completion of (job, slot): the pipe's own events of the job's pieces (resident frames, the source slot of a scatter) or an
-// event behind the last copy on the slot's copy stream (the pulling slots of a scatter)
+// completion of (job, slot): the pipe tickets of the job's pieces (resident frames, the source slot of a scatter), or an event
+// behind the last copy on the slot's copy stream (the pulling slots of a scatter) and the tickets for the stall check
 int finish_job(Slot &s, const Job &j, const std::vector<long> &tickets)
 {
-  std::vector<hipEvent_t> &ev = s.piece_ev[j.id % RING];
-  ev.clear();
-  for (long t : tickets) {
-    void *e = nullptr;
-    const int st = fotg_pipe_ticket_event(s.pipe, t, &e);
-    if (st != FOTG_OK) return st;
-    ev.push_back((hipEvent_t)e);
-  }
+  s.piece_tk[j.id % RING] = tickets;
   s.on_copy[j.id % RING] = false;
   return FOTG_OK;
 }
@@ -158,7 +157,7 @@ int issue_scatter(fotg_node *nd, Slot &s, const Job &j)
   // the job's event: behind the last copy on the copy stream (which is behind every compute of the job)
   if (hipEventRecord(s.done[j.id % RING], s.copy) != hipSuccess) return FOTG_ERR_HIP;
   s.on_copy[j.id % RING] = true;
-  s.piece_ev[j.id % RING].clear();
+  s.piece_tk[j.id % RING] = tickets;
   return FOTG_OK;
 }
 
@@ -178,6 +177,7 @@ void worker(fotg_node *nd, int k)
     {
       std::lock_guard<std::mutex> lk(nd->mu);
       s.status[j.id % RING] = st;
+      s.hip_err[j.id % RING] = st == FOTG_ERR_HIP ? fotg_last_hip_error() : 0;
       ++s.issued;
     }
     nd->cv_issued.notify_all();
@@ -257,6 +257,7 @@ int fotg_node_create(const fotg_params *p, int w_org, int h_org, const int *devi
   if (!nd) return FOTG_ERR_ARG;
   nd->ndev = ndev; nd->depth = depth; nd->max_batch = max_batch; nd->w = w_org; nd->h = h_org; nd->noc = p->noc; nd->nch = p->depth ? 1 : 2; nd->u8_color = p->u8_color;
   nd->frame_elems = (size_t)w_org * h_org * p->noc;
+  for (auto &v : nd->jstatus_id) v = -1;
   for (int k = 0; k < ndev; ++k) {
     Slot &s = nd->slot[k];
     s.device = devices[k]; s.index = k;
@@ -295,19 +296,31 @@ int fotg_node_submit_u8(fotg_node *nd, int n, const unsigned char *const *I0, co
 int fotg_node_submit_scatter(fotg_node *nd, int n, const float *I0, const float *I1, float *outflow, int chunk, long *ticket)
 {
   if (!nd) return FOTG_ERR_ARG;
-  // the staging buffers of the pulling slots, sized for max_batch pairs per chunk, on first use
-  for (int k = 1; k < nd->ndev; ++k) {
-    Slot &s = nd->slot[k];
-    if (!s.stage_in.empty()) continue;
-    OnDevice od(s.device);
-    if (!s.copy && hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking) != hipSuccess) return FOTG_ERR_HIP;
-    for (int b = 0; b < nd->depth + 1; ++b) {
-      void *in = nullptr; float *o = nullptr;
-      if (hipMalloc(&in, 2 * (size_t)nd->max_batch * nd->frame_elems * 4) != hipSuccess || hipMalloc((void **)&o, (size_t)nd->max_batch * nd->flow_elems * 4) != hipSuccess) {
-        (void)hipFree(in);
+  // the staging buffers of the pulling slots, sized for max_batch pairs per chunk, on first use: all of a slot's buffers or none
+  // (a partial set would silently run the slot without the copy / compute overlap), under the node's mutex (two submitting threads)
+  {
+    std::lock_guard<std::mutex> lk(nd->mu);
+    for (int k = 1; k < nd->ndev; ++k) {
+      Slot &s = nd->slot[k];
+      if (!s.stage_in.empty()) continue;
+      OnDevice od(s.device);
+      if (!s.copy && hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking) != hipSuccess) return FOTG_ERR_HIP;
+      std::vector<void *> in;
+      std::vector<float *> outb;
+      bool ok = true;
+      for (int b = 0; b < nd->depth + 1 && ok; ++b) {
+        void *pi = nullptr; float *po = nullptr;
+        ok = hipMalloc(&pi, 2 * (size_t)nd->max_batch * nd->frame_elems * 4) == hipSuccess;
+        if (ok) { in.push_back(pi); ok = hipMalloc((void **)&po, (size_t)nd->max_batch * nd->flow_elems * 4) == hipSuccess; }
+        if (ok) outb.push_back(po);
+      }
+      if (!ok) {
+        nd->last_hip = (int)hipGetLastError();
+        for (void *q : in) (void)hipFree(q);
+        for (float *q : outb) (void)hipFree(q);
         return FOTG_ERR_HIP;
       }
-      s.stage_in.push_back(in); s.stage_out.push_back(o);
+      s.stage_in = in; s.stage_out = outb;
     }
   }
   const void *a[1] = {I0}, *b[1] = {I1};
@@ -318,35 +331,45 @@ int fotg_node_submit_scatter(fotg_node *nd, int n, const float *I0, const float 
 int fotg_node_wait(fotg_node *nd, long ticket)
 {
   if (!nd || ticket < 0) return FOTG_ERR_ARG;
-  int st = FOTG_OK;
+  std::lock_guard<std::mutex> one(nd->wait_mu);
+  long first;
   {
     std::unique_lock<std::mutex> lk(nd->mu);
     if (ticket >= nd->submitted) return FOTG_ERR_ARG;
-    if (ticket < nd->waited) return FOTG_OK;                    // tickets are waited for in order; an older one is done
+    // a job that has been waited for before (tickets are waited for in order): its OWN status, as long as the ring remembers it
+    if (ticket < nd->waited) return nd->jstatus_id[ticket % RING] == ticket ? nd->jstatus[ticket % RING] : FOTG_OK;
     nd->cv_issued.wait(lk, [&] { for (int k = 0; k < nd->ndev; ++k) if (nd->slot[k].issued <= ticket) return false; return true; });
+    first = nd->waited;
   }
-  // every job up to `ticket`, in order (their ring entries become free)
-  for (long id = nd->waited; id <= ticket; ++id) {
+  // every job up to `ticket`, in order (their ring entries become free).  A piece whose tile solver gave up a bounded wait is
+  // recomputed by the pipe's host wait where its frames are still in place (resident shards, the source slot of a scatter) and
+  // reported (FOTG_ERR_STALL for THIS job, on every wait for it) where they are not (pulled pieces: their staging buffers have been
+  // recycled).  The return value is the worst status of the jobs this call covers; each job keeps its own for later waits.
+  int worst = FOTG_OK;
+  for (long id = first; id <= ticket; ++id) {
+    int st = FOTG_OK;
     for (int k = 0; k < nd->ndev; ++k) {
       Slot &s = nd->slot[k];
-      if (s.status[id % RING] != FOTG_OK) { st = s.status[id % RING]; continue; }
+      if (s.status[id % RING] != FOTG_OK) { st = s.status[id % RING]; if (st == FOTG_ERR_HIP) nd->last_hip = s.hip_err[id % RING]; continue; }
       OnDevice od(s.device);
-      if (s.on_copy[id % RING]) { if (hipEventSynchronize(s.done[id % RING]) != hipSuccess) st = FOTG_ERR_HIP; }
-      else for (hipEvent_t e : s.piece_ev[id % RING]) if (hipEventSynchronize(e) != hipSuccess) st = FOTG_ERR_HIP;
+      if (s.on_copy[id % RING] && hipEventSynchronize(s.done[id % RING]) != hipSuccess) { st = FOTG_ERR_HIP; nd->last_hip = (int)hipGetLastError(); }
+      for (long t : s.piece_tk[id % RING]) {
+        const int sp = fotg_pipe_wait(s.pipe, t, nullptr, s.on_copy[id % RING] ? 2 : 1);
+        if (sp == FOTG_ERR_HIP) nd->last_hip = fotg_last_hip_error();
+        if (sp != FOTG_OK && st == FOTG_OK) st = sp;
+      }
     }
-  }
-  // a timed-out inter-workgroup wait anywhere on the node since the last wait: the flows of the jobs waited for here are suspect
-  for (int k = 0; k < nd->ndev; ++k)
-    for (int q = 0; q < nd->depth; ++q) {
-      fotg_ctx *c = nullptr;
-      if (fotg_pipe_context(nd->slot[k].pipe, q, &c) == FOTG_OK && fotg_ctx_counter(c, "take_stall") == 1 && st == FOTG_OK) st = FOTG_ERR_STALL;
+    {
+      std::lock_guard<std::mutex> lk(nd->mu);
+      nd->jstatus[id % RING] = st; nd->jstatus_id[id % RING] = id;
+      nd->waited = id + 1;
     }
-  {
-    std::lock_guard<std::mutex> lk(nd->mu);
-    if (ticket + 1 > nd->waited) nd->waited = ticket + 1;
+    if (st != FOTG_OK && worst == FOTG_OK) worst = st;
   }
-  return st;
+  return worst;
 }
+
+int fotg_node_last_hip_error(const fotg_node *nd) { return nd ? nd->last_hip : 0; }
 
 int fotg_node_sync(fotg_node *nd)
 {

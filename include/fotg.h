@@ -26,10 +26,13 @@ extern "C" {
 #define FOTG_ERR_BATCH        3   /* n > max_batch */
 #define FOTG_ERR_UNSUPPORTED  4   /* valid in the reference but not implemented here */
 #define FOTG_ERR_STALL        5   /* a bounded wait between workgroups of the tile solver (levels of more than 96 rows) timed out (preempted or
-                                     starved producer): the flow this call produced is NOT valid.  Returned by the entry points that
-                                     synchronise with the host -- fotg_calc, fotg_pipe_wait(host_wait = 1), fotg_pipe_sync; callers of
-                                     the asynchronous entry points ask fotg_ctx_counter(ctx, "take_stall") after their own
-                                     synchronisation (it does not synchronise; read-and-clear).  Re-submit the batch. */
+                                     starved producer) and the batch could not be recomputed.  The entry points that synchronise with the
+                                     host and still have the call's inputs -- fotg_calc, fotg_pipe_wait(host_wait = 1), fotg_pipe_sync,
+                                     fotg_node_wait -- recompute a stalled batch on the solver path without such waits and SUCCEED (the
+                                     context's "stalls" counter counts them); they return this code only when that fails too, or for
+                                     batches whose inputs are gone (fotg_pipe_wait(host_wait = 2), pulled pieces of fotg_node_submit_scatter).
+                                     Callers of the asynchronous entry points ask fotg_ctx_counter(ctx, "take_stall") after their own
+                                     synchronisation (it does not synchronise; read-and-clear) and re-submit. */
 
 #define FOTG_SOR_LEXICOGRAPHIC 0  /* kroeger FDF1.0.1/solver.c:77-421 order (parity mode, default) */
 #define FOTG_SOR_REDBLACK      1  /* red-black ordering of the same 2x2 block update (src/kernels/flowUtil.cu:297-362 ordering) */
@@ -135,19 +138,27 @@ int fotg_pipe_submit(fotg_pipe *pipe, int n, const float *I0, const float *I1, c
 int fotg_pipe_submit_u8(fotg_pipe *pipe, int n, const unsigned char *I0, const unsigned char *I1, const float *initflow,
                         float *outflow, void *after_stream, long *ticket);
 /* host_wait = 0: `stream` (NULL = default stream) waits for batch `ticket` on the device, the call returns at once;
- * host_wait != 0: the calling thread waits */
+ * host_wait = 1: the calling thread waits; if the context of the batch has flagged a timed-out inter-workgroup wait, the batches of
+ *   that context that have not been verified yet are recomputed (from the arguments of their submits -- which the caller keeps in
+ *   place until a ticket has been waited for) and the call succeeds;
+ * host_wait = 2: the calling thread waits; a flagged batch is reported (FOTG_ERR_STALL, on every wait for that ticket) instead of
+ *   recomputed -- for callers whose frames are not in place any more.
+ * Per-ticket state is kept for the last 4 * depth submissions.  May be called from another thread than the one that submits. */
 int fotg_pipe_wait(fotg_pipe *pipe, long ticket, void *stream, int host_wait);
 /* the calling thread waits for everything submitted so far */
 int fotg_pipe_sync(fotg_pipe *pipe);
-/* the completion event (a hipEvent_t) of batch `ticket`, for waiting from another thread or on several pipes at once without
- * touching the pipe: valid for the next 4 * depth submissions (afterwards it belongs to a later batch of the same slot) */
+/* the completion event (a hipEvent_t) of batch `ticket` (FOTG_ERR_ARG for a ticket that has not been submitted), for waiting on
+ * several pipes at once: valid for the next 4 * depth submissions (afterwards it belongs to a later batch of the same slot).  Note
+ * the head-of-line effect of that: with more than 4 * depth newer submissions outstanding, a wait for an old ticket waits for a
+ * later batch of its slot (a latency cost, never a correctness one). */
 int fotg_pipe_ticket_event(fotg_pipe *pipe, long ticket, void **event);
 /* the engine context of a slot (geometry queries, taps, counters) */
 int fotg_pipe_context(fotg_pipe *pipe, int slot, fotg_ctx **ctx);
 
 /* ---- one process, several GPUs (no reference equivalent: src/run_dense.cpp:277-289 drives one device) ------------
- * Frame pairs are independent, so a batch of n pairs is cut into contiguous shards -- pair k goes to slot k * ndev / n
- * (fotg_node_shard: sizes differ by at most one) -- and every slot runs its shard through a pipe of its own (above) on its device,
+ * Frame pairs are independent, so a batch of n pairs is cut into contiguous shards -- slot d gets the pairs [begin, begin + count)
+ * with count = n / ndev (+ 1 for the first n % ndev slots) and begin = d * (n / ndev) + min(d, n % ndev); ALWAYS take them from
+ * fotg_node_shard -- and every slot runs its shard through a pipe of its own (above) on its device,
  * issued by a host thread of its own; there is no exchange between the GPUs on the data path.  `devices` may name a device more
  * than once (two slots on one GPU).  max_batch = pairs per pipe submission on ONE device (a shard larger than that runs as
  * consecutive pieces on consecutive pipe slots), depth = batches in flight per device.  Up to 16 submitted jobs may be waiting to
@@ -167,8 +178,14 @@ int fotg_node_submit_u8(fotg_node *node, int n, const unsigned char *const *I0, 
  * other slot pulls its shard over xGMI in chunks of `chunk` <= max_batch pairs (hipMemcpyPeerAsync into depth + 1 staging buffers
  * on a copy stream of its own), computes chunk t while chunk t + 1 travels, and writes its flows back into `outflow`. */
 int fotg_node_submit_scatter(fotg_node *node, int n, const float *I0, const float *I1, float *outflow, int chunk, long *ticket);
-/* the calling thread waits for job `ticket` (and every job before it) on all devices; FOTG_ERR_STALL as for fotg_pipe_wait */
+/* The calling thread waits for job `ticket` and every job before it on all devices.  A piece whose tile solver gave up a bounded
+ * wait is recomputed where its frames are still in place (resident shards, the source slot of a scatter: the call then succeeds);
+ * pulled pieces of a scatter cannot be (their staging buffers have been recycled): FOTG_ERR_STALL, re-submit the job.  Returns the
+ * worst status of the jobs this call covers; every job keeps its own status for later (repeated, out-of-order) waits for it, for
+ * the next 16 jobs.  fotg_node_last_hip_error: the HIP error behind the last FOTG_ERR_HIP a wait returned (it was raised on a worker
+ * thread, where fotg_last_hip_error() of the waiting thread does not see it). */
 int fotg_node_wait(fotg_node *node, long ticket);
+int fotg_node_last_hip_error(const fotg_node *node);
 int fotg_node_sync(fotg_node *node);
 int fotg_node_info(const fotg_node *node, int *ndev, int *out_w, int *out_h, int *flow_channels);
 int fotg_node_pipe(fotg_node *node, int slot, fotg_pipe **pipe);

@@ -264,8 +264,10 @@ def test_bench_gpus_2_end_to_end_on_one_gpu():
     assert [p["rank"] for p in d["rank_placement"]] == [0, 1]
 
 
-def test_node_reports_a_stalled_wait(monkeypatch):
-    """a timed-out inter-workgroup wait in any context of any slot surfaces at fotg_node_wait as FOTG_ERR_STALL, once"""
+def test_node_heals_or_reports_a_stalled_wait_per_job(monkeypatch):
+    """several jobs in flight and a timed-out inter-workgroup wait in one context: fotg_node_wait recomputes the pieces whose frames
+    are in place (resident shards) and succeeds; every job keeps its OWN status for repeated / out-of-order waits; pulled pieces of a
+    scatter (staging buffers recycled) are reported as FOTG_ERR_STALL for exactly that job"""
     import ctypes as C
     import torch
     from flowonthego_amd.node import FlowNode
@@ -280,11 +282,28 @@ def test_node_reports_a_stalled_wait(monkeypatch):
     assert torch.equal(torch.cat(o), want)
     pipe, ctx = C.c_void_p(), C.c_void_p()
     assert L.fotg_node_pipe(node._h, 1, pipe) == 0 and L.fotg_pipe_context(pipe, 0, ctx) == 0
+    # three resident jobs in flight, a stall flagged on slot 1 / context 0 while they run
+    jobs = [node.submit(4, I0, I1) for _ in range(3)]
     assert L.fotg_ctx_counter(ctx, b"inject_stall") == 0
-    t, o = node.submit(4, I0, I1)
-    with pytest.raises(F.FotgError):
-        node.wait(t)                                               # FOTG_ERR_STALL
-    t, o = node.submit(4, I0, I1)
-    node.wait(t)                                                   # reported once; the node is usable again
-    assert torch.equal(torch.cat(o), want)
+    for t, o in jobs:
+        node.wait(t)                                               # healed: no error
+        assert torch.equal(torch.cat(o), want)
+    for t, o in jobs:
+        node.wait(t)                                               # repeated waits: each job's own (good) status
+    assert L.fotg_ctx_counter(ctx, b"stalls") == 1
+    # scatter: the pulled pieces of slot 1 cannot be recomputed -- that job, and only that job, reports the stall
+    o0 = torch.empty_like(want); o1 = torch.empty_like(want); o2 = torch.empty_like(want)
+    torch.cuda.synchronize()
+    t0, _ = node.submit_scatter(G0, G1, o0, chunk=1)
+    node.wait(t0)
+    assert torch.equal(o0, want)
+    t1, _ = node.submit_scatter(G0, G1, o1, chunk=1)
+    torch.cuda.synchronize()                                       # (job 1 has run; its tickets are unverified)
+    assert L.fotg_ctx_counter(ctx, b"inject_stall") == 0
+    assert L.fotg_node_wait(node._h, t1) == 5                      # FOTG_ERR_STALL
+    t2, _ = node.submit_scatter(G0, G1, o2, chunk=1)
+    node.wait(t2)                                                  # the next job is not blamed
+    assert torch.equal(o2, want)
+    assert L.fotg_node_wait(node._h, t1) == 5 and L.fotg_node_wait(node._h, t0) == 0 and L.fotg_node_wait(node._h, t2) == 0
+    assert L.fotg_node_last_hip_error(node._h) == 0
     node.close()
