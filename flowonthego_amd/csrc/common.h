@@ -65,6 +65,18 @@ __device__ __forceinline__ void permlane16_swap(float &a, float &b)
   // swaps rows 1, 3 of a with rows 0, 2 of b
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
+// The same idea for a launch whose image dimension is not a multiple of 8 (a single 4K pair): workgroups go to the XCDs round
+// robin by linear id, so NEIGHBOURING work items -- which read overlapping data (the covering patches of neighbouring pixels)
+// -- sit on eight different XCDs and each XCD's L2 fetches that data for itself (measured: densify_kernel<12,1> at 4K level 2
+// fetched 8x its inputs).  Deal every XCD one CONTIGUOUS eighth of the x range instead.  The launch rounds gridDim.x up to a
+// multiple of 8; returns -1 for the surplus workgroups.
+__device__ __forceinline__ int xcd_banded_x(int nwork)
+{
+  const int per = ((int)gridDim.x + 7) >> 3;             // work items per XCD (gridDim.x is a multiple of 8)
+  const int x = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  return ((int)blockIdx.x >> 3) < per && x < nwork ? x : -1;
+}
+
 __device__ __forceinline__ float row_allsum(float v)
 {
 #define FOTG_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, false))

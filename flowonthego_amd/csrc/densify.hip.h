@@ -67,9 +67,12 @@ __device__ __forceinline__ void gather_own(const float *__restrict__ p_iter, con
 
 template <int PS, int NOC>
 __global__ __launch_bounds__(256) void densify_kernel(const float *__restrict__ p_iter, const float *__restrict__ pweight,
-                                                      float *__restrict__ flowout, long flow_stride, LevelGeom g, int nch)
+                                                      float *__restrict__ flowout, long flow_stride, LevelGeom g, int nch, int nwg)
 {
-  const WgId wg = xcd_local_wg();
+  // batches: all of a pair on one XCD; otherwise (nwg > 0: the launch has rounded gridDim.x up to a multiple of 8) every XCD a
+  // contiguous band of rows, so that a patch is fetched by one L2 (two at a band boundary) instead of by all eight
+  WgId wg = xcd_local_wg();
+  if (nwg > 0) { wg.x = xcd_banded_x(nwg); if (wg.x < 0) return; }
   const int idx = wg.x * blockDim.x + threadIdx.x;
   if (idx >= g.w * g.h) return;
   const int pair = wg.y;

@@ -707,14 +707,17 @@ static int aggregate_impl(fotg_ctx *c, int l, int n, const float *p_iter, const 
     return FOTG_OK;
   }
   dim3 grid((g.w * g.h + 255) / 256, n), block(256);
-#define DF(PS_, NOC_) densify_kernel<PS_, NOC_><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch)
+  // (n not a multiple of 8: XCD-banded placement, see xcd_banded_x; only worth it for launches that span the chip)
+  int nwg = 0;
+  if ((n & 7) != 0 && grid.x >= 64) { nwg = (int)grid.x; grid.x = (grid.x + 7) & ~7u; }
+#define DF(PS_, NOC_) densify_kernel<PS_, NOC_><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch, nwg)
   if (c->ps == 4) { if (c->noc == 1) DF(4, 1); else DF(4, 3); }
   else if (c->ps == 16) { if (c->noc == 1) DF(16, 1); else DF(16, 3); }
 #undef DF
-  else if (c->ps == 8 && c->noc == 1) densify_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
-  else if (c->ps == 8) densify_kernel<8, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
-  else if (c->noc == 1) densify_kernel<12, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
-  else densify_kernel<12, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch);
+  else if (c->ps == 8 && c->noc == 1) densify_kernel<8, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch, nwg);
+  else if (c->ps == 8) densify_kernel<8, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch, nwg);
+  else if (c->noc == 1) densify_kernel<12, 1><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch, nwg);
+  else densify_kernel<12, 3><<<grid, block, 0, s>>>(p_iter, pweight, flowout, fs, g, nch, nwg);
   LAUNCHCHK();
   return FOTG_OK;
 }
