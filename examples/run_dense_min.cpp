@@ -12,6 +12,7 @@
 #include <vector>
 #include <string.h>
 #include "fotg/oflow.h"
+#include "fotg/flowio.h"
 
 static std::vector<float> read_raw(const char *path, size_t n)
 {
@@ -20,29 +21,6 @@ static std::vector<float> read_raw(const char *path, size_t n)
   if (!f || fread(v.data(), sizeof(float), n, f) != n) { fprintf(stderr, "cannot read %zu floats from %s\n", n, path); exit(1); }
   fclose(f);
   return v;
-}
-
-// SaveFlowFile (src/run_dense.cpp:26-67): "PIEH", width, height, then (u,v) float32 row-major
-static void save_flo(const char *path, const float *uv, int w, int h)
-{
-  FILE *f = fopen(path, "wb");
-  if (!f) { fprintf(stderr, "cannot write %s\n", path); exit(1); }
-  fprintf(f, "PIEH");
-  fwrite(&w, sizeof(int), 1, f);
-  fwrite(&h, sizeof(int), 1, f);
-  fwrite(uv, sizeof(float), (size_t)2 * w * h, f);
-  fclose(f);
-}
-
-// SavePFMFile (kroeger/run_dense.cpp:60-81): "Pf", width height, scale -1 (little endian), rows bottom-up, values negated
-static void save_pfm(const char *path, const float *d, int w, int h)
-{
-  FILE *f = fopen(path, "wb");
-  if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(1); }
-  fprintf(f, "Pf\n%d %d\n%f\n", w, h, -1.0f);
-  for (int y = h - 1; y >= 0; --y)
-    for (int x = 0; x < w; ++x) { const float v = -d[(size_t)y * w + x]; fwrite(&v, sizeof(float), 1, f); }
-  fclose(f);
 }
 
 int main(int argc, char **argv)
@@ -85,8 +63,8 @@ int main(int argc, char **argv)
   OFC::fotgCheck(fotg_upsample_crop(ofc.handle(), 1, dflow, dfull, nullptr), "fotg_upsample_crop");
   std::vector<float> full((size_t)nch * W * H);
   hipMemcpy(full.data(), dfull, full.size() * 4, hipMemcpyDeviceToHost);
-  if (depth) save_pfm(argv[6], full.data(), W, H);
-  else save_flo(argv[6], full.data(), W, H);
+  // SavePFMFile / SaveFlowFile of the reference (kroeger/run_dense.cpp:16-81), include/fotg/flowio.h
+  if (!(depth ? OFC::SavePFMFile(full.data(), W, H, argv[6]) : OFC::SaveFlowFile(full.data(), W, H, argv[6]))) { fprintf(stderr, "cannot write %s\n", argv[6]); return 1; }
   printf("%s: %dx%d %s written (finest scale %dx%d, op-point %d)\n", argv[6], W, H, depth ? "disparity" : "flow", ow, oh, oppt);
   hipFree(d0); hipFree(d1); hipFree(dflow); hipFree(dfull);
   return 0;
