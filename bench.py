@@ -57,11 +57,12 @@ sys.path.insert(0, ROOT)
 W, H, OP_POINT = 1920, 1080, 2
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak
-TRAFFIC_FILE = next((f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+TRAFFIC_FILE = next((f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
                      if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f))), "r02_pmc_traffic.json")
-TRAFFIC_NOTE = ("HBM bytes per launch from profiles/%s (separate rocprofv3 --pmc passes of this command; bytes = 2 x FETCH_SIZE + WRITE_SIZE: the "
-                "x 2 is the guide's gfx950 correction, established for 16-byte-per-lane streaming reads (pyr_base_kernel) -- kernels that read "
-                "with dword loads (lk, densify, vr_data) may be OVERSTATED by up to 2x on the read side) -- NOT measured in this run" % TRAFFIC_FILE)
+TRAFFIC_NOTE = ("L2-MISS bytes per launch (requests that left an XCD's L2: Infinity-Cache hits are INCLUDED, so this is an upper bound of the HBM "
+                "traffic) from profiles/%s: separate rocprofv3 --pmc passes of this command, bytes = 2 x FETCH_SIZE + WRITE_SIZE -- the x 2 is the guide's "
+                "gfx950 correction, established for 16-byte-per-lane streaming reads (pyr_base_kernel); kernels that read with dword loads (lk, densify, "
+                "vr_data) may be OVERSTATED by up to 2x on the read side.  NOT measured in this run" % TRAFFIC_FILE)
 
 
 def synth_batch(n, seed, device):
@@ -153,7 +154,7 @@ def roofline(ofc, I0, I1, lib, stream_ptr, batch):
         pass
     gbs = alg / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,1,4,true> (frames -> pyramid level 4, both frames of the batch in one launch)",
-            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_semantics": "L2-miss bytes (Infinity-Cache hits included)",
             "traffic_source": TRAFFIC_NOTE, "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms,
             "measured": "one launch at a time on an otherwise idle GPU; with %s batches in flight the same kernel stretches (profiles/)" % "several"}
 
@@ -184,7 +185,7 @@ def roofline_dominant(ofc, lib, stream_ptr, batch, stage_ms):
     return {"bound": "hbm", "bound_note": "nearest roof the contract names; the kernel is latency-bound (bound_by) and its data is L2 resident",
             "kernel": "fotg::vr_sor_stream_kernel<72,70,4,32> (one sor_coupled call = 3 lexicographic sweeps of the %dx%d level, "
                       "one workgroup per pair; %d launches per step)" % (lw, lh, inner),
-            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_NOTE,
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_semantics": "L2-miss bytes (Infinity-Cache hits included)", "traffic_source": TRAFFIC_NOTE,
             "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_per_step": inner,
             "share_of_step": inner * ms / sum(stage_ms.values()),
             "bound_by": "dependency-chain latency: %d anti-diagonal steps in lock step (~%.0f ns each), one workgroup = one CU per pair; "
@@ -212,7 +213,7 @@ def roofline_fused_level(ofc, batch, stage_ms, lvl):
     inner = lvl + 1
     return {"bound": "hbm", "bound_note": "nearest roof the contract names; the kernel is bound by the solver's dependency chain and the VALU of ONE CU per pair",
             "kernel": "fotg::vr_inner_fused_kernel<1,8,32,true,true,%d> (level %d, %dx%d: set-up + %d x {data term, 3 sweeps} + w+d in one launch, one workgroup per pair)" % (1024 if lw * lh > 1024 else 512, lvl, lw, lh, inner),
-            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_NOTE,
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_semantics": "L2-miss bytes (Infinity-Cache hits included)", "traffic_source": TRAFFIC_NOTE,
             "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_per_step": 1, "share_of_step": ms / sum(stage_ms.values())}
 
 
@@ -313,19 +314,19 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=
         inner = lvl + 1
         traffic4k, src4k = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_4k_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r05_4k_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_4k_pmc_traffic.json")) else "r04_4k_pmc_traffic.json")) as f:
                 tk = json.load(f)["kernels"]
             cand = [v["hbm_bytes_per_launch_corrected"] for k, v in tk.items() if "vr_sor_tile_kernel" in k]
             if cand:
                 traffic4k = int(max(cand))                       # (the largest tile launch = the finest level)
-                src4k = ("HBM bytes per launch from profiles/r04_4k_pmc_traffic.json (separate rocprofv3 --pmc passes of tools/time_4k_op4.py; "
-                         "bytes = 2 x FETCH_SIZE + WRITE_SIZE) -- NOT measured in this run")
+                src4k = ("L2-miss bytes per launch (Infinity-Cache hits included) from profiles/r0x_4k_pmc_traffic.json (separate rocprofv3 --pmc passes of "
+                         "tools/time_4k_op4.py; bytes = 2 x FETCH_SIZE + WRITE_SIZE) -- NOT measured in this run")
         except Exception:
             pass
         res["rooflines"].append({"bound": "hbm", "bound_note": "nearest roof the contract names; the kernel is a pipeline of dependency chains (bound_by)",
                                  "kernel": "fotg::vr_sor_tile_kernel<8> (one sor_coupled call = %d lexicographic sweeps of the %dx%d level as tiles of 64 rows "
                                            "x one sweep on %d workgroups; %d launches per pair at this level)" % (op.var_ref_iter, lw, lh, -(-lh // 64) * op.var_ref_iter, inner),
-                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic4k, "traffic_source": src4k,
+                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic4k, "traffic_semantics": "L2-miss bytes (Infinity-Cache hits included)", "traffic_source": src4k,
                                  "algorithmic_bytes_per_launch": alg, "ms_per_launch": mss, "launches_per_pair": inner,
                                  "share_of_pair": sum(v for k, v in st.items() if k.startswith("varref[")) / sum(st.values()),
                                  "bound_by": "%d anti-diagonal steps of one wave per tile (~%.0f ns each) + the pipeline lag between tiles" %

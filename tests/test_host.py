@@ -239,3 +239,25 @@ def test_bench_gpus_flag_cannot_print_a_line_for_another_n():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and '"metric"' not in r.stdout
+
+
+def test_cpp_flow_writers_match_the_python_ones(tmp_path):
+    """include/fotg/flowio.h: OFC::SaveFlowFile / OFC::SavePFMFile (kroeger/run_dense.cpp:16-81) write the bytes flowonthego_amd.flo
+    writes (whose .flo layout is pinned against the reference's golden file in tests/test_oracle.py)"""
+    import subprocess
+    import numpy as np
+    from flowonthego_amd import flo
+    src = tmp_path / "w.cpp"
+    src.write_text('#include "fotg/flowio.h"\n#include <vector>\nint main(int c, char **v) { const int w = 7, h = 5; std::vector<float> uv(2 * w * h), d(w * h);\n'
+                   'for (int i = 0; i < 2 * w * h; ++i) uv[i] = 0.25f * i - 3.0f; for (int i = 0; i < w * h; ++i) d[i] = -0.5f * i;\n'
+                   'return OFC::SaveFlowFile(uv.data(), w, h, v[1]) && OFC::SavePFMFile(d.data(), w, h, v[2]) && !OFC::SaveFlowFile(uv.data(), w, h, "/nonexistent/x.flo") ? 0 : 1; }\n')
+    exe = tmp_path / "w"
+    subprocess.check_call(["g++", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    subprocess.check_call([str(exe), str(tmp_path / "a.flo"), str(tmp_path / "a.pfm")])
+    uv = (0.25 * np.arange(70, dtype=np.float32) - 3.0).astype(np.float32).reshape(5, 7, 2)
+    d = (-0.5 * np.arange(35, dtype=np.float32)).reshape(5, 7)
+    flo.write_flo(str(tmp_path / "b.flo"), uv)
+    flo.write_pfm(str(tmp_path / "b.pfm"), d)
+    assert (tmp_path / "a.flo").read_bytes() == (tmp_path / "b.flo").read_bytes()
+    assert (tmp_path / "a.pfm").read_bytes() == (tmp_path / "b.pfm").read_bytes()
+    assert np.array_equal(flo.read_flo(str(tmp_path / "a.flo")), uv) and np.array_equal(flo.read_pfm(str(tmp_path / "a.pfm")), d)
