@@ -65,6 +65,7 @@ struct FotgTune {
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
   int vr_first_data; // FOTG_VR_FIRST_DATA: 0 = the first inner iteration's data term in a launch of its own (not in the set-up launch)
   int pyr_split;    // FOTG_PYR_SPLIT: launches the base pyramid kernel of a batch is cut into (1 = one launch)
+  int pyr_persist;  // FOTG_PYR_PERSIST: 0 = one workgroup per tile group; k > 0 = persistent launch of about k workgroups per CU
   int vr_fused_nt;  // FOTG_VR_FUSED_NT: threads per workgroup of the fused per-level kernel on gray levels of 1025..2048 pixels (512 / 1024)
   int lk_shw;       // FOTG_LK_SHW: shared LDS window of a wave's four patches: -1 automatic (RGB patches of 8 x 8 and more), 0 off, 1 on; 2 / 3 with FOTG_TEST_TAPS: on + some / all rows on the global-memory path
   int lk_lpp;       // FOTG_LK_LPP: lanes per patch of the LK kernel: 0 automatic, 8, 16
@@ -247,6 +248,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_first_data = env_int("FOTG_VR_FIRST_DATA", 1);
   c->tune.vr_fused_nt = env_int("FOTG_VR_FUSED_NT", 1024);
   c->tune.pyr_split = env_int("FOTG_PYR_SPLIT", 1);
+  c->tune.pyr_persist = env_int("FOTG_PYR_PERSIST", 0);
   c->tune.test_taps = env_int("FOTG_TEST_TAPS", 0);
   c->tune.lk_shw = env_int("FOTG_LK_SHW", -1);
   c->tune.lk_lpp = env_int("FOTG_LK_LPP", 0);
@@ -405,9 +407,16 @@ static int pyramid_impl(fotg_ctx *c, int n, const T *I0, const T *I1, hipStream_
   // fast path: no horizontal padding, rows and frames aligned for the wide loads (16 B for f32, 4 B for u8)
   const uintptr_t amask = sizeof(T) == 4 ? 15 : 3;
   const int fast = (c->padw == 0) && ((c->w_org * SRCC) % 4 == 0) && (((uintptr_t)A & amask) == 0) && (!B || ((uintptr_t)B & amask) == 0) && ((fstride % 4) == 0);
-  dim3 grid((tiles + 3) / 4, nimg), block(256);
-#define BASE(LV) do { if (fast) pyr_base_kernel<T, NOC, LV, true, SRCC><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, coef0, coef2); \
-    else pyr_base_kernel<T, NOC, LV, false, SRCC><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, coef0, coef2); } while (0)
+  const int groups = (tiles + 3) / 4;
+  dim3 grid(groups, nimg), block(256);
+  // FOTG_PYR_PERSIST = k > 0 (pipes: FOTG_PIPE_PYR_PERSIST): a persistent launch of about k workgroups per CU (pyr_base_kernel)
+  if (c->tune.pyr_persist > 0 && B) {
+    const int total = c->tune.pyr_persist >= 100 ? c->tune.pyr_persist : 256 * c->tune.pyr_persist;       // (>= 100: the total number of workgroups)
+    const int per_img = (total + nimg - 1) / nimg;
+    if (per_img >= 1 && per_img < groups) grid.x = per_img;
+  }
+#define BASE(LV) do { if (fast) pyr_base_kernel<T, NOC, LV, true, SRCC><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, coef0, coef2, groups); \
+    else pyr_base_kernel<T, NOC, LV, false, SRCC><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, coef0, coef2, groups); } while (0)
   if (stages & 1) {
     // FOTG_PYR_SPLIT > 1: the batch's images in that many launches, one after the other.  The launch is the path's only HBM-bound
     // kernel and fills every wave slot of the chip for its whole duration; with several batches in flight the kernels of the
@@ -1440,6 +1449,7 @@ int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int
     // several batches in flight: the base pyramid launch of a batch in up to 16 parts (pyramid_impl; measured 170 -> 181 k pairs/s
     // at batch 64 with four in flight, at the price of ~5 % on a batch that runs alone -- which is why only pipes do it)
     if (depth > 1) q->ctx[k]->tune.pyr_split = env_int("FOTG_PIPE_PYR_SPLIT", 16);
+    if (depth > 1) q->ctx[k]->tune.pyr_persist = env_int("FOTG_PIPE_PYR_PERSIST", 0);
   }
   *out = q;
   return FOTG_OK;

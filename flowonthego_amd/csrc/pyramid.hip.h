@@ -18,13 +18,14 @@ namespace fotg {
 // value -- what cv::imread(.., IMREAD_GRAYSCALE) hands kroeger/run_dense.cpp:199-209 for a colour file: OpenCV's fixed-point
 // BGR2GRAY, (1868 B + 9617 G + 4899 R + 8192) >> 14, here on load (integer arithmetic: exact by construction).  coef0 / coef2 are
 // the weights of the first and third byte of a pixel (BGR order: 1868, 4899; RGB order: 4899, 1868).
-template <typename T, int NOC, int LV, bool FAST, int SRCC = NOC>
-__global__ __launch_bounds__(256) void pyr_base_kernel(
+// one workgroup's four tiles (a wave = 256 source pixels x 2^LV rows -> one output row segment): wgx = tile group, wgy = image
+template <typename T, int NOC, int LV, bool FAST, int SRCC>
+__device__ __forceinline__ void pyr_base_tiles(
     const T *__restrict__ frames0, const T *__restrict__ frames1, int n_per_src, long frame_stride,  // 2 x n frames, h_org x w_org x SRCC
     int w_org, int h_org, int left, int top,               // padding offsets (floor(pad/2))
     int Wp, int Hp,                                        // padded frame size
     float *__restrict__ dst0, float *__restrict__ dst1, long dst_stride, int tw, int ps,  // level LV padded buffers
-    int coef0 = 0, int coef2 = 0)
+    int coef0, int coef2, const int wgx, const int wgy)
     // FAST: 16-B loads legal (no horizontal pad, 16-B aligned rows)
 {
   constexpr bool C2G = SRCC != NOC;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int strips = (Wp + 255) >> 8;
-  const WgId wg = xcd_local_wg();            // image k (pair k % n) on XCD k % 8, where pyr_finish and the per-pair kernels run
+  const WgId wg = {wgx, wgy};
   const int tile = wg.x * 4 + wave;
   const int oh = Hp >> LV;
   if (tile >= strips * oh) return;
@@ -289,6 +290,30 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(
         for (int c = 0; c < NOC; ++c) out[((size_t)(oy + ps) * tw + (ox + ps)) * NOC + c] = cur[0][c];
       }
     }
+  }
+}
+
+// The kernel: grid (tile groups, images).  A launch with fewer tile groups than the level has (gridDim.x < groups) is PERSISTENT:
+// every workgroup walks the groups gridDim.x apart.  Several batches in flight use that to cap the pyramid's share of the chip's
+// wave slots: the plain launch fills every slot with 256-thread workgroups for its whole duration and hands freed slots to its
+// own pending workgroups one at a time, so a 1024-thread workgroup of another batch (the level solvers) never finds its sixteen
+// slots on one CU and waits for the launch to end; the HBM stream itself needs a fraction of the slots (sixteen 16-byte loads per
+// lane in flight).
+template <typename T, int NOC, int LV, bool FAST, int SRCC = NOC>
+__global__ __launch_bounds__(256) void pyr_base_kernel(
+    const T *__restrict__ frames0, const T *__restrict__ frames1, int n_per_src, long frame_stride,
+    int w_org, int h_org, int left, int top, int Wp, int Hp,
+    float *__restrict__ dst0, float *__restrict__ dst1, long dst_stride, int tw, int ps,
+    int coef0 = 0, int coef2 = 0, int groups = 0)
+{
+  const WgId wg = xcd_local_wg();            // image k (pair k % n) on XCD k % 8, where pyr_finish and the per-pair kernels run
+  if (groups <= (int)gridDim.x) {
+    pyr_base_tiles<T, NOC, LV, FAST, SRCC>(frames0, frames1, n_per_src, frame_stride, w_org, h_org, left, top, Wp, Hp, dst0, dst1, dst_stride, tw, ps, coef0, coef2, wg.x, wg.y);
+    return;
+  }
+  for (int x = wg.x; x < groups; x += (int)gridDim.x) {
+    pyr_base_tiles<T, NOC, LV, FAST, SRCC>(frames0, frames1, n_per_src, frame_stride, w_org, h_org, left, top, Wp, Hp, dst0, dst1, dst_stride, tw, ps, coef0, coef2, x, wg.y);
+    asm volatile("" ::: "memory");             // (the wave-private LDS slabs of one group's hand-over are not reordered with the next group's)
   }
 }
 
