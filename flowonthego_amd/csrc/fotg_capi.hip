@@ -812,7 +812,7 @@ static std::atomic<long> g_tile_launches{0};        // fotg_debug_counter("sor_t
 static int a_level(const fotg_ctx *c, const VrArgs &a) { for (int l = c->p.sc_l; l <= c->p.sc_f; ++l) if (c->vra[l].w == a.w && c->vra[l].h == a.h) return l; return c->p.sc_l; }
 static std::atomic<long> g_stream_launches{0};      // fotg_debug_counter("sor_stream"): tests assert the kernel really ran
 // streaming solver (vr_sor_stream_kernel): diagonals travel through LDS rings, two rows per lane.
-template <int RD, int RCW>
+template <int RD, int RCW, bool FMA = false>
 static bool launch_sor_stream_k(const VrArgs &b, int n, float omega, hipStream_t s)
 {
   constexpr int M = FOTG_SYNC_M, U = 32;
@@ -825,8 +825,8 @@ static bool launch_sor_stream_k(const VrArgs &b, int n, float omega, hipStream_t
   const int lds = RCN * GEO::CSLOT + RDN * GEO::DB + GEO::DB;
   if (lds > 160 * 1024) return false;
   static int lds_set[32] = {0};
-  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_sor_stream_kernel<RD, RCW, M, U>), lds, lds_set)) return false;
-  vr_sor_stream_kernel<RD, RCW, M, U><<<n, 1024, lds, s>>>(b, omega);
+  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_sor_stream_kernel<RD, RCW, M, U, FMA>), lds, lds_set)) return false;
+  vr_sor_stream_kernel<RD, RCW, M, U, FMA><<<n, 1024, lds, s>>>(b, omega);
   ++g_stream_launches;
   return true;
 }
@@ -836,6 +836,7 @@ static bool launch_sor_stream_k(const VrArgs &b, int n, float omega, hipStream_t
 static bool launch_sor_stream(const fotg_ctx *c, const VrArgs &b, int n, float omega, hipStream_t s)
 {
   if (!c->tune.vr_stream) return false;
+  if (c->p.fast_math) return launch_sor_stream_k<72, 70, true>(b, n, omega, s) || launch_sor_stream_k<100, 98, true>(b, n, omega, s);
   return launch_sor_stream_k<72, 70>(b, n, omega, s) || launch_sor_stream_k<100, 98>(b, n, omega, s);
 }
 
@@ -951,7 +952,8 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
       const int sw = sweeps - done < 4 ? sweeps - done : 4;
       // (the data-term launch in front of the call has cleared the words already when the caller arranged that: VrArgs::zsync)
       if (!(sync_zeroed && done == 0)) (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n) * sizeof(int), s);
-      vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sw, FOTG_TILE_THREADS, 0, s>>>(a, g, sw, omega);
+      if (c->p.fast_math) vr_sor_tile_kernel<FOTG_TILE_P, true><<<n * g.NB * sw, FOTG_TILE_THREADS, 0, s>>>(a, g, sw, omega);
+      else vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sw, FOTG_TILE_THREADS, 0, s>>>(a, g, sw, omega);
       ++g_tile_launches;
     }
     return;

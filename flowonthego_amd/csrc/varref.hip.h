@@ -902,7 +902,8 @@ __device__ __forceinline__ void glds16(const void *src, unsigned lds_dst_byte)
 // second row costs no prefetch registers, its top neighbour is the lane's own previous result, the two rows are
 // independent within a step (better issue than one dependent chain), and three solver waves have a SIMD each (the
 // loaders and the writer sit on the fourth).
-template <int RD, int RCW, int M, int U>
+// FMA: the cell update with fused multiply-adds (fotg_params::fast_math, the tolerance mode; see vr_sor_tile_kernel)
+template <int RD, int RCW, int M, int U, bool FMA = false>
 __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float omega)
 {
   using GEO = StreamGeom<RD, RCW>;
@@ -1019,6 +1020,17 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
       auto relax = [&](v2f own, float4 c0, float4 c1, float hl, v2f left, v2f top, v2f right, v2f bottom, float om) {
         const v2f a1 = {c0.x, c0.y}, bb = {c0.z, c0.w};
         const float a22 = c1.x, hr = c1.y, vb = c1.z, vt = c1.w;
+        if constexpr (FMA) {
+          const v2f vhr = {hr, hr}, vvt = {vt, vt}, vvb = {vb, vb}, vhl = {hl, hl}, vom = {om, om};
+          v2f sv = __builtin_elementwise_fma(vhr, right, bb);
+          sv = __builtin_elementwise_fma(vvt, top, sv);
+          sv = __builtin_elementwise_fma(vvb, bottom, sv);
+          const v2f B = __builtin_elementwise_fma(vhl, left, sv);
+          const v2f col0 = {c0.x, c0.y}, col1 = {c0.y, a22}, bx = {B.x, B.x}, by = {B.y, B.y};
+          v2f tt = __builtin_elementwise_fma(col0, bx, col1 * by);
+          tt = tt - own;
+          return __builtin_elementwise_fma(vom, tt, own);
+        }
         v2f sv = hr * right;
         // vt * top with vt read in place (the high half of the register pair the cell was loaded into: the compiler copies it to
         // a pair of its own first)

@@ -1200,6 +1200,7 @@ def test_stalled_wait_heals_at_the_host_sync_points(monkeypatch):
     outs = [pipe.new_outflow(1) for _ in range(4)]
     torch.cuda.synchronize()
     ts = [pipe.submit(A[None], B[None], None, outs[k])[0] for k in range(4)]       # tickets 0, 2 on slot 0; 1, 3 on slot 1
+    torch.cuda.synchronize()                                              # (device-wide: the four batches have run)
     L.fotg_ctx_counter(pipe.context(0), b"inject_stall")
     for o in outs:
         o.zero_()                                                         # (whatever the first pass wrote: the recomputation must rewrite it)
