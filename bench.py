@@ -558,6 +558,8 @@ def main():
     ap.add_argument("--scatter-gather", action="store_true", help="multi-rank runs: also time rank 0 scattering the frames of all "
                     "ranks over RCCL and gathering the flows back (SURVEY 8e); reported beside `value`, never part of it")
     ap.add_argument("--sor-mode", type=int, default=0, help="0 lexicographic (reference order, parity mode), 1 red-black")
+    ap.add_argument("--fast-math", action="store_true", help="run the timed loop in the tolerance mode of the patch loop / solvers (fotg_params::fast_math; "
+                    "the line says so in `metric`); default: the parity mode, with the tolerance mode reported beside it (`fast_math`)")
     a = ap.parse_args()
 
     if a.gpus < 1:
@@ -613,6 +615,7 @@ def main():
     from flowonthego_amd.oflow import OFClass
     lib = F.lib()                               # raises if libfotg.so is missing: no fallback
     op = F.operating_point(OP_POINT, W, 1, sor_mode=a.sor_mode)
+    op.fast_math = bool(a.fast_math)
     ofc = OFClass(op, F.img_params(width=W, height=H, padding=op.patch_size), max_batch=a.batch, device=local)
     I0, I1 = synth_batch(a.batch, 1234 + rank, dev)
     out = ofc.new_outflow(a.batch)
@@ -696,7 +699,7 @@ def main():
         td.all_gather(allr, mine)
         per_rank = [float(t.item()) for t in allr]
 
-    res = {"metric": "frame-pairs/sec @1080p DIS op-pt 2" + (" (%d batches of %d in flight)" % (D, a.batch) if pipe else ""), "value": value, "unit": "frame-pairs/s", "n_gpus": world,
+    res = {"metric": "frame-pairs/sec @1080p DIS op-pt 2" + (" (%d batches of %d in flight)" % (D, a.batch) if pipe else "") + (" [fast_math: tolerance mode]" if a.fast_math else ""), "value": value, "unit": "frame-pairs/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[2]: batch=%d synthetic 1920x1080 gray f32 pairs per GPU, DIS op-pt 2 "

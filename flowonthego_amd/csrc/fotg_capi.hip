@@ -69,6 +69,7 @@ struct FotgTune {
   int vr_fused_nt;  // FOTG_VR_FUSED_NT: threads per workgroup of the fused per-level kernel on gray levels of 1025..2048 pixels (512 / 1024)
   int lk_shw;       // FOTG_LK_SHW: shared LDS window of a wave's four patches: -1 automatic (RGB patches of 8 x 8 and more), 0 off, 1 on; 2 / 3 with FOTG_TEST_TAPS: on + some / all rows on the global-memory path
   int lk_lpp;       // FOTG_LK_LPP: lanes per patch of the LK kernel: 0 automatic, 8, 16
+  int lk_fast_r;    // FOTG_LK_FAST_R: fast_math, gray 8 x 8 / 12 x 12 patches: radius of the staged window (2), 0 = the whole reachable region
   int lk_lpp_min_waves;   // FOTG_LK_LPP_MIN_WAVES: automatic: eight lanes per patch from this many waves per launch on
   int test_taps;    // FOTG_TEST_TAPS: 1 = fotg_ctx_counter(ctx, "inject_stall") is live (tests of the FOTG_ERR_STALL reporting)
 };
@@ -253,6 +254,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.lk_shw = env_int("FOTG_LK_SHW", -1);
   c->tune.lk_lpp = env_int("FOTG_LK_LPP", 0);
   c->tune.lk_lpp_min_waves = env_int("FOTG_LK_LPP_MIN_WAVES", 2048);
+  c->tune.lk_fast_r = env_int("FOTG_LK_FAST_R", 2);
   if (hipHostMalloc((void **)&c->stall_host, 64, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void **)&c->stall_dev, c->stall_host, 0) != hipSuccess) { g_last_hip = (int)hipGetLastError(); fotg_destroy(c); return FOTG_ERR_HIP; }
   memset(c->stall_host, 0, 64);
@@ -623,7 +625,7 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   a.trace = gs.trace_host ? c->trace_dev[l] : nullptr;
   a.g = g;
   a.max_iter = c->p.max_iter; a.min_iter = c->p.min_iter; a.patnorm = c->p.patnorm;
-  a.shw_test = (c->tune.test_taps && c->tune.lk_shw >= 2) ? c->tune.lk_shw - 1 : 0;
+  a.shw_test = (c->tune.test_taps && c->tune.lk_shw >= 2) ? c->tune.lk_shw - 1 : 0;     // (fast_math: 2 = every evaluation reads the level image instead of the staged window)
   a.costfct = c->p.costfct; a.huber_bsq = c->p.normoutlier * c->p.normoutlier; a.huber_2bsq = a.huber_bsq * 2.0f;   // kroeger/oflow.cpp:106-107
   a.dp_thresh_sq = c->p.dp_thresh * c->p.dp_thresh;                 // kroeger/oflow.cpp:88
   a.dr_thresh = c->p.dr_thresh; a.res_thresh = c->p.res_thresh;
@@ -649,17 +651,19 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
   // fotg_params::fast_math: the tolerance-mode kernel (lk_fast.hip.h) for what every operating point runs -- L2 cost, optical
   // flow, min_iter == max_iter, res_thresh <= 0; anything else (and the per-iteration trace tap) stays on the exact kernel
   if (c->p.fast_math && !c->p.depth && c->p.costfct == 0 && c->p.min_iter == c->p.max_iter && !(c->p.res_thresh > 0.0f) && !gs.trace_host) {
-    const int lppf = ((c->ps == 8 || c->ps == 12) && c->noc == 1 && (c->tune.lk_lpp == 8 || (c->tune.lk_lpp == 0 && c->ps == 8 && waves8 >= c->tune.lk_lpp_min_waves))) ? 8 : 16;
-    const int ppwf = 64 / lppf;
-    dim3 gridf((g.nop + ppwf - 1) / ppwf, n);
-#define LKF(PS_, NOC_, LPP_) lk_fast_kernel<PS_, NOC_, LPP_><<<gridf, block, 0, s>>>(a)
+    // gray 8 x 8 / 12 x 12 patches stage a window of radius 2 around the start (FOTG_LK_FAST_R=0: the whole reachable region).
+    // Sixteen lanes per patch throughout: eight (3 x 6 / 2 x 4 blocks) and four (4 x 4 blocks at ps 8) were measured slower or
+    // equal at every launch size (docs/EXPERIMENTS.md, round 5).
+    const bool small = c->noc == 1 && (c->ps == 8 || c->ps == 12) && c->tune.lk_fast_r > 0;
+    dim3 gridf((g.nop + 3) / 4, n);
+#define LKF(PS_, NOC_, R_) lk_fast_kernel<PS_, NOC_, 16, R_><<<gridf, block, 0, s>>>(a)
     switch (c->ps * 10 + c->noc) {
-      case 41: LKF(4, 1, 16); break;   case 43: LKF(4, 3, 16); break;
-      case 81: if (lppf == 8) LKF(8, 1, 8); else LKF(8, 1, 16); break;
-      case 83: LKF(8, 3, 16); break;
-      case 121: if (lppf == 8) LKF(12, 1, 8); else LKF(12, 1, 16); break;
-      case 123: LKF(12, 3, 16); break;
-      case 161: LKF(16, 1, 16); break; default: LKF(16, 3, 16); break;
+      case 41: LKF(4, 1, 0); break;   case 43: LKF(4, 3, 0); break;
+      case 81: if (small) LKF(8, 1, 2); else LKF(8, 1, 0); break;
+      case 83: LKF(8, 3, 0); break;
+      case 121: if (small) LKF(12, 1, 2); else LKF(12, 1, 0); break;
+      case 123: LKF(12, 3, 0); break;
+      case 161: LKF(16, 1, 0); break; default: LKF(16, 3, 0); break;
     }
 #undef LKF
     LAUNCHCHK();

@@ -15,7 +15,7 @@
 //    res_thresh > 0, another cost function or depth mode run the exact kernel also with fast_math set.)
 //  * the 2x2 Cholesky solve (patch.cpp:184) becomes a multiplication with the inverse H^-1 = L^-T L^-1 computed once from the same
 //    factor, the constant term folded in: dp = H^-1 S + k, four fused multiply-adds, no division in the loop.
-//  * a lane owns a BH x BW BLOCK of the patch (3 x 3 at ps 12, 4 x 2 at ps 8 with eight lanes per patch) instead of every 16th
+//  * a lane owns a BH x BW BLOCK of the patch (3 x 3 at ps 12, 2 x 2 at ps 8: sixteen lanes per patch) instead of every 16th
 //    pixel: the block's bilinear taps are a (BH+1) x (BW+1) window of the staged I1 -- 16 LDS values for 9 pixels instead of 36,
 //    all at compile-time offsets from ONE per-lane address.
 //  * the window in LDS holds I1 - mean T: the constant does not change the projections (the centred gradients sum to zero) and
@@ -69,16 +69,23 @@ __device__ __forceinline__ void lkf_allsum2(float &a, float &b)
   }
 }
 
-constexpr int lkf_min_waves(int ps, int noc, int lpp)
+constexpr int lkf_win(int ps, int r) { return ps + 2 * (r > 0 ? r : ps / 2 + 1) + 2; }
+constexpr int lkf_min_waves(int ps, int noc, int lpp, int r)
 {
   // what the private windows leave room for in the CU's 160 KB of LDS (waves per SIMD)
-  const int bytes = (64 / lpp) * (2 * ps + 4) * (2 * ps + 4) * noc * 4;
+  const int bytes = (64 / lpp) * lkf_win(ps, r) * lkf_win(ps, r) * noc * 4;
   const int per_cu = 160 * 1024 / bytes;
   return per_cu >= 16 ? 4 : per_cu >= 12 ? 3 : per_cu >= 8 ? 2 : 1;
 }
 
-template <int PS, int NOC, int LPP>
-__global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kernel(LkArgs a)
+// R: radius of the staged window.  0: the whole reachable region (a patch is reset when it has moved more than ps/2, so every
+// evaluation is inside: (2ps+4)^2 values per patch).  R > 0: positions within R pixels of the start -- where patches started from
+// the coarser level's flow end up -- come out of a (ps + 2R + 2)^2 window (44 % of the LDS at ps 12 and R = 2: twice the patches
+// per wave at the same occupancy, and less to stage); an iteration in which any running patch of the wave is outside reads its
+// taps from the level image instead (same clamped coordinates, same values: the two paths are bit-identical, tested by forcing
+// the second one).
+template <int PS, int NOC, int LPP, int R = 0>
+__global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP, R)) void lk_fast_kernel(LkArgs a)
 {
   constexpr int PPW = 64 / LPP;                      // patches per wave
   constexpr int LC = LPP == 16 ? 4 : 2, LR = LPP / LC;   // lanes of a patch as LR x LC blocks: 16 = 4 x 4, 8 = 4 x 2, 4 = 2 x 2
@@ -87,7 +94,8 @@ __global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kerne
   constexpr int NE = BH * BW * NOC;
   constexpr int NV = PS * PS * NOC;
   constexpr int PAD = PS;
-  constexpr int WIN = 2 * PS + 4;                    // window edge (lk.hip.h)
+  constexpr int RR = R > 0 ? R : PS / 2 + 1;         // positions up to RR from the start are inside the window
+  constexpr int WIN = lkf_win(PS, R);                // window edge: ps + 2 RR + 2 (lk.hip.h: 2 ps + 4)
   constexpr int WROW = WIN * NOC;                    // floats per window row
   __shared__ float win_all[PPW * WIN * WIN * NOC];
   const int lane = threadIdx.x & 63, row = lane / LPP, j = lane % LPP;
@@ -165,15 +173,23 @@ __global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kerne
   float P0 = PIN0, P1 = PIN1, PTX = RX + P0, PTY = RY + P1;
   const float STX = PTX, STY = PTY;
   const bool START_OK = VALID && !(PTX < a.g.lb || PTY < a.g.lb || PTX > a.g.ubw || PTY > a.g.ubh);
-  const int WX0 = (int)floorf(STX) + PAD - PS - 1, WY0 = (int)floorf(STY) + PAD - PS - 1;
+  // window origin (padded coordinates): the leftmost tap of a position RR left of the start, floor(stx) - RR - ps/2
+  const float FSX = floorf(STX), FSY = floorf(STY);
+  const int WX0 = (int)FSX + PAD - RR - PS / 2, WY0 = (int)FSY + PAD - RR - PS / 2;
   if (START_OK) {
-    // the reachable window of I1 (lk.hip.h), minus the template mean
+    // the window of I1 minus the template mean: a lane takes columns j, j + LPP, .. of every row (clamped like the level's border)
     float *const wdst = win_all + row * (WIN * WIN * NOC);
-    for (int t = j; t < WIN * WIN; t += LPP) {
-      const int wy = t / WIN, wx = t - wy * WIN;
-      const size_t src = ((size_t)clampi(WY0 + wy, a.g.th) * tw + clampi(WX0 + wx, tw)) * NOC;
+    constexpr int NCOL = (WIN + LPP - 1) / LPP;
+    int cofs[NCOL];
 #pragma unroll
-      for (int c = 0; c < NOC; ++c) wdst[t * NOC + c] = I1[src + c] - MT;
+    for (int k = 0; k < NCOL; ++k) cofs[k] = clampi(WX0 + j + k * LPP, tw) * NOC;
+    for (int wy = 0; wy < WIN; ++wy) {
+      const float *rowp = I1 + (size_t)clampi(WY0 + wy, a.g.th) * tw * NOC;
+#pragma unroll
+      for (int k = 0; k < NCOL; ++k)
+        if (j + k * LPP < WIN)
+#pragma unroll
+          for (int c = 0; c < NOC; ++c) wdst[(wy * WIN + j + k * LPP) * NOC + c] = rowp[cofs[k] + c] - MT;
     }
   }
   asm volatile("" ::: "memory");      // (the window is filled by the lanes of the row and read by all of them; LDS accesses of a wave execute in order)
@@ -187,25 +203,24 @@ __global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kerne
   constexpr int RW = BW * NOC;                           // values per block row
   constexpr int NPR = RW / 2;                            // pairs per block row (+ one single value when RW is odd)
   typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));
-  auto sample = [&](float (&q)[NE]) {
-    const float r0 = __builtin_amdgcn_fractf(PTX), r1 = __builtin_amdgcn_fractf(PTY);      // x - floor(x) (:344-345) in one instruction
-    // ceil(x + 1e-5) keeps the reference's corner pair (:340-343); the window index is formed in floating point (exact: small integers)
-    const float cx = ceilf(PTX + .00001f), cy = ceilf(PTY + .00001f);
-    const float we0 = r0 * r1, we1 = __builtin_fmaf(-r0, r1, r1), we2 = __builtin_fmaf(-r0, r1, r0), we3 = (1.0f - r0) - we1;
-    int ib = (int)__builtin_fmaf(cy, (float)WROW, cx * (float)NOC) + laneoff;
-    asm volatile("" : "+v"(ib));                          // (one address register, the taps are immediates of the LDS reads)
-    const float *tp = win_all + ib;
+  // the four bilinear weights at (PTX, PTY) and the integer corner (ceil(x + 1e-5), ceil(y + 1e-5)) as floats
+  // (plain scalars, not a struct: a struct handed through the lambdas below ended up in private memory)
+#define FOTG_LKF_TAPS                                                                                                          \
+  const float r0 = __builtin_amdgcn_fractf(PTX), r1 = __builtin_amdgcn_fractf(PTY); /* x - floor(x) (:344-345) in one instruction */ \
+  /* ceil(x + 1e-5) keeps the reference's corner pair (:340-343); the window index is formed in floating point (exact) */     \
+  const float cx = ceilf(PTX + .00001f), cy = ceilf(PTY + .00001f);                                                           \
+  const float we0 = r0 * r1, we1 = __builtin_fmaf(-r0, r1, r1), we2 = __builtin_fmaf(-r0, r1, r0), we3 = (1.0f - r0) - we1
+  // the block's (BH+1) x (BW+1) window through a pair loader (values k, k+1 of window row dy) and a single-value loader, then the
+  // four-tap blend; one body for both sources, everything in registers (arrays local to this lambda: nothing goes to scratch)
+  auto sample_with = [&](float we0, float we1, float we2, float we3, auto ld2, auto ld1, float (&q)[NE]) {
     const lkf_v2f w0 = {we0, we0}, w1 = {we1, we1}, w2 = {we2, we2}, w3 = {we3, we3};
     lkf_v2f A[BH + 1][NPR > 0 ? NPR : 1], Cc[BH + 1][NPR > 0 ? NPR : 1];
     float sA[BH + 1], sC[BH + 1];
 #pragma unroll
     for (int dy = 0; dy <= BH; ++dy) {
 #pragma unroll
-      for (int m = 0; m < NPR; ++m) {
-        A[dy][m] = *reinterpret_cast<const v2u *>(tp + dy * WROW + 2 * m);
-        Cc[dy][m] = *reinterpret_cast<const v2u *>(tp + dy * WROW + 2 * m + NOC);
-      }
-      if constexpr (RW & 1) { sA[dy] = tp[dy * WROW + RW - 1]; sC[dy] = tp[dy * WROW + RW - 1 + NOC]; }
+      for (int m = 0; m < NPR; ++m) { A[dy][m] = ld2(dy, 2 * m); Cc[dy][m] = ld2(dy, 2 * m + NOC); }
+      if constexpr (RW & 1) { sA[dy] = ld1(dy, RW - 1); sC[dy] = ld1(dy, RW - 1 + NOC); }
     }
 #pragma unroll
     for (int dy = 0; dy < BH; ++dy) {
@@ -218,11 +233,26 @@ __global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kerne
         q[dy * RW + RW - 1] = __builtin_fmaf(we0, sC[dy + 1], __builtin_fmaf(we1, sA[dy + 1], __builtin_fmaf(we2, sC[dy], we3 * sA[dy])));
     }
   };
+  // from the staged window
+  auto sample = [&](float (&q)[NE]) {
+    FOTG_LKF_TAPS;
+    int ib = (int)__builtin_fmaf(cy, (float)WROW, cx * (float)NOC) + laneoff;
+    asm volatile("" : "+v"(ib));                          // (one address register, the taps are immediates of the LDS reads)
+    const float *tp = win_all + ib;
+    sample_with(we0, we1, we2, we3, [&](int dy, int k) -> lkf_v2f { return *reinterpret_cast<const v2u *>(tp + dy * WROW + k); },
+                [&](int dy, int k) { return tp[dy * WROW + k]; }, q);
+  };
+  // (R > 0, rare, wave-uniform) the same taps from the level image, clamped like the staged copy
+  auto sample_image = [&](float (&q)[NE]) {
+    FOTG_LKF_TAPS;
+    const int gx0 = (int)cx - 1 + PAD - PS / 2 + bx, gy0 = (int)cy - 1 + PAD - PS / 2 + by;
+    auto px = [&](int dy, int k) { return I1[((size_t)clampi(gy0 + dy, a.g.th) * tw + clampi(gx0 + k / NOC, tw)) * NOC + k % NOC] - MT; };
+    sample_with(we0, we1, we2, we3, [&](int dy, int k) -> lkf_v2f { return lkf_v2f{px(dy, k), px(dy, k + 1)}; }, px, q);
+  };
+#undef FOTG_LKF_TAPS
   // S = sum (Tx - mean Tx, Ty - mean Ty) q over the patch
   float S0 = 0.f, S1 = 0.f;
-  auto project = [&]() {
-    float q[NE];
-    sample(q);
+  auto accumulate = [&](const float (&q)[NE]) {
     lkf_v2f sa = {0.f, 0.f}, sb = {0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -234,13 +264,21 @@ __global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kerne
     S0 = sa.x; S1 = sa.y;
     lkf_allsum2<LPP>(S0, S1);
   };
+  // far: a running patch of this lane's row sits outside the staged window (R > 0 only; the whole wave then reads the level image:
+  // two complete code paths, so that nothing but the two sums is merged behind them)
+  const bool FORCE_IMAGE = R > 0 && a.shw_test == 2;       // test tap
+  auto project = [&](bool far) {
+    float q[NE];
+    if (R > 0 && __builtin_amdgcn_ballot_w64(far | FORCE_IMAGE) != 0) { sample_image(q); accumulate(q); }
+    else { sample(q); accumulate(q); }
+  };
 
   // The loop is free of divergent branches: every lane evaluates every iteration (a masked-out row costs the wave the same
   // instructions), the rows that are still running take the results; a row that never started or has been reset reads
   // whatever its position selects in LDS (out-of-range LDS reads return zeros) and drops it.
   bool ACT = START_OK && a.max_iter > 0;
   int CNT = 0;
-  project();                                             // OptimizeStart's first error image (:154)
+  project(false);                                        // OptimizeStart's first error image (:154): at the start position
   for (int it = 1; it <= a.max_iter; ++it) {
     if (__builtin_amdgcn_ballot_w64(ACT) == 0) break;
     const float x0 = __builtin_fmaf(IH00, S0, __builtin_fmaf(IH01, S1, K0));
@@ -251,12 +289,14 @@ __global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kerne
     // :199-208 and oracle definition D3 (a non-finite update resets the patch): the comparisons are false for NaN, so `keep`
     // is false for every non-finite position as well
     const bool keep = (__builtin_fmaf(ddx, ddx, ddy * ddy) <= a.outlier_sq) & (nPTX >= a.g.lb) & (nPTY >= a.g.lb) & (nPTX <= a.g.ubw) & (nPTY <= a.g.ubh);
+    // |position - start| <= R on both axes is inside the staged window (a reset patch is back at the start)
+    const bool far = R > 0 && keep && fmaxf(fabsf(ddx), fabsf(ddy)) > (float)R;
     P0 = ACT ? (keep ? nP0 : PIN0) : P0;
     P1 = ACT ? (keep ? nP1 : PIN1) : P1;
     CNT += ACT ? 1 : 0;
     ACT = ACT & keep & (it < a.max_iter);
     PTX = RX + P0; PTY = RY + P1;
-    if (it < a.max_iter) project();                      // (wave-uniform)
+    if (it < a.max_iter) project(ACT & far);             // (wave-uniform)
   }
 
   // ---- results: the residual at the final position = the patch weights of the densification (patchgrid.cpp:213-275)
@@ -265,7 +305,8 @@ __global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP)) void lk_fast_kerne
   for (int e = 0; e < NE; ++e) r[e] = 0.f;               // patches that never started: oracle definition D2
   if (START_OK) {
     float q[NE];
-    sample(q);
+    if (R > 0 && __builtin_amdgcn_ballot_w64((fmaxf(fabsf(PIN0 - P0), fabsf(PIN1 - P1)) > (float)R) | FORCE_IMAGE) != 0) sample_image(q);
+    else sample(q);
     float mq = 0.f;
     if (PN) {
       float s = q[0];

@@ -158,13 +158,48 @@ def test_fast_math_other_configurations(case, op_point, kw, alley):
     assert mean <= TOL_MEAN
 
 
-@pytest.mark.parametrize("lpp", ["8", "16"])
-def test_fast_math_lanes_per_patch(lpp, alley, monkeypatch):
-    """both layouts of the 8 x 8 gray kernel (FOTG_LK_LPP forces what the launch size selects)"""
-    monkeypatch.setenv("FOTG_LK_LPP", lpp)
+@pytest.mark.parametrize("case,op_point", [("alley", 2), ("synth_odd", 3)])
+def test_fast_math_small_window_and_level_image_paths_agree(case, op_point, alley, monkeypatch):
+    """gray 8 x 8 / 12 x 12 patches stage a window of radius 2 around the start; an evaluation outside it reads the level image.
+    Both paths deliver the same values: forcing EVERY evaluation through the level image (FOTG_LK_SHW=3 with FOTG_TEST_TAPS=1) gives
+    the same bits, and so does the kernel that stages the whole reachable region (FOTG_LK_FAST_R=0)."""
     F, OFClass, _, O = _mods()
-    f0, f1, _ = frames("alley", alley)
-    (ex_lo, ex_full), (fa_lo, fa_full) = fast_and_exact(F, OFClass, f0, f1, 2)
-    mean, p99, mx = stats(fa_full[0], ex_full[0])
-    print("alley op-pt 2, %s lanes per patch: mean %.3g  p99 %.3g  max %.3g px" % (lpp, mean, p99, mx))
-    assert mean <= TOL_MEAN
+    f0, f1, _ = frames(case, alley)
+    h, w = f0.shape
+    outs = []
+    for env in ({}, {"FOTG_TEST_TAPS": "1", "FOTG_LK_SHW": "3"}, {"FOTG_LK_FAST_R": "0"}):
+        for k in ("FOTG_TEST_TAPS", "FOTG_LK_SHW", "FOTG_LK_FAST_R"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        op = F.operating_point(op_point, w, 1)
+        op.fast_math = True
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        outs.append(ofc.calc(dev(f0), dev(f1)).cpu().numpy())
+        ofc.close()
+    assert np.array_equal(outs[0], outs[1]), "window path != level-image path"
+    assert np.array_equal(outs[0], outs[2]), "radius-2 window != whole-region window"
+
+
+def test_fast_math_large_motion_leaves_the_small_window():
+    """a pair whose patches move further than the staged radius (no coarser level to start from: one scale only, 4 px shift):
+    evaluations leave the window for real, same bits as the whole-region kernel, flow within tolerance of the parity mode"""
+    import os
+    F, OFClass, _, O = _mods()
+    f0, f1 = synth_pair(256, 384, seed=31, shift=(4.0, -3.0))
+    res = {}
+    for r in ("2", "0"):
+        os.environ["FOTG_LK_FAST_R"] = r
+        try:
+            for fast in (True, False):
+                op = F.operating_point(2, 384, 1)
+                op.coarsest_scale = op.finest_scale = 1
+                op.fast_math = fast
+                ofc = OFClass(op, F.img_params(width=384, height=256, padding=op.patch_size))
+                res[(r, fast)] = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+                ofc.close()
+        finally:
+            del os.environ["FOTG_LK_FAST_R"]
+    assert np.array_equal(res[("2", True)], res[("0", True)])
+    assert float(np.abs(res[("0", False)]).mean()) > 0.5                       # the patches really moved
+    assert epe(res[("2", True)], res[("0", False)]).mean() <= TOL_MEAN
