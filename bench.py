@@ -147,13 +147,13 @@ def roofline(ofc, I0, I1, lib, stream_ptr, batch):
     try:
         with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             k = json.load(f)["kernels"]
-        key = [x for x in k if "pyr_base_kernel<float, 1, 4, true>" in x]
+        key = [x for x in k if "pyr_base_kernel<float, 1, 4, true" in x]
         if key and batch == 64:
             traffic = k[key[0]]["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass
     gbs = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,1,4,true> (frames -> pyramid level 4, both frames of the batch in one launch)",
+    return {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,1,4,true,1> (frames -> pyramid level 4, both frames of the batch in one launch)",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_semantics": "L2-miss bytes (Infinity-Cache hits included)",
             "traffic_source": TRAFFIC_NOTE, "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms,
             "measured": "one launch at a time on an otherwise idle GPU; with %s batches in flight the same kernel stretches (profiles/)" % "several"}
