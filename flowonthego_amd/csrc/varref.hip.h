@@ -925,7 +925,11 @@ __global__ __launch_bounds__(1024) void vr_sor_stream_kernel(VrArgs a, float ome
   const int NI = (E + omax) / M + 1;                              // barrier intervals every wave goes through
   const int nsolver = a.nsweeps * NB;
   // roles: solver waves 0..2, helpers on SIMD 3 (waves 3, 7, 11, 15)
-  const int wvL0 = 3, wvL1 = 7, wvL2 = 11, wvW = 15;
+#ifndef FOTG_STREAM_WV
+#define FOTG_STREAM_WV 3, 7, 11, 15
+#endif
+  constexpr int wv_roles[4] = {FOTG_STREAM_WV};
+  const int wvL0 = wv_roles[0], wvL1 = wv_roles[1], wvL2 = wv_roles[2], wvW = wv_roles[3];
   const unsigned CRING = (unsigned)RCN * CSLOT, DRING = (unsigned)RDN * DB;     // bytes
   const unsigned DBASE = CRING, DUMP = CRING + DRING;             // C ring | D ring | one spare D row for the no-op tail steps
   char *Dg = reinterpret_cast<char *>(a.Dp(pair));
