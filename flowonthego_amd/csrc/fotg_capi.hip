@@ -16,6 +16,7 @@
 #include "densify.hip.h"
 #include "varref.hip.h"
 #include "varref_tiles.hip.h"
+#include "varref_levelpipe.hip.h"
 #include "varref_depth.hip.h"
 #include "upsample.hip.h"
 
@@ -62,6 +63,7 @@ struct FotgTune {
   int vr_path;      // FOTG_VR_PATH: 0 automatic, 1 single-wave global-memory solver only, 2 no fused per-level kernel
   int vr_stream;    // FOTG_VR_STREAM: 0 = resident-D kernel instead of the streaming solver
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
+  int vr_levelpipe; // FOTG_VR_LEVELPIPE: 1 = tall levels run all inner iterations as one pipeline launch (varref_levelpipe.hip.h)
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
   int vr_first_data; // FOTG_VR_FIRST_DATA: 0 = the first inner iteration's data term in a launch of its own (not in the set-up launch)
   int pyr_split;    // FOTG_PYR_SPLIT: launches the base pyramid kernel of a batch is cut into (1 = one launch)
@@ -126,6 +128,8 @@ struct fotg_ctx {
   long x_pair_stride[FOTG_MAXLEV];
   int x_rt[FOTG_MAXLEV];
   int *tileSync;
+  long sync_total;                   // ints in tileSync in front of the time-out counter: max(tile_sync_words, level-pipe words) for max_batch pairs
+  int lp_ntr;                        // tile rows of the data term the level-pipe words are sized for (the tallest tile level)
   // a bounded inter-workgroup wait that gave up (tile solver pipeline) sets this word of pinned host memory from the device;
   // fotg_calc, fotg_pipe_wait(host_wait) and fotg_pipe_sync read it after their synchronisation and return FOTG_ERR_STALL
   int *stall_host, *stall_dev;
@@ -221,7 +225,7 @@ void fotg_destroy(fotg_ctx *c)
     (void)hipFree(c->vrC[l]); (void)hipFree(c->vrD[l]); (void)hipFree(c->vrX[l]);
   }
   if (c->stall_host) (void)hipHostFree(c->stall_host);
-  (void)hipFree(c->vr); (void)hipFree(c->tileSync);
+  (void)hipFree(c->vr); (void)hipFree(c->tileSync); (void)hipFree(c->stamps);
   for (auto &e : c->tev) if (e) (void)hipEventDestroy(e);
   delete c;
 }
@@ -246,6 +250,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_stream = env_int("FOTG_VR_STREAM", 1);
   c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
   c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
+  c->tune.vr_levelpipe = env_int("FOTG_VR_LEVELPIPE", 0);
   c->tune.vr_first_data = env_int("FOTG_VR_FIRST_DATA", 1);
   c->tune.vr_fused_nt = env_int("FOTG_VR_FUSED_NT", 1024);
   c->tune.pyr_split = env_int("FOTG_PYR_SPLIT", 1);
@@ -347,8 +352,12 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
         ALLOC(c->vrX[l], xb);
         if (hipMemset(c->vrX[l], 0, xb) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
         if (!c->tileSync) {
-          ALLOC(c->tileSync, (tile_sync_words((int)B) + 32) * sizeof(int));
-          if (hipMemset(c->tileSync, 0, (tile_sync_words((int)B) + 32) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
+          // (the first level that gets here is the finest = tallest one: its tile rows size the level-pipe words)
+          c->lp_ntr = (gl.h + FOTG_TH - 1) / FOTG_TH;
+          const long lp = lp_tile_words((int)B) + lp_data_words((int)B, c->lp_ntr);
+          c->sync_total = lp > tile_sync_words((int)B) ? lp : tile_sync_words((int)B);
+          ALLOC(c->tileSync, (c->sync_total + 32) * sizeof(int));
+          if (hipMemset(c->tileSync, 0, (c->sync_total + 32) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
         }
       }
     }
@@ -810,6 +819,7 @@ static bool launch_sor_pipe(int n, float omega, hipStream_t s, const VrArgs &b)
 }
 
 static std::atomic<long> g_tile_launches{0};        // fotg_debug_counter("sor_tiles")
+static std::atomic<long> g_levelpipe_launches{0};   // fotg_debug_counter("level_pipe")
 #ifndef FOTG_TILE_P
 #define FOTG_TILE_P 8                    // prefetch depth (diagonals) of the tile solver
 #endif
@@ -943,7 +953,7 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
     g.NB = (a.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS;
     g.npairs = n;
     g.sync = c->tileSync;
-    g.timeouts = g.sync + tile_sync_words(c->max_batch);
+    g.timeouts = g.sync + c->sync_total;
     g.stall_flag = c->stall_dev;
 #ifdef FOTG_TILE_STATS
     if (!c->stamps) { if (hipMalloc((void **)&c->stamps, 4096 * 32 * 8) != hipSuccess) return; }
@@ -1006,6 +1016,13 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   VrArgs az = a;
   const bool tiles = c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->vrX[l] && c->tileSync && c->p.tv_solverit > 0 && c->tune.vr_setup;
   if (tiles) { az.zsync = c->tileSync; az.zsync_n = (int)tile_sync_words(n); }
+  // FOTG_VR_LEVELPIPE=1: the level's whole fixed-point loop as ONE pipeline launch behind the set-up launch (varref_levelpipe.hip.h).
+  // At least two sweeps per call (what keeps a band's last sweep behind the data term of its neighbours), at most four (X buffers).
+  const int ntr = (g.h + FOTG_TH - 1) / FOTG_TH;
+  const bool levelpipe = tiles && c->tune.vr_levelpipe && c->tune.vr_path == 0 && c->tune.vr_first_data && inner >= 1 && inner <= FOTG_LP_KMAX &&
+                         c->p.tv_solverit >= 2 && c->p.tv_solverit <= 4 && ntr <= c->lp_ntr && g.h <= 4096 &&
+                         lp_tile_words(n) + lp_data_words(n, ntr) <= c->sync_total;
+  if (levelpipe) { az.zsync_n = (int)(lp_tile_words(n) + lp_data_words(n, ntr)); }
   bool merged_first = false;
   if (c->tune.vr_setup) {
     // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
@@ -1023,6 +1040,38 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     LAUNCHCHK();
     vr_deriv2_kernel<NOC><<<grid, block, 0, s>>>(a);
     LAUNCHCHK();
+  }
+  if (levelpipe) {
+    TileArgs tg;
+    tg.X = c->vrX[l] + (size_t)(a.C - c->vrC[l]) / a.c_pair_stride * c->x_pair_stride[l];
+    tg.x_pair_stride = c->x_pair_stride[l];
+    tg.x_buf_stride = (long)(a.S + 1 + FOTG_TILE_DUMP) * c->x_rt[l];
+    tg.RT = c->x_rt[l];
+    tg.NB = (a.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS;
+    tg.npairs = n;
+    tg.sync = c->tileSync;
+    tg.timeouts = tg.sync + c->sync_total;
+    tg.stall_flag = c->stall_dev;
+    LevelPipeArgs q;
+    q.K = inner; q.ntr = ntr; q.tiles_x = (g.w + FOTG_TW - 1) / FOTG_TW;
+    q.dprog = c->tileSync + lp_tile_words(n);
+    q.quarter_alpha = quarter_alpha; q.half_delta_over3 = half_delta_over3; q.half_gamma_over3 = half_gamma_over3;
+    q.dbg = c->tune.vr_levelpipe >> 4;       // (FOTG_VR_LEVELPIPE = 1 + 16 * dbg)
+    q.stamps = nullptr;
+    if (q.dbg & 4) {                         // diagnosis only: per-role time stamps (tools/levelpipe_stamps.py)
+      if (!c->stamps && hipMalloc((void **)&c->stamps, 8 * 8 * 8192) != hipSuccess) return FOTG_ERR_HIP;
+      (void)hipMemsetAsync(c->stamps, 0, 8 * 8 * 8192, s);
+      q.stamps = (long long *)c->stamps;
+    }
+    const int sw = c->p.tv_solverit;
+    const unsigned nwg = (unsigned)n * (unsigned)(inner * tg.NB * sw + (inner - 1) * ntr);
+    if (c->p.fast_math) vr_level_pipe_kernel<NOC, FOTG_TILE_P, true><<<nwg, 256, 0, s>>>(a, tg, q, sw, c->p.tv_sor);
+    else vr_level_pipe_kernel<NOC, FOTG_TILE_P, false><<<nwg, 256, 0, s>>>(a, tg, q, sw, c->p.tv_sor);
+    LAUNCHCHK();
+    ++g_levelpipe_launches;
+    vr_finish_kernel<<<grid, block, 0, s>>>(a, flow, fs);
+    LAUNCHCHK();
+    return FOTG_OK;
   }
   for (int it = 0; it < inner; ++it) {
     if (!(it == 0 && merged_first)) {
@@ -1634,6 +1683,7 @@ long fotg_debug_counter(const char *name)
 {
   if (name && !strcmp(name, "sor_stream")) return g_stream_launches;
   if (name && !strcmp(name, "sor_tiles")) return g_tile_launches;
+  if (name && !strcmp(name, "level_pipe")) return g_levelpipe_launches;
   return -1;
 }
 
@@ -1693,7 +1743,7 @@ long fotg_ctx_counter(fotg_ctx *c, const char *name)
     if (!dg.ok || hipDeviceSynchronize() != hipSuccess) return -1;
     {
       int v = 0;
-      if (hipMemcpy(&v, c->tileSync + tile_sync_words(c->max_batch), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      if (hipMemcpy(&v, c->tileSync + c->sync_total, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
       tot += v;
     }
     return tot;

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""time line of the roles of the level pipeline at the finest level of the 4K operating-point-4 pair (FOTG_VR_LEVELPIPE=65: stamps)"""
+import os, sys, ctypes
+os.environ["FOTG_VR_LEVELPIPE"] = "65"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from conftest import synth_pair
+import flowonthego_amd as F
+from flowonthego_amd.oflow import OFClass
+from flowonthego_amd._lib import lib
+f0, f1 = synth_pair(2160, 3840, seed=5)
+a, b = torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda()
+op = F.operating_point(4, 3840, 1)
+ofc = OFClass(op, F.img_params(width=3840, height=2160, padding=op.patch_size))
+for _ in range(3):
+    ofc.calc(a, b)
+torch.cuda.synchronize()
+hip = ctypes.CDLL("libamdhip64.so")
+ptr = lib().fotg_ctx_counter(ofc._h, b"stamps_ptr")
+st = np.zeros((8192, 8), np.int64)
+hip.hipMemcpy(st.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), st.nbytes, 2)
+st = st[st[:, 0] != 0]
+t0 = st[:, 0].min()
+rows = []
+for r in st:
+    isdata = (r[2] >> 60) & 1
+    kc = (r[2] >> 40) & 0xff
+    if isdata:
+        rows.append((r[0], "data  k %d ty %2d" % (kc, r[2] & 0xfffff), r))
+    else:
+        rows.append((r[0], "tile  k %d n %d b %d" % (kc, (r[2] >> 20) & 0x3ff, (r[2] >> 30) & 0x3ff), r))
+print("%d roles, whole launch %.1f us" % (len(rows), (st[:, 1].max() - t0) / 100))
+for _, name, r in sorted(rows, key=lambda x: (x[2][2] >> 40) & 0xff):
+    if "data" in name and (r[2] & 0xfffff) % 8 not in (0, 7):
+        continue
+    print("  %-22s start %7.1f end %7.1f | %s" % (name, (r[0] - t0) / 100, (r[1] - t0) / 100, " ".join("%7.1f" % ((x - t0) / 100) for x in r[3:8] if x)))
