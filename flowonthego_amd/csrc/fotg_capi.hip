@@ -63,7 +63,7 @@ struct FotgTune {
   int vr_path;      // FOTG_VR_PATH: 0 automatic, 1 single-wave global-memory solver only, 2 no fused per-level kernel
   int vr_stream;    // FOTG_VR_STREAM: 0 = resident-D kernel instead of the streaming solver
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
-  int vr_levelpipe; // FOTG_VR_LEVELPIPE: 1 = tall levels run all inner iterations as one pipeline launch (varref_levelpipe.hip.h)
+  int vr_levelpipe; // FOTG_VR_LEVELPIPE: 1 (default) = tall levels run all inner iterations as one pipeline launch (varref_levelpipe.hip.h); 0 = one tile-solver launch per sor_coupled call; + 16 x diagnosis bits
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
   int vr_first_data; // FOTG_VR_FIRST_DATA: 0 = the first inner iteration's data term in a launch of its own (not in the set-up launch)
   int pyr_split;    // FOTG_PYR_SPLIT: launches the base pyramid kernel of a batch is cut into (1 = one launch)
@@ -250,7 +250,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_stream = env_int("FOTG_VR_STREAM", 1);
   c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
   c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
-  c->tune.vr_levelpipe = env_int("FOTG_VR_LEVELPIPE", 0);
+  c->tune.vr_levelpipe = env_int("FOTG_VR_LEVELPIPE", 1);
   c->tune.vr_first_data = env_int("FOTG_VR_FIRST_DATA", 1);
   c->tune.vr_fused_nt = env_int("FOTG_VR_FUSED_NT", 1024);
   c->tune.pyr_split = env_int("FOTG_PYR_SPLIT", 1);
@@ -1064,9 +1064,19 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
       q.stamps = (long long *)c->stamps;
     }
     const int sw = c->p.tv_solverit;
-    const unsigned nwg = (unsigned)n * (unsigned)(inner * tg.NB * sw + (inner - 1) * ntr);
-    if (c->p.fast_math) vr_level_pipe_kernel<NOC, FOTG_TILE_P, true><<<nwg, 256, 0, s>>>(a, tg, q, sw, c->p.tv_sor);
-    else vr_level_pipe_kernel<NOC, FOTG_TILE_P, false><<<nwg, 256, 0, s>>>(a, tg, q, sw, c->p.tv_sor);
+    const unsigned nwg = (unsigned)n * (unsigned)(inner * tg.NB * sw + (inner - 1) * ntr * FOTG_LP_DW);
+    // a launch that fits the chip with one workgroup per CU asks for enough LDS to get exactly that: a solver wave that shares its
+    // SIMD with a data-term wave of another workgroup runs up to 25 % slower (measured)
+    const int excl = (nwg <= 256 && !(q.dbg & 8)) ? 72 * 1024 : 0;
+    if (c->p.fast_math) {
+      static int lds_set[32] = {0};
+      if (excl && !ensure_dyn_lds(reinterpret_cast<const void *>(&vr_level_pipe_kernel<NOC, FOTG_TILE_P, true>), excl, lds_set)) return FOTG_ERR_HIP;
+      vr_level_pipe_kernel<NOC, FOTG_TILE_P, true><<<nwg, 256, excl, s>>>(a, tg, q, sw, c->p.tv_sor);
+    } else {
+      static int lds_set[32] = {0};
+      if (excl && !ensure_dyn_lds(reinterpret_cast<const void *>(&vr_level_pipe_kernel<NOC, FOTG_TILE_P, false>), excl, lds_set)) return FOTG_ERR_HIP;
+      vr_level_pipe_kernel<NOC, FOTG_TILE_P, false><<<nwg, 256, excl, s>>>(a, tg, q, sw, c->p.tv_sor);
+    }
     LAUNCHCHK();
     ++g_levelpipe_launches;
     vr_finish_kernel<<<grid, block, 0, s>>>(a, flow, fs);

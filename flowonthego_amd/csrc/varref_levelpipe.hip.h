@@ -33,13 +33,14 @@ namespace fotg {
 struct LevelPipeArgs {
   int K;                                     // inner iterations = sor_coupled calls
   int ntr, tiles_x;                          // tile rows / tiles per row of the data term (FOTG_TW x FOTG_TH pixels)
-  int *dprog;                                // [pair][FOTG_LP_KMAX][ntr] x 32 ints: progress of the data term of iteration k in tile row ty
+  int *dprog;                                // [pair][FOTG_LP_KMAX][ntr][FOTG_LP_DW] x 32 ints: progress of the data term of iteration k in tile row ty, per workgroup of the row
   float quarter_alpha, half_delta_over3, half_gamma_over3;
   long long *stamps;                         // diagnosis (dbg & 4): per ticket 8 words: start, end, role, first step / first publish (wall clock, 10 ns)
   int dbg;                                   // FOTG_VR_LEVELPIPE_DBG (diagnosis): 1 = the data term waits for the whole previous call, 2 = a call's first sweep for the whole data term
 };
 __host__ __device__ inline long lp_tile_words(int npairs) { return 32L * (1 + (long)npairs * FOTG_LP_KMAX * 4 * 64); }
-__host__ __device__ inline long lp_data_words(int npairs, int ntr) { return 32L * (long)npairs * FOTG_LP_KMAX * ntr; }
+#define FOTG_LP_DW 1                         // workgroups per tile row of the data term (tile tx goes to workgroup tx % FOTG_LP_DW)
+__host__ __device__ inline long lp_data_words(int npairs, int ntr) { return 32L * (long)npairs * FOTG_LP_KMAX * ntr * FOTG_LP_DW; }
 
 __device__ __forceinline__ void st_sc1_f4(void *p, float4 v)
 {
@@ -72,7 +73,7 @@ __device__ __forceinline__ void lp_report_timeout(const TileArgs &g)
 #define FOTG_LP_MW (1 * FOTG_TW)
 #endif
 template <int NOC>
-__device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g, const LevelPipeArgs &q, int pair, int kc, int ty, int nsweeps, int ticket)
+__device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g, const LevelPipeArgs &q, int pair, int kc, int ty, int half, int nsweeps, int ticket)
 {
   constexpr int MW = FOTG_LP_MW, NPX = MW / FOTG_TW;
   constexpr int UW = MW + 4, UH = FOTG_TH + 4, SW = MW + 2, SH = FOTG_TH + 2;
@@ -83,7 +84,11 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
   const int lx = threadIdx.x % FOTG_TW, ly = threadIdx.x / FOTG_TW;
   const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
   const float2 *D = a.Dp(pair);
-  int *const myprog = q.dprog + 32 * (((long)pair * FOTG_LP_KMAX + kc) * q.ntr + ty);
+  // Two workgroups share a tile row, tile tx belongs to workgroup tx % 2: a tile costs a round of fixed latencies (the producers'
+  // progress, the staging loads, the acknowledgement of the written-through cells: 4.5-5 us) while the solver's wavefront crosses
+  // it in 3.6 us -- one workgroup per row set the pace of every later stage.  Each publishes how far the row is done AS FAR AS IT
+  // IS CONCERNED: behind its tile tx that is the end of tile tx + 1 (the other workgroup's); the row's progress is the minimum.
+  int *const myprog = q.dprog + 32 * ((((long)pair * FOTG_LP_KMAX + kc) * q.ntr + ty) * FOTG_LP_DW + half);
   // the last sweep of call kc - 1 in the bands whose rows this tile row reads (rows y0 - 2 .. y0 + FOTG_TH + 1)
   const int blo = (y0 - 2 < 0 ? 0 : y0 - 2) / FOTG_TILE_ROWS, bhi0 = (y0 + FOTG_TH + 1) / FOTG_TILE_ROWS, bhi = bhi0 > g.NB - 1 ? g.NB - 1 : bhi0;
   const int *const p0 = g.sync + 32 * (1 + ((pair * FOTG_LP_KMAX + kc - 1) * 4 + nsweeps - 1) * 64 + blo);
@@ -92,7 +97,8 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   int seen0 = -1, seen1 = -1;
   const int ntx = (w + MW - 1) / MW;
-  for (int tx = 0; tx < ntx; ++tx) {
+  if (half >= ntx && threadIdx.x == 0) __hip_atomic_store(myprog, 0x3ffffff0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (no tile of its own)
+  for (int tx = half; tx < ntx; tx += FOTG_LP_DW) {
     const int x0 = tx * MW;
     // ---- wait: every cell this macro tile reads (its pixels +- 2) has its final value of iteration kc - 1
     {
@@ -153,13 +159,20 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
       __builtin_amdgcn_raw_buffer_store_b128(u0, rsC, off, 0, 16);          // (aux 16 = sc1: written through)
       __builtin_amdgcn_raw_buffer_store_b128(u1, rsC, off + 16, 0, 16);
     }
-    // ---- publish: this wave's stores have completed, then all waves', then the row's progress
+    // ---- publish: this wave's stores have completed, then all waves', then the row's progress.  The polls for the NEXT tile are
+    // requested in front of the wait, so that their round trip overlaps the acknowledgement of the written-through cells.
+    int pre0 = -1, pre1 = -1;
+    if ((threadIdx.x >> 6) == 0) asm volatile("global_load_dword %0, %2, %3 sc1\n\tglobal_load_dword %1, %2, %4 sc1" : "=&v"(pre0), "=&v"(pre1) : "v"(0), "s"(p0), "s"(p1) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x >> 6) == 0) {
+      pre0 = __builtin_amdgcn_readfirstlane(pre0); pre1 = __builtin_amdgcn_readfirstlane(pre1);
+      seen0 = pre0 > seen0 ? pre0 : seen0; seen1 = pre1 > seen1 ? pre1 : seen1;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int pub = tx == ntx - 1 ? 0x3ffffff0 : x0 + MW - 1 + y0;
+      const int pub = tx + FOTG_LP_DW >= ntx ? 0x3ffffff0 : x0 + FOTG_LP_DW * MW - 1 + y0;
       __hip_atomic_store(myprog, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (q.stamps && tx < 5) q.stamps[(long)ticket * 8 + 3 + tx] = wall_clock64();
+      if (q.stamps && tx / FOTG_LP_DW < 5) q.stamps[(long)ticket * 8 + 3 + tx / FOTG_LP_DW] = wall_clock64();
     }
   }
 }
@@ -167,14 +180,14 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
 // ------------------------------------------------------------------------------------------------------------------------------
 // TILE role: varref_tiles.hip.h's tile (sweep n, band b) of call kc
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int P, bool FMA>
+template <int P, bool FMA, bool CSC1>
 __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g, const LevelPipeArgs &q, int pair, int kc, int n, int b, int nsweeps, float omega, int ticket)
 {
   constexpr int G = FOTG_TILE_G, BR = FOTG_TILE_ROWS, U = FOTG_TILE_U, RING = 2 * G, W = FOTG_TILE_W;
   static_assert(U % P == 0 && P % G == 0 && U % G == 0 && U % RING == 0, "ring slots and barrier phase are compile-time");
   __shared__ float2 res_ring[RING][BR];
   __shared__ int seen_lds[4];                                     // own, below, top, data term (min over the band's tile rows)
-  __shared__ int dp_lds[8];                                       // the band's eight data-term progress words as the poller last saw them
+  __shared__ int dp_lds[8 * FOTG_LP_DW];                          // the band's data-term progress words (tile row x workgroup) as the poller last saw them
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (wv == 3) return;                                            // (a barrier counts the waves that have not ended)
   const int S = a.S, RP = a.RP, RPD = a.RPD, h = a.h;
@@ -186,7 +199,10 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
   // the data term of this call in the band's tile rows (first sweep of calls >= 1; the others follow the first sweep)
   const bool wdata = n == 0 && kc > 0;
   const int ty0 = b * (BR / FOTG_TH), nty = (q.ntr - ty0) < BR / FOTG_TH ? (q.ntr - ty0) : BR / FOTG_TH;
-  const int *const dpw = q.dprog + 32 * (((long)pair * FOTG_LP_KMAX + kc) * q.ntr + ty0);
+  const int *const dpw = q.dprog + 32 * ((((long)pair * FOTG_LP_KMAX + kc) * q.ntr + ty0) * FOTG_LP_DW);
+  // what workgroup hh of tile row ty0 + r claims before it has finished a tile: the tiles in front of its first one are not its
+  // business (hh = 1: "up to the end of tile 0"); and no tile row has cells on the diagonals above its first row
+  auto floor_of = [&](int r, int hh) { const int y0r = (ty0 + r) * FOTG_TH; const int own = hh * FOTG_LP_MW - 1 + y0r; const int none = y0r - 1; return hh > 0 && own > none ? own : none; };
   float2 *const Dlev = a.Dp(pair);
   float2 *const Xp = g.X + (size_t)pair * g.x_pair_stride;
   const float2 *const Xin = n == 0 ? Dlev : Xp + (size_t)(n - 1) * g.x_buf_stride;
@@ -199,7 +215,7 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
 
   if (threadIdx.x < 3) seen_lds[threadIdx.x] = (threadIdx.x == 0 ? prog_own : threadIdx.x == 1 ? prog_bel : prog_top) ? -1 : 0x3fffffff;
   if (threadIdx.x == 3) seen_lds[3] = wdata ? -1 : 0x3fffffff;
-  if (threadIdx.x >= 8 && threadIdx.x < 16) dp_lds[threadIdx.x - 8] = (wdata && (int)threadIdx.x - 8 < nty) ? -1 : 0x3fffffff;
+  if (threadIdx.x >= 32 && threadIdx.x < 32 + 8 * FOTG_LP_DW) dp_lds[threadIdx.x - 32] = (wdata && ((int)threadIdx.x - 32) / FOTG_LP_DW < nty) ? -1 : 0x3fffffff;
   __syncthreads();
 
   // ======================================== poller wave ========================================
@@ -214,17 +230,15 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
         if (prog_top) __builtin_amdgcn_global_load_lds((gvoid *)prog_top, (lvoid *)&seen_lds[2], 4, 0, 16);
       }
       if (wdata) {
-        // the eight rows' words, one lane each; the minimum of what has landed so far goes to seen_lds[3] (a stale view only delays)
-        if (lane < nty) __builtin_amdgcn_global_load_lds((gvoid *)(dpw + 32 * lane), (lvoid *)&dp_lds[0], 4, 0, 16);
+        // the rows' words, one lane each; the minimum of what has landed so far goes to seen_lds[3] (a stale view only delays)
+        if (lane < nty * FOTG_LP_DW) __builtin_amdgcn_global_load_lds((gvoid *)(dpw + 32 * lane), (lvoid *)&dp_lds[0], 4, 0, 16);
         if (lane == 0) {
-          // (a tile row has no cell on the diagonals above its first row: those count as done, so that a band does not wait for
-          // the wavefront to reach its last rows before it may start)
           int m = 0x3fffffff;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
+          for (int r = 0; r < 8 * FOTG_LP_DW; ++r) {
             int v = __hip_atomic_load(&dp_lds[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int none = (ty0 + r) * FOTG_TH - 1;
-            v = v < none ? none : v;
+            const int fl = floor_of(r / FOTG_LP_DW, r % FOTG_LP_DW);
+            v = v < fl ? fl : v;
             m = v < m ? v : m;
           }
           __hip_atomic_store(&seen_lds[3], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -289,7 +303,8 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
   const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc((void *)Xin, 0, (S + 1) * ipitch, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void *)Xout, 0, (S + 1) * tpitch, 0x00020000);
   // (the system cells come from another workgroup of this launch: agent-scope loads, aux 16 = sc1)
-  auto ld_c = [&](unsigned vo, unsigned so) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsC, vo, so, 16)); };
+  // (CSC1 = false: call 0, whose system was written by the set-up launch -- ordinary loads)
+  auto ld_c = [&](unsigned vo, unsigned so) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsC, vo, so, CSC1 ? 16 : 0)); };
   auto ld_x = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) { return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 16)); };
   auto ld_x2 = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 16)); };
 
@@ -307,22 +322,28 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
       seen = 0x3fffffff;
     }
   };
-  // the data term: the slowest of the band's tile rows
+  // the data term: the slowest of the band's tile rows.  One poll per LANE (lane r reads word r: all words in one round trip -- the
+  // first sweep of a call runs right behind the data term and comes here every few steps), then the minimum over the lanes.
+  const int myfl = lane < nty * FOTG_LP_DW ? floor_of(lane / FOTG_LP_DW, lane % FOTG_LP_DW) : 0x3fffffff;
+  const int *const mydp = dpw + 32 * (lane < nty * FOTG_LP_DW ? lane : 0);
   auto wait_data = [&](int need) __attribute__((always_inline)) {
     if (seen_dat >= need) return;
     int spins = 0;
     do {
-      int m = 0x3fffffff;
-      for (int r = 0; r < nty; ++r) {
-        const int none = (ty0 + r) * FOTG_TH - 1;                  // (no cell of this tile row on the diagonals up to here)
-        int v = none;                                             // (a row that is not needed yet is not polled: what is known about it is `none`)
-        if (none < need) { v = lp_poll(dpw + 32 * r); v = v < none ? none : v; }
-        m = v < m ? v : m;
-      }
-      seen_dat = m;
+      int v;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(mydp) : "memory");
+      v = v < myfl ? myfl : v;
+      // minimum over the first 16 lanes (the others hold "everything"): row rotations, like row_allsum
+#define FOTG_DPPI(x, ctrl) __builtin_amdgcn_update_dpp(0x3fffffff, x, ctrl, 0xF, 0xF, false)
+      { int o = FOTG_DPPI(v, 0x128); v = o < v ? o : v; }
+      { int o = FOTG_DPPI(v, 0x124); v = o < v ? o : v; }
+      { int o = FOTG_DPPI(v, 0x122); v = o < v ? o : v; }
+      { int o = FOTG_DPPI(v, 0x121); v = o < v ? o : v; }
+#undef FOTG_DPPI
+      seen_dat = __builtin_amdgcn_readfirstlane(v);
       if (seen_dat >= need) break;
-      __builtin_amdgcn_s_sleep(2);
-    } while (++spins < (1 << 18));
+      __builtin_amdgcn_s_sleep(1);
+    } while (++spins < (1 << 20));
     if (seen_dat < need) {
       if (lane == 0) lp_report_timeout(g);
       seen_dat = 0x3fffffff;
@@ -450,15 +471,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   bool isdata = false;
   if (idx >= T) {
     idx -= T;
-    const int seg = q.ntr + T;
+    const int seg = q.ntr * FOTG_LP_DW + T;
     kc = 1 + idx / seg;
     idx %= seg;
-    if (idx < q.ntr) isdata = true; else idx -= q.ntr;
+    if (idx < q.ntr * FOTG_LP_DW) isdata = true; else idx -= q.ntr * FOTG_LP_DW;
   }
   if (kc >= q.K) return;
   if (q.stamps && threadIdx.x == 0) { q.stamps[(long)t * 8] = wall_clock64(); q.stamps[(long)t * 8 + 2] = ((long long)(isdata ? 1 : 0) << 60) | ((long long)kc << 40) | idx; }
   if (isdata) {
-    lp_data_role<NOC>(a, g, q, pair, kc, idx, nsweeps, t);
+    lp_data_role<NOC>(a, g, q, pair, kc, idx / FOTG_LP_DW, idx % FOTG_LP_DW, nsweeps, t);
     if (q.stamps && threadIdx.x == 0) q.stamps[(long)t * 8 + 1] = wall_clock64();
     return;
   }
@@ -476,7 +497,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   }
   if (n < 0) return;
   if (q.stamps && threadIdx.x == 0) q.stamps[(long)t * 8 + 2] |= ((long long)n << 20) | ((long long)b << 30) | (1ll << 59);
-  lp_tile_role<P, FMA>(a, g, q, pair, kc, n, b, nsweeps, omega, t);
+  if (kc == 0) lp_tile_role<P, FMA, false>(a, g, q, pair, kc, n, b, nsweeps, omega, t);
+  else lp_tile_role<P, FMA, true>(a, g, q, pair, kc, n, b, nsweeps, omega, t);
   if (q.stamps && threadIdx.x == 0) q.stamps[(long)t * 8 + 1] = wall_clock64();
 }
 

@@ -318,13 +318,18 @@ def test_streaming_solver_kernel(mode, monkeypatch):
     assert F.lib().fotg_debug_counter(b"sor_stream") == before + expect
 
 
-def test_tile_solver_pipeline():
+@pytest.mark.parametrize("levelpipe", ["1", "0"])
+def test_tile_solver_pipeline(levelpipe, monkeypatch):
     """levels of more than 96 rows are relaxed by the tile pipeline (varref_tiles.hip.h): one workgroup (solver wave + writer wave)
-    per (sweep, band of 64 rows), (du,dv) handed from tile to tile through global memory behind progress words.  Sizes: op-pt 3 at
-    1080p (levels 240x136: 3 bands, 480x272: 5 bands), a 132-row level (third band of 4 rows), op-pt 4 on a tall frame (544 rows:
-    9 bands), batches of two; 1, 2 and 4 sweeps.  Bit-identical to the oracle, no wait timed out."""
+    per (sweep, band of 64 rows), (du,dv) handed from tile to tile through global memory behind progress words -- as one launch per
+    sor_coupled call (FOTG_VR_LEVELPIPE=0) or, the default, with ALL inner iterations of the level and their data terms as one pipeline
+    launch (varref_levelpipe.hip.h; calls of 2..4 sweeps).  Sizes: op-pt 3 at 1080p (levels 240x136: 3 bands, 480x272: 5 bands), a
+    132-row level (third band of 4 rows), op-pt 4 on a tall frame (544 rows: 9 bands), batches of two; 1, 2 and 4 sweeps.
+    Bit-identical to the oracle, no wait timed out."""
     F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_LEVELPIPE", levelpipe)
     before = F.lib().fotg_debug_counter(b"sor_tiles")
+    before_lp = F.lib().fotg_debug_counter(b"level_pipe")
     for (w, h), op_point, width_for_op, sweeps in (((1920, 1080), 3, 1920, 3), ((640, 528), 3, 640, 3), ((480, 2176), 4, 3840, 3),
                                                    ((640, 528), 3, 640, 1), ((640, 528), 3, 640, 2), ((640, 528), 3, 640, 4)):
         f0, f1 = synth_pair(h, w, seed=4)
@@ -338,23 +343,26 @@ def test_tile_solver_pipeline():
         assert np.array_equal(out[0], O.flow(a, b, p, 0)) and np.array_equal(out[1], O.flow(b, a, p, 0)), (w, h, sweeps)
         assert F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
         ofc.close()
-    assert F.lib().fotg_debug_counter(b"sor_tiles") > before
+    assert F.lib().fotg_debug_counter(b"sor_tiles") > before                 # (the one-sweep case runs a launch per call in both modes)
+    assert (F.lib().fotg_debug_counter(b"level_pipe") > before_lp) == (levelpipe == "1")
 
 
-def test_tile_solver_rgb_frames():
+@pytest.mark.parametrize("levelpipe", ["1", "0"])
+def test_tile_solver_rgb_frames(levelpipe, monkeypatch):
     """the tile pipeline under a three-channel data term (op-pt 3, 640 x 528 RGB: levels of 132 and 264 rows), batch of two:
     bit-identical to the oracle, no wait timed out"""
     F, OFClass, _, O = _mods()
+    monkeypatch.setenv("FOTG_VR_LEVELPIPE", levelpipe)
     f0, f1 = synth_pair(528, 640, seed=31, noc=3)
     op = F.operating_point(3, 640, 3)
     op.grad_descent_iter = 6
     ofc = OFClass(op, F.img_params(width=640, height=528, padding=op.patch_size), max_batch=2)
-    before = F.lib().fotg_debug_counter(b"sor_tiles")
+    before = F.lib().fotg_debug_counter(b"level_pipe" if levelpipe == "1" else b"sor_tiles")
     out = ofc.calc_batch(dev(np.stack([f0, f1])), dev(np.stack([f1, f0]))).cpu().numpy()
     p = oracle_params(O, op)
     a, b = O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f)
     assert np.array_equal(out[0], O.flow(a, b, p, 0)) and np.array_equal(out[1], O.flow(b, a, p, 0))
-    assert F.lib().fotg_debug_counter(b"sor_tiles") > before and F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
+    assert F.lib().fotg_debug_counter(b"level_pipe" if levelpipe == "1" else b"sor_tiles") > before and F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
     ofc.close()
 
 
@@ -448,7 +456,7 @@ def test_levels_taller_than_1024_rows(path, monkeypatch):
     f0, f1 = synth_pair(h, w, seed=8)
     op = F.operating_point(3, w, 1)
     assert op.finest_scale == 0
-    name = b"sor_tiles"
+    name = b"level_pipe" if path == "0" else b"sor_tiles"          # (FOTG_VR_PATH=0: the level's whole fixed-point loop as one pipeline launch)
     before = F.lib().fotg_debug_counter(name)
     ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
     out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
@@ -1176,17 +1184,18 @@ def test_stalled_wait_heals_at_the_host_sync_points(monkeypatch):
     assert oh > 96                                                        # the finest level runs on the tile solver
     host = np.zeros((oh, ow, 2), np.float32)
     args = (ofc._h, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), None, host.ctypes.data_as(C.c_void_p))
-    tiles0 = L.fotg_debug_counter(b"sor_tiles")
+    count = lambda: L.fotg_debug_counter(b"sor_tiles") + L.fotg_debug_counter(b"level_pipe")      # launches with inter-workgroup waits
+    tiles0 = count()
     assert L.fotg_calc(*args) == 0 and L.fotg_ctx_counter(ofc._h, b"stalls") == 0
-    tiles1 = L.fotg_debug_counter(b"sor_tiles")
+    tiles1 = count()
     assert tiles1 > tiles0 and np.array_equal(host, ref)
     L.fotg_ctx_counter(ofc._h, b"inject_stall")
     assert L.fotg_ctx_counter(ofc._h, b"stalls") == 1                     # (non-synchronising query)
     host[:] = 0
     assert L.fotg_calc(*args) == 0                                        # healed: no error for a valid call
-    tiles2 = L.fotg_debug_counter(b"sor_tiles")
+    tiles2 = count()
     assert np.array_equal(host, ref) and L.fotg_ctx_counter(ofc._h, b"stalls") == 1
-    assert tiles2 - tiles1 == tiles1 - tiles0                             # the second pass did not use the tile pipeline
+    assert tiles2 - tiles1 == tiles1 - tiles0                             # the second pass used neither the tile solver nor the level pipeline
     assert L.fotg_calc(*args) == 0 and np.array_equal(host, ref) and L.fotg_ctx_counter(ofc._h, b"stalls") == 1
     # asynchronous callers: the consuming query sees every stall once, and a stale flag is never blamed on a later call
     out = ofc.calc_batch(A[None], B[None])
@@ -1405,3 +1414,40 @@ def test_golden_flo_on_the_coarse_grid(alley, alley_golden_flow):
     print("coarse-grid EPE vs alley_0001.flo: mean %.5f px (coarse) = %.4f px full resolution, p99 %.4f, max %.4f (coarse px)"
           % (e.mean(), 8 * e.mean(), np.percentile(e, 99), e.max()))
     assert e.mean() < 0.03 / 8 * 1.5 and np.percentile(e, 99) < 0.2 / 8 * 1.5
+
+
+def test_level_pipeline_equals_the_launch_per_stage_path(monkeypatch):
+    """the default refinement of tall levels -- every inner iteration of the level, data terms included, as ONE pipeline launch
+    (varref_levelpipe.hip.h) -- against one launch per stage (FOTG_VR_LEVELPIPE=0): the same bits for a single 4K-class pair at the
+    quality preset (six scales, levels of 136 / 272 / 544 rows with 5 / 4 / 3 inner iterations), for batches that make more
+    workgroups than the chip holds at once (the ticket order keeps every wait bounded), for RGB and in the tolerance mode; no wait
+    timed out; and the pair alone equals the oracle"""
+    F, OFClass, _, O = _mods()
+    L = F.lib()
+
+    def run(w, h, op_point, frames, n, lp, noc=1, fast=False):
+        monkeypatch.setenv("FOTG_VR_LEVELPIPE", lp)
+        op = F.operating_point(op_point, w, noc)
+        op.grad_descent_iter = min(op.grad_descent_iter, 12)              # (keeps the oracle quick; the refinement is what is under test)
+        op.fast_math = fast
+        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=n)
+        before = L.fotg_debug_counter(b"level_pipe")
+        out = ofc.calc_batch(*frames).clone()
+        torch.cuda.synchronize()
+        assert L.fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0 and L.fotg_ctx_counter(ofc._h, b"stalls") == 0
+        launched = L.fotg_debug_counter(b"level_pipe") - before
+        ofc.close()
+        return out, launched, op
+
+    for (w, h, op_point, n, noc, fast) in ((2048, 1152, 4, 1, 1, False), (1920, 1080, 3, 12, 1, False), (640, 528, 3, 2, 3, False), (2048, 1152, 4, 1, 1, True)):
+        pairs = [synth_pair(h, w, seed=900 + k, noc=noc) for k in range(min(n, 3))]
+        f0 = dev(np.stack([pairs[k % len(pairs)][0] for k in range(n)]))
+        f1 = dev(np.stack([pairs[k % len(pairs)][1] for k in range(n)]))
+        a, la, op = run(w, h, op_point, (f0, f1), n, "1", noc, fast)
+        b, lb, _ = run(w, h, op_point, (f0, f1), n, "0", noc, fast)
+        assert la > 0 and lb == 0, (w, h, la, lb)
+        assert torch.equal(a, b), (w, h, op_point, n, noc, fast)
+        if n == 1 and not fast:
+            p = oracle_params(O, op)
+            ref = O.flow(O.pad_frame(pairs[0][0], p.sc_f), O.pad_frame(pairs[0][1], p.sc_f), p, 0)
+            assert np.array_equal(a[0].cpu().numpy(), ref)

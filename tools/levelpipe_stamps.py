@@ -28,11 +28,11 @@ for r in st:
     isdata = (r[2] >> 60) & 1
     kc = (r[2] >> 40) & 0xff
     if isdata:
-        rows.append((r[0], "data  k %d ty %2d" % (kc, r[2] & 0xfffff), r))
+        rows.append((r[0], "data  k %d ty %2d.%d" % (kc, (r[2] & 0xfffff) // 2, (r[2] & 0xfffff) % 2), r))
     else:
         rows.append((r[0], "tile  k %d n %d b %d" % (kc, (r[2] >> 20) & 0x3ff, (r[2] >> 30) & 0x3ff), r))
 print("%d roles, whole launch %.1f us" % (len(rows), (st[:, 1].max() - t0) / 100))
 for _, name, r in sorted(rows, key=lambda x: (x[2][2] >> 40) & 0xff):
-    if "data" in name and (r[2] & 0xfffff) % 8 not in (0, 7):
+    if "data" in name and ((r[2] & 0xfffff) // 2) % 8 not in (0, 7):
         continue
     print("  %-22s start %7.1f end %7.1f | %s" % (name, (r[0] - t0) / 100, (r[1] - t0) / 100, " ".join("%7.1f" % ((x - t0) / 100) for x in r[3:8] if x)))
