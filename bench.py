@@ -333,6 +333,22 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=
                                              (lw + lh - 1, mss * 1e6 / (lw + lh - 1))})
     except Exception as e:
         res["rooflines"].append({"unavailable": str(e)})
+    # the level pipeline (the default path of the tall levels: every inner iteration of a level -- data terms and sor_coupled calls --
+    # as one launch): algorithmic bytes of the finest level = inner x (3 sweeps x 48 B per cell) + (inner - 1) x 84 B per cell for the
+    # data terms (11 planes, (du,dv), the 32-byte system cell), over the stage time of that level (set-up and final w + d included)
+    try:
+        inner = lvl + 1
+        alg_lp = lw * lh * (inner * op.var_ref_iter * 48 + (inner - 1) * 84)
+        ms_lp = st["varref[%d]" % lvl]
+        res["rooflines"].append({"bound": "hbm", "bound_note": "nearest roof the contract names; the launch is a pipeline of dependency chains",
+                                 "kernel": "fotg::vr_level_pipe_kernel (level %d, %dx%d: %d inner iterations x %d sweeps + %d data terms as one launch; FOTG_VR_LEVELPIPE=0 "
+                                           "runs one vr_sor_tile_kernel launch per call instead)" % (lvl, lw, lh, inner, op.var_ref_iter, inner - 1),
+                                 "achieved": alg_lp / (ms_lp * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_lp / (ms_lp * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": None, "algorithmic_bytes_per_launch": alg_lp, "ms_per_launch": ms_lp,
+                                 "level_pipe_launches_per_process": int(lib.fotg_debug_counter(b"level_pipe")),
+                                 "bound_by": "S = %d anti-diagonal steps of the first call + the lag of %d pipeline stages behind it" % (lw + lh - 1, inner * op.var_ref_iter + inner - 1)})
+    except Exception as e:
+        res["rooflines"].append({"unavailable": str(e)})
     # four pairs in flight (a 4K video: consecutive pairs, one per submit)
     D = 4
     pipe = FlowPipeline(op, ip, max_batch=1, depth=D, device=local)

@@ -64,6 +64,7 @@ struct FotgTune {
   int vr_stream;    // FOTG_VR_STREAM: 0 = resident-D kernel instead of the streaming solver
   int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
   int vr_levelpipe; // FOTG_VR_LEVELPIPE: 1 (default) = tall levels run all inner iterations as one pipeline launch (varref_levelpipe.hip.h); 0 = one tile-solver launch per sor_coupled call; + 16 x diagnosis bits
+  int lp_max_pairs; // pairs per launch up to which the level pipeline is used (contexts of a pipe: 4 / depth -- with more pairs resident the launch-per-stage path has the higher THROUGHPUT, the level pipeline the lower latency: measured)
   int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
   int vr_first_data; // FOTG_VR_FIRST_DATA: 0 = the first inner iteration's data term in a launch of its own (not in the set-up launch)
   int pyr_split;    // FOTG_PYR_SPLIT: launches the base pyramid kernel of a batch is cut into (1 = one launch)
@@ -251,6 +252,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
   c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
   c->tune.vr_levelpipe = env_int("FOTG_VR_LEVELPIPE", 1);
+  c->tune.lp_max_pairs = env_int("FOTG_VR_LEVELPIPE_MAX_PAIRS", 1 << 20);
   c->tune.vr_first_data = env_int("FOTG_VR_FIRST_DATA", 1);
   c->tune.vr_fused_nt = env_int("FOTG_VR_FUSED_NT", 1024);
   c->tune.pyr_split = env_int("FOTG_PYR_SPLIT", 1);
@@ -1019,7 +1021,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   // FOTG_VR_LEVELPIPE=1: the level's whole fixed-point loop as ONE pipeline launch behind the set-up launch (varref_levelpipe.hip.h).
   // At least two sweeps per call (what keeps a band's last sweep behind the data term of its neighbours), at most four (X buffers).
   const int ntr = (g.h + FOTG_TH - 1) / FOTG_TH;
-  const bool levelpipe = tiles && c->tune.vr_levelpipe && c->tune.vr_path == 0 && c->tune.vr_first_data && inner >= 1 && inner <= FOTG_LP_KMAX &&
+  const bool levelpipe = tiles && c->tune.vr_levelpipe && n <= c->tune.lp_max_pairs && c->tune.vr_path == 0 && c->tune.vr_first_data && inner >= 1 && inner <= FOTG_LP_KMAX &&
                          c->p.tv_solverit >= 2 && c->p.tv_solverit <= 4 && ntr <= c->lp_ntr && g.h <= 4096 &&
                          lp_tile_words(n) + lp_data_words(n, ntr) <= c->sync_total;
   if (levelpipe) { az.zsync_n = (int)(lp_tile_words(n) + lp_data_words(n, ntr)); }
@@ -1515,6 +1517,8 @@ int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int
     // at batch 64 with four in flight, at the price of ~5 % on a batch that runs alone -- which is why only pipes do it)
     if (depth > 1) q->ctx[k]->tune.pyr_split = env_int("FOTG_PIPE_PYR_SPLIT", 16);
     if (depth > 1) q->ctx[k]->tune.pyr_persist = env_int("FOTG_PIPE_PYR_PERSIST", 0);
+    // several batches in flight: the level pipeline (latency) only while few pairs are resident, the launch-per-stage path (throughput) beyond
+    if (depth > 1) q->ctx[k]->tune.lp_max_pairs = env_int("FOTG_PIPE_LEVELPIPE_MAX_PAIRS", 4 / depth > 1 ? 4 / depth : 1);
   }
   *out = q;
   return FOTG_OK;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Soak of the tile solver pipeline (vr_sor_tile_kernel: levels of more than 96 rows, workgroups handing diagonals over through
-memory behind progress words) WHILE a second context keeps HBM saturated with pyramid launches on a stream of its own -- the
+"""Soak of the tile solver / level pipeline (vr_level_pipe_kernel, the default; FOTG_VR_LEVELPIPE=0: vr_sor_tile_kernel: levels of more
+than 96 rows, workgroups handing diagonals over through memory behind progress words) WHILE a second context keeps HBM saturated with pyramid launches on a stream of its own -- the
 condition of the headline configuration (several batches in flight) for users of operating points 3 / 4.  Every call must
 equal the result computed on an idle GPU, and no bounded wait may time out.
 usage: python tools/soak_tiles.py [calls] [op-point] [width] [height] [batch]      (writes a summary line as JSON)"""
@@ -39,7 +39,7 @@ prs = [synth_pair(h, w, seed=90 + k) for k in range(nb)]
 I0 = torch.from_numpy(np.stack([q[0] for q in prs])).to(dev); I1 = torch.from_numpy(np.stack([q[1] for q in prs])).to(dev)
 ref = T.calc_batch(I0, I1).clone()
 torch.cuda.synchronize()
-before = lib().fotg_debug_counter(b"sor_tiles")
+before = lib().fotg_debug_counter(b"sor_tiles") + lib().fotg_debug_counter(b"level_pipe")
 out = T.new_outflow(nb)
 bad = 0
 t0 = time.perf_counter()
@@ -55,9 +55,9 @@ for k in range(0, calls, CH):
         print("calls", k, "..", k + CH, ": result differs, max abs", float((out - ref).abs().max()), flush=True)
 assert hip.hipStreamSynchronize(sD) == 0
 el = time.perf_counter() - t0
-tiles = lib().fotg_debug_counter(b"sor_tiles") - before
+tiles = lib().fotg_debug_counter(b"sor_tiles") + lib().fotg_debug_counter(b"level_pipe") - before     # launches with inter-workgroup waits (FOTG_VR_LEVELPIPE=0: one per sor_coupled call)
 res = {"tool": "tools/soak_tiles.py", "calls": calls, "op_point": oppt, "size": [w, h], "pairs_per_call": nb, "seconds": round(el, 1),
-       "tile_launches": int(tiles), "mismatching_checks": bad, "checks": calls // CH,
+       "tile_or_level_pipe_launches": int(tiles), "level_pipe": os.environ.get("FOTG_VR_LEVELPIPE", "1") != "0", "mismatching_checks": bad, "checks": calls // CH,
        "tile_timeouts": int(lib().fotg_ctx_counter(T._h, b"tile_timeouts")), "stalls_reported": int(lib().fotg_ctx_counter(T._h, b"stalls")),
        "disturber": "2 x fotg_pyramid_pair(batch 64, 1080p f32) per call on a second stream (HBM saturated)"}
 print(json.dumps(res))
