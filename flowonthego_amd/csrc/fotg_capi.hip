@@ -355,7 +355,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
         if (hipMemset(c->vrX[l], 0, xb) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
         if (!c->tileSync) {
           // (the first level that gets here is the finest = tallest one: its tile rows size the level-pipe words)
-          c->lp_ntr = (gl.h + FOTG_TH - 1) / FOTG_TH;
+          c->lp_ntr = (gl.h + FOTG_LP_TH - 1) / FOTG_LP_TH;
           const long lp = lp_tile_words((int)B) + lp_data_words((int)B, c->lp_ntr);
           c->sync_total = lp > tile_sync_words((int)B) ? lp : tile_sync_words((int)B);
           ALLOC(c->tileSync, (c->sync_total + 32) * sizeof(int));
@@ -1020,7 +1020,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   if (tiles) { az.zsync = c->tileSync; az.zsync_n = (int)tile_sync_words(n); }
   // FOTG_VR_LEVELPIPE=1: the level's whole fixed-point loop as ONE pipeline launch behind the set-up launch (varref_levelpipe.hip.h).
   // At least two sweeps per call (what keeps a band's last sweep behind the data term of its neighbours), at most four (X buffers).
-  const int ntr = (g.h + FOTG_TH - 1) / FOTG_TH;
+  const int ntr = (g.h + FOTG_LP_TH - 1) / FOTG_LP_TH;
   const bool levelpipe = tiles && c->tune.vr_levelpipe && n <= c->tune.lp_max_pairs && c->tune.vr_path == 0 && c->tune.vr_first_data && inner >= 1 && inner <= FOTG_LP_KMAX &&
                          c->p.tv_solverit >= 2 && c->p.tv_solverit <= 4 && ntr <= c->lp_ntr && g.h <= 4096 &&
                          lp_tile_words(n) + lp_data_words(n, ntr) <= c->sync_total;

@@ -39,6 +39,9 @@ struct LevelPipeArgs {
   int dbg;                                   // FOTG_VR_LEVELPIPE_DBG (diagnosis): 1 = the data term waits for the whole previous call, 2 = a call's first sweep for the whole data term
 };
 __host__ __device__ inline long lp_tile_words(int npairs) { return 32L * (1 + (long)npairs * FOTG_LP_KMAX * 4 * 64); }
+#ifndef FOTG_LP_TH
+#define FOTG_LP_TH 8                         // rows of a tile row of the data term (a multiple of FOTG_TH; FOTG_TILE_ROWS is a multiple of it)
+#endif
 #define FOTG_LP_DW 1                         // workgroups per tile row of the data term (tile tx goes to workgroup tx % FOTG_LP_DW)
 __host__ __device__ inline long lp_data_words(int npairs, int ntr) { return 32L * (long)npairs * FOTG_LP_KMAX * ntr * FOTG_LP_DW; }
 
@@ -75,12 +78,12 @@ __device__ __forceinline__ void lp_report_timeout(const TileArgs &g)
 template <int NOC>
 __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g, const LevelPipeArgs &q, int pair, int kc, int ty, int half, int nsweeps, int ticket)
 {
-  constexpr int MW = FOTG_LP_MW, NPX = MW / FOTG_TW;
-  constexpr int UW = MW + 4, UH = FOTG_TH + 4, SW = MW + 2, SH = FOTG_TH + 2;
+  constexpr int MW = FOTG_LP_MW, NPX = MW / FOTG_TW, NPY = FOTG_LP_TH / 8, NP = NPX * NPY;      // pixels per thread: NPX x NPY (32 x 8 threads)
+  constexpr int UW = MW + 4, UH = FOTG_LP_TH + 4, SW = MW + 2, SH = FOTG_LP_TH + 2;
   __shared__ float2 uv[UW * UH];
   __shared__ float sm[SW * SH];
   const int st = a.st, w = a.w, h = a.h, S = a.S;
-  const int y0 = ty * FOTG_TH;
+  const int y0 = ty * FOTG_LP_TH;
   const int lx = threadIdx.x % FOTG_TW, ly = threadIdx.x / FOTG_TW;
   const float *wx = a.single(pair, P_WX), *wy = a.single(pair, P_WY);
   const float2 *D = a.Dp(pair);
@@ -89,8 +92,8 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
   // it in 3.6 us -- one workgroup per row set the pace of every later stage.  Each publishes how far the row is done AS FAR AS IT
   // IS CONCERNED: behind its tile tx that is the end of tile tx + 1 (the other workgroup's); the row's progress is the minimum.
   int *const myprog = q.dprog + 32 * ((((long)pair * FOTG_LP_KMAX + kc) * q.ntr + ty) * FOTG_LP_DW + half);
-  // the last sweep of call kc - 1 in the bands whose rows this tile row reads (rows y0 - 2 .. y0 + FOTG_TH + 1)
-  const int blo = (y0 - 2 < 0 ? 0 : y0 - 2) / FOTG_TILE_ROWS, bhi0 = (y0 + FOTG_TH + 1) / FOTG_TILE_ROWS, bhi = bhi0 > g.NB - 1 ? g.NB - 1 : bhi0;
+  // the last sweep of call kc - 1 in the bands whose rows this tile row reads (rows y0 - 2 .. y0 + FOTG_LP_TH + 1)
+  const int blo = (y0 - 2 < 0 ? 0 : y0 - 2) / FOTG_TILE_ROWS, bhi0 = (y0 + FOTG_LP_TH + 1) / FOTG_TILE_ROWS, bhi = bhi0 > g.NB - 1 ? g.NB - 1 : bhi0;
   const int *const p0 = g.sync + 32 * (1 + ((pair * FOTG_LP_KMAX + kc - 1) * 4 + nsweeps - 1) * 64 + blo);
   const int *const p1 = g.sync + 32 * (1 + ((pair * FOTG_LP_KMAX + kc - 1) * 4 + nsweeps - 1) * 64 + bhi);
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)a.Cp(pair), 0, (int)((size_t)a.c_pair_stride * 16), 0x00020000);
@@ -102,7 +105,7 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
     const int x0 = tx * MW;
     // ---- wait: every cell this macro tile reads (its pixels +- 2) has its final value of iteration kc - 1
     {
-      const int dlast = x0 + MW - 1 + y0 + FOTG_TH - 1 + 2;
+      const int dlast = x0 + MW - 1 + y0 + FOTG_LP_TH - 1 + 2;
       const int need = (q.dbg & 1) ? 0x3ffffff0 : dlast < S - 1 ? dlast : S - 1;
       if ((threadIdx.x >> 6) == 0) {
         int spins = 0;
@@ -117,12 +120,12 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
       __syncthreads();
     }
     // this thread's NPX pixels (one per 32-pixel tile of the macro tile): their own inputs first, the loads overlap the staging below
-    PixIn<NOC> pin[NPX];
-    float2 duv[NPX];
-    bool inimg[NPX];
+    PixIn<NOC> pin[NP];
+    float2 duv[NP];
+    bool inimg[NP];
 #pragma unroll
-    for (int e = 0; e < NPX; ++e) {
-      const int i = x0 + e * FOTG_TW + lx, j = y0 + ly;
+    for (int e = 0; e < NP; ++e) {
+      const int i = x0 + (e % NPX) * FOTG_TW + lx, j = y0 + (e / NPX) * 8 + ly;
       inimg[e] = i < w && j < h;
       const int ic0 = inimg[e] ? i : 0, jc0 = inimg[e] ? j : 0;
       pin[e] = data_load<NOC>(a, pair, ic0, jc0);
@@ -142,10 +145,10 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < NPX; ++e) {
+    for (int e = 0; e < NP; ++e) {
       if (!inimg[e]) continue;
-      const int i = x0 + e * FOTG_TW + lx, j = y0 + ly;
-      const int sc = (ly + 1) * SW + (e * FOTG_TW + lx + 1);
+      const int i = x0 + (e % NPX) * FOTG_TW + lx, j = y0 + (e / NPX) * 8 + ly;
+      const int sc = ((e / NPX) * 8 + ly + 1) * SW + ((e % NPX) * FOTG_TW + lx + 1);
       const float s_o = sm[sc];
       const float hr = (i < w - 1) ? s_o + sm[sc + 1] : 0.0f;
       const float hl = (i > 0) ? sm[sc - 1] + s_o : 0.0f;
@@ -187,7 +190,9 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
   static_assert(U % P == 0 && P % G == 0 && U % G == 0 && U % RING == 0, "ring slots and barrier phase are compile-time");
   __shared__ float2 res_ring[RING][BR];
   __shared__ int seen_lds[4];                                     // own, below, top, data term (min over the band's tile rows)
-  __shared__ int dp_lds[8 * FOTG_LP_DW];                          // the band's data-term progress words (tile row x workgroup) as the poller last saw them
+  constexpr int NDW = (FOTG_TILE_ROWS / FOTG_LP_TH) * FOTG_LP_DW;       // data-term words of a band
+  static_assert(NDW <= 16 && FOTG_TILE_ROWS % FOTG_LP_TH == 0 && FOTG_LP_TH % 8 == 0, "one poll lane per word, row rotations over 16 lanes");
+  __shared__ int dp_lds[NDW];                          // the band's data-term progress words (tile row x workgroup) as the poller last saw them
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (wv == 3) return;                                            // (a barrier counts the waves that have not ended)
   const int S = a.S, RP = a.RP, RPD = a.RPD, h = a.h;
@@ -198,11 +203,11 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
   const int *const prog_top = b > 0 ? pw(kc, n, b - 1) : nullptr;
   // the data term of this call in the band's tile rows (first sweep of calls >= 1; the others follow the first sweep)
   const bool wdata = n == 0 && kc > 0;
-  const int ty0 = b * (BR / FOTG_TH), nty = (q.ntr - ty0) < BR / FOTG_TH ? (q.ntr - ty0) : BR / FOTG_TH;
+  const int ty0 = b * (BR / FOTG_LP_TH), nty = (q.ntr - ty0) < BR / FOTG_LP_TH ? (q.ntr - ty0) : BR / FOTG_LP_TH;
   const int *const dpw = q.dprog + 32 * ((((long)pair * FOTG_LP_KMAX + kc) * q.ntr + ty0) * FOTG_LP_DW);
   // what workgroup hh of tile row ty0 + r claims before it has finished a tile: the tiles in front of its first one are not its
   // business (hh = 1: "up to the end of tile 0"); and no tile row has cells on the diagonals above its first row
-  auto floor_of = [&](int r, int hh) { const int y0r = (ty0 + r) * FOTG_TH; const int own = hh * FOTG_LP_MW - 1 + y0r; const int none = y0r - 1; return hh > 0 && own > none ? own : none; };
+  auto floor_of = [&](int r, int hh) { const int y0r = (ty0 + r) * FOTG_LP_TH; const int own = hh * FOTG_LP_MW - 1 + y0r; const int none = y0r - 1; return hh > 0 && own > none ? own : none; };
   float2 *const Dlev = a.Dp(pair);
   float2 *const Xp = g.X + (size_t)pair * g.x_pair_stride;
   const float2 *const Xin = n == 0 ? Dlev : Xp + (size_t)(n - 1) * g.x_buf_stride;
@@ -215,7 +220,7 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
 
   if (threadIdx.x < 3) seen_lds[threadIdx.x] = (threadIdx.x == 0 ? prog_own : threadIdx.x == 1 ? prog_bel : prog_top) ? -1 : 0x3fffffff;
   if (threadIdx.x == 3) seen_lds[3] = wdata ? -1 : 0x3fffffff;
-  if (threadIdx.x >= 32 && threadIdx.x < 32 + 8 * FOTG_LP_DW) dp_lds[threadIdx.x - 32] = (wdata && ((int)threadIdx.x - 32) / FOTG_LP_DW < nty) ? -1 : 0x3fffffff;
+  if (threadIdx.x >= 32 && threadIdx.x < 32 + NDW) dp_lds[threadIdx.x - 32] = (wdata && ((int)threadIdx.x - 32) / FOTG_LP_DW < nty) ? -1 : 0x3fffffff;
   __syncthreads();
 
   // ======================================== poller wave ========================================
@@ -235,7 +240,7 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
         if (lane == 0) {
           int m = 0x3fffffff;
 #pragma unroll
-          for (int r = 0; r < 8 * FOTG_LP_DW; ++r) {
+          for (int r = 0; r < NDW; ++r) {
             int v = __hip_atomic_load(&dp_lds[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int fl = floor_of(r / FOTG_LP_DW, r % FOTG_LP_DW);
             v = v < fl ? fl : v;
