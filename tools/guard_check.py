@@ -34,3 +34,7 @@ run(1920, 1080, 3, 1, (a, b), fast=True)
 run(1920, 1080, 2, 1, (a, b), colour=True)
 f0, f1 = synth_pair(436, 1024, seed=3)
 run(1024, 436, 2, 1, (torch.from_numpy(f0).cuda()[None], torch.from_numpy(f1).cuda()[None]))
+f0, f1 = synth_pair(2160, 3840, seed=5)                 # BASELINE configs[3]: the level pipeline of the tall levels
+a, b = torch.from_numpy(f0).cuda()[None], torch.from_numpy(f1).cuda()[None]
+run(3840, 2160, 4, 1, (a, b))
+run(3840, 2160, 4, 1, (a, b), fast=True)
