@@ -72,6 +72,9 @@ __device__ __forceinline__ void lp_report_timeout(const TileArgs &g)
 // round of fixed latencies (poll of the producers' progress, the staging loads, the acknowledgement of the written-through system
 // cells: ~10 us) whatever its width, and the wavefront of the solver advances FOTG_LP_MW diagonals in 12.8 us -- with 32-pixel tiles
 // (3.2 us of wavefront each) the data term set the pace of the whole pipeline.
+#ifndef FOTG_LP_PQ
+#define FOTG_LP_PQ 2           // poll rounds (one per G diagonals) the poller wave keeps in flight before it waits for the oldest
+#endif
 #ifndef FOTG_LP_MW
 #define FOTG_LP_MW (1 * FOTG_TW)
 #endif
@@ -248,9 +251,9 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
           }
           __hip_atomic_store(&seen_lds[3], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // at most two intervals' polls in flight
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * FOTG_LP_PQ) : "memory");          // at most FOTG_LP_PQ intervals' polls in flight
       } else {
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // at most three intervals' polls in flight
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (FOTG_LP_PQ + 1)) : "memory");
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may land after the workgroup's LDS is released
@@ -309,9 +312,13 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
   const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void *)Xout, 0, (S + 1) * tpitch, 0x00020000);
   // (the system cells come from another workgroup of this launch: agent-scope loads, aux 16 = sc1)
   // (CSC1 = false: call 0, whose system was written by the set-up launch -- ordinary loads)
-  auto ld_c = [&](unsigned vo, unsigned so) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsC, vo, so, CSC1 ? 16 : 0)); };
-  auto ld_x = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) { return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 16)); };
-  auto ld_x2 = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 16)); };
+#ifndef FOTG_LP_EXP
+#define FOTG_LP_EXP 0          // timing-only builds (WRONG results): 2 system cells with ordinary loads in every call, 4 neighbour rows too
+#endif
+  constexpr int AUXC = (CSC1 && !(FOTG_LP_EXP & 2)) ? 16 : 0, AUXX = (FOTG_LP_EXP & 4) ? 0 : 16;
+  auto ld_c = [&](unsigned vo, unsigned so) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsC, vo, so, AUXC)); };
+  auto ld_x = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) { return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, AUXX)); };
+  auto ld_x2 = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, AUXX)); };
 
   int seen_own = prog_own ? -1 : 0x3fffffff, seen_bel = prog_bel ? -1 : 0x3fffffff, seen_top = prog_top ? -1 : 0x3fffffff, seen_dat = wdata ? -1 : 0x3fffffff;
   auto wait_for = [&](const int *p, int &seen, int need) __attribute__((always_inline)) {

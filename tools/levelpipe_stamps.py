@@ -32,6 +32,13 @@ for r in st:
     else:
         rows.append((r[0], "tile  k %d n %d b %d" % (kc, (r[2] >> 20) & 0x3ff, (r[2] >> 30) & 0x3ff), r))
 print("%d roles, whole launch %.1f us" % (len(rows), (st[:, 1].max() - t0) / 100))
+if os.environ.get("FOTG_STAMPS_BRIEF"):
+    # pace (us per step) of every call's first and last tile role over steps 0-512 / 512-1024 / 1024-end
+    for _, name, r in sorted(rows, key=lambda x: (x[2][2] >> 40) & 0xff):
+        if name.startswith("tile") and (name.endswith("n 0 b 0") or name.endswith("n 2 b 8") or name.endswith("n 0 b 4")):
+            t = [(x - t0) / 100 for x in (r[4], r[5], r[6], r[1])]
+            print("  %-20s first step %6.1f  pace %.3f %.3f %.3f  end %6.1f" % (name, t[0], (t[1] - t[0]) / 512, (t[2] - t[1]) / 512, (t[3] - t[2]) / 479, t[3]))
+    sys.exit(0)
 for _, name, r in sorted(rows, key=lambda x: (x[2][2] >> 40) & 0xff):
     if "data" in name and ((r[2] & 0xfffff) // 2) % 8 not in (0, 7):
         continue
