@@ -235,7 +235,7 @@ def roofline_lk(ofc, batch, stage_ms):
     return {"bound": "valu", "kernel": "fotg::lk_kernel<8,1,false,true,%s> (level %d: %d patches x %d evaluations x 64 px per pair)" % ("true,8" if lpp8 else "false,16", lvl, nop, evals),
             "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "useful_flops_per_launch": flops,
             "ms_per_launch": ms, "share_of_step": sum(v for k, v in stage_ms.items() if k.startswith("lk[")) / sum(stage_ms.values()),
-            "note": "useful flops only; the instruction stream is ~3-4x that (profiles/r04_pmc_valu.json: 330 VALU wave-instructions per EIGHT-patch "
+            "note": "useful flops only; the instruction stream is ~3-4x that (profiles/r05_pmc_valu.json: 330 VALU wave-instructions per EIGHT-patch "
                     "iteration with eight lanes per patch, 234 per four-patch iteration with sixteen); the launch retires one VALU wave-instruction per ~4.3 cycles and SIMD, where the hardware issues plain f32 / int adds "
                     "at 2.3 and selects, compares, DPP, conversions, packed f32 at 4.1-4.4 (profiles/r03_valu_issue_probe.json): about three quarters "
                     "of the issue rate of its mix"}
@@ -302,7 +302,7 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=
                          "note": ("useful flops only (16 per pixel-evaluation); tolerance mode: 91 VALU wave-instructions per four-patch iteration "
                                   "(profiles/r05_pmc_valu.json), VALU busy 87 %") if fast else
                                  ("useful flops only (16 per pixel-evaluation); the kernel is bound by the issue rate of its instruction stream (263 VALU "
-                                  "wave-instructions per four-patch iteration, profiles/r04_pmc_valu.json, retired at one per ~4.8 cycles and SIMD; five instead of "
+                                  "wave-instructions per four-patch iteration, profiles/r05_pmc_valu.json, retired at one per ~4.8 cycles and SIMD; five instead of "
                                   "three waves per SIMD do not speed it up: docs/EXPERIMENTS.md)")}]
     # one sor_coupled call of the finest level through the tile pipeline
     try:
