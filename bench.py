@@ -766,7 +766,7 @@ def main():
             # the whole path against the same roof: pairs/s x 16 654 080 B / 8 TB/s
             res["whole_path_hbm_frac"] = value / world * (2 * W * H * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS
             res["time_dominant_stage"] = max(st, key=st.get)
-            # the tolerance mode of the patch loop (fotg_params::fast_math, csrc/lk_fast.hip.h) on the headline workload -- NOT `value`
+            # the tolerance mode (fotg_params::fast_math: patch loop csrc/lk_fast.hip.h, data term csrc/varref_dataterm.inc.h) on the headline workload -- NOT `value`
             # (the default / parity mode): same steps, one batch at a time and in flight, with the endpoint error against the parity
             # mode's flows (which are bit-identical to the CPU oracle)
             opf = F.operating_point(OP_POINT, W, 1, sor_mode=a.sor_mode)
@@ -778,7 +778,7 @@ def main():
             ofc.calc_batch(I0, I1, None, out); ofcf.calc_batch(I0, I1, None, outf)
             ef = torch.cat([torch.sqrt(((ofcf.upsample_crop(outf[k:k + 8]) - ofc.upsample_crop(out[k:k + 8])) ** 2).sum(-1)).flatten() for k in range(0, a.batch, 8)])
             res["fast_math"] = {"value": a.batch / tff, "unit": "frame-pairs/s", "ms_per_step": tff * 1e3,
-                                "note": "fotg_params::fast_math = 1 (tolerance mode of the patch loop), one batch at a time; `value` above is the parity mode",
+                                "note": "fotg_params::fast_math = 1 (tolerance mode of the patch loop and of the refinement's data term), one batch at a time; `value` above is the parity mode",
                                 "lk_stage_ms": {k: round(v, 4) for k, v in stf.items() if k.startswith("lk[")},
                                 "lk_stage_ms_parity_mode": {k: round(v, 4) for k, v in st.items() if k.startswith("lk[")},
                                 "epe_vs_parity_mode_px": {"mean": float(ef.mean()), "p99": float(torch.quantile(ef[::64], 0.99)), "max": float(ef.max()),

@@ -881,15 +881,15 @@ static int fused_lds_bytes(const VrArgs &b, bool with_c)
   return 128 + (b.S + 2) * b.RPD * (int)sizeof(float2) + ((b.w * b.h + 3) / 4) * 16 + (with_c ? (b.SC * b.RP + 1) * 32 : 0);
 }
 
-template <int NOC, bool CL = false, bool RES = false, int NT = 512>
+template <int NOC, bool CL = false, bool RES = false, int NT = 512, bool FM = false>
 static bool launch_inner_fused(const VrArgs &b, int n, int inner, float qa, float hd, float hg, float omega, float *flow, long fs, hipStream_t s,
                                const float *I0, const float *I1, long img_stride, int tw, int pad)
 {
   constexpr int P = 8, U = 32;
   const int lds = fused_lds_bytes(b, CL);
   static int lds_set[32] = {0};
-  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, P, U, CL, RES, NT>), lds, lds_set)) return false;
-  vr_inner_fused_kernel<NOC, P, U, CL, RES, NT><<<n, NT, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
+  if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_inner_fused_kernel<NOC, P, U, CL, RES, NT, FM>), lds, lds_set)) return false;
+  vr_inner_fused_kernel<NOC, P, U, CL, RES, NT, FM><<<n, NT, lds, s>>>(b, inner, qa, hd, hg, omega, flow, fs, I0, I1, img_stride, tw, pad);
   return true;
 }
 
@@ -898,6 +898,9 @@ template <int NOC>
 static bool dispatch_inner_fused(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, int inner, float qa, float hd, float hg, float omega, float *flow,
                                  long fs, hipStream_t s, const float *I0, const float *I1, long img_stride, int tw, int pad, int taps)
 {
+  // (fast_math: the data term in the tolerance mode's arithmetic, varref_dataterm.inc.h)
+#define FOTG_FUSED(...) (c->p.fast_math ? launch_inner_fused<__VA_ARGS__, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad) \
+                                        : launch_inner_fused<__VA_ARGS__, false>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad))
   const int lds = fused_lds_bytes(a, false);
   // one workgroup does the per-pixel phases of its pair: only worth it for small levels (measured: 60x34 yes, 120x68 no)
   // (red-black has no dependency chain: its half-sweeps use all the workgroup's threads, and one launch per level beats
@@ -918,14 +921,14 @@ static bool dispatch_inner_fused(const fotg_ctx *c, const VrArgs &a, int n, int 
     // gray levels of <= 4 pixels per thread also keep their per-pixel inputs in registers over the loop
     if constexpr (NOC == 1) {
       // (levels of more than 1024 pixels: 1024 threads, two pixels each -- 4 waves per SIMD hide the latencies of the per-pixel phases)
-      if (c->tune.vr_fused_nt == 1024 && a.w * a.h > 1024 && a.w * a.h <= 2048 &&
-          launch_inner_fused<1, true, true, 1024>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
-      if (a.w * a.h <= 4 * 512 && launch_inner_fused<1, true, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
+      if (c->tune.vr_fused_nt == 1024 && a.w * a.h > 1024 && a.w * a.h <= 2048 && FOTG_FUSED(1, true, true, 1024)) return true;
+      if (a.w * a.h <= 4 * 512 && FOTG_FUSED(1, true, true, 512)) return true;
     }
-    if (launch_inner_fused<NOC, true>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad)) return true;
+    if (FOTG_FUSED(NOC, true, false, 512)) return true;
   }
 
-  return launch_inner_fused<NOC>(b, n, inner, qa, hd, hg, omega, flow, fs, s, I0, I1, img_stride, tw, pad);
+  return FOTG_FUSED(NOC, false, false, 512);
+#undef FOTG_FUSED
 }
 
 // FOTG_SOR_POINT (sor_coupled_slow_but_readable, a compatibility mode): the single-wave wavefront solver with the point update
@@ -1031,8 +1034,12 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     // (tune.vr_setup = 0: memset + the three plane-at-a-time launches; tests)
     // (the launch also builds the system of the first inner iteration unless tune.vr_first_data = 0)
     merged_first = c->tune.vr_first_data && inner > 0;
-    vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
-                                                                                       merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
+    if (c->p.fast_math)
+      vr_setup_kernel<NOC, 2, true><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
+                                                                                                  merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
+    else
+      vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
+                                                                                         merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
     LAUNCHCHK();
   } else {
     HIPCHK(hipMemsetAsync(a.D, 0, (size_t)n * a.d_pair_stride * sizeof(float2), s));      // image_erase(du), image_erase(dv) (:185-186)
@@ -1087,7 +1094,8 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   }
   for (int it = 0; it < inner; ++it) {
     if (!(it == 0 && merged_first)) {
-      vr_data_kernel<NOC><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(az, quarter_alpha, half_delta_over3, half_gamma_over3);
+      if (c->p.fast_math) vr_data_kernel<NOC, true><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(az, quarter_alpha, half_delta_over3, half_gamma_over3);
+      else vr_data_kernel<NOC><<<dim3(((g.w + FOTG_TW - 1) / FOTG_TW) * ((g.h + FOTG_TH - 1) / FOTG_TH), n), 256, 0, s>>>(az, quarter_alpha, half_delta_over3, half_gamma_over3);
       LAUNCHCHK();
     }
     if (c->p.tv_solverit > 0) {

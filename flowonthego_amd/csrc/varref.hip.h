@@ -192,13 +192,13 @@ __global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
 // entries outside the image hold the values of the clamped coordinate, exactly what the reference's replicate indexing
 // reads, and the 5-tap helpers index the LDS tiles through pointers biased to global coordinates.
 // (defined behind the data term: the first inner iteration's system, computed by the set-up launch itself)
-template <int NOC, int NCH>
+template <int NOC, int NCH, bool FM>
 __device__ __forceinline__ void first_data_term(const VrArgs &a, int pair, int tx0, int ty0, const float *__restrict__ flow, long flow_stride,
                                                 float quarter_alpha, float half_delta_over3, float half_gamma_over3);
 
 // first_data != 0 (flow mode): the launch also builds the system of the FIRST inner iteration (du = dv = 0), i.e. what
 // vr_data_kernel would do next -- one launch and one read of the planes less per level.
-template <int NOC, int NCH = 2>
+template <int NOC, int NCH = 2, bool FM = false>
 __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__restrict__ I0, const float *__restrict__ I1,
                                                        long img_stride, int tw, int pad,
                                                        const float *__restrict__ flow, long flow_stride, int zero_d = 0,
@@ -262,22 +262,9 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
   if constexpr (NCH == 2) {
     if (first_data) {
       __syncthreads();                                           // the planes of the tile's pixels are in memory (stores of this workgroup)
-      first_data_term<NOC, NCH>(a, pair, tx0, ty0, flow, flow_stride, quarter_alpha, half_delta_over3, half_gamma_over3);
+      first_data_term<NOC, NCH, FM>(a, pair, tx0, ty0, flow, flow_stride, quarter_alpha, half_delta_over3, half_gamma_over3);
     }
   }
-}
-
-__device__ __forceinline__ float smooth_w(float2 l, float2 c, float2 r, float2 t, float2 b, int j, int h, float quarter_alpha)
-{
-  const float c0 = -0.5f, c1 = -0.0f, c2 = 0.5f;
-  const float ux = c0 * l.x + c1 * c.x + c2 * r.x;
-  const float vx = c0 * l.y + c1 * c.y + c2 * r.y;
-  float uy, vy;
-  if (j == 0) { uy = (c0 + c1) * c.x + c2 * b.x; vy = (c0 + c1) * c.y + c2 * b.y; }
-  else if (j == h - 1) { uy = c0 * t.x + (c1 + c2) * c.x; vy = c0 * t.y + (c1 + c2) * c.y; }
-  else { uy = c0 * t.x + c1 * c.x + c2 * b.x; vy = c0 * t.y + c1 * c.y + c2 * b.y; }
-  const float eps = 0.001f * 0.001f;
-  return quarter_alpha / sqrtf(ux * ux + uy * uy + vx * vx + vy * vy + eps);
 }
 
 // Everything compute_data / sub_laplacian read from global memory for one pixel, gathered up front so callers can
@@ -315,127 +302,49 @@ __device__ __forceinline__ PixIn<NOC> data_load(const VrArgs &a, int pair, int i
   return p;
 }
 
-// compute_data (:310-438) + sub_laplacian (:172-199) + the 2x2 block inverse of sor_coupled's first sweep
-// (solver.c:115-120) for pixel (i,j), given the four smoothness pair sums and (du,dv); writes the skewed system cell.
-template <int NOC>
+// smooth_w() and data_term_cell() in the two arithmetics of the library (varref_dataterm.inc.h): the reference's operation by
+// operation (parity mode) and, for fotg_params::fast_math, with v_rcp / v_rsq instead of IEEE divisions and square roots (tolerance mode)
+#define FOTG_DT_FAST 0
+#define FOTG_DT_NAME(x) x##_exact
+#include "varref_dataterm.inc.h"
+#undef FOTG_DT_FAST
+#undef FOTG_DT_NAME
+#define FOTG_DT_FAST 1
+#define FOTG_DT_NAME(x) x##_fast
+#include "varref_dataterm.inc.h"
+#undef FOTG_DT_FAST
+#undef FOTG_DT_NAME
+template <bool FM = false>
+__device__ __forceinline__ float smooth_w(float2 l, float2 c, float2 r, float2 t, float2 b, int j, int h, float quarter_alpha)
+{
+  if constexpr (FM) return smooth_w_fast(l, c, r, t, b, j, h, quarter_alpha);
+  else return smooth_w_exact(l, c, r, t, b, j, h, quarter_alpha);
+}
+template <int NOC, bool FM = false>
 __device__ __forceinline__ void data_term_cell(const VrArgs &a, int i, int j, const PixIn<NOC> &p, float hr, float hl, float vb, float vt,
                                                float u, float v, float half_delta_over3, float half_gamma_over3, float4 &c0, float4 &c1)
 {
-  const int w = a.w, h = a.h;
-  // compute_data (:310-438)
-  const float dnorm = 0.1f * 0.1f, epsc = 0.001f * 0.001f, epsg = 0.001f * 0.001f;
-  const float m = p.m;
-  float A11 = 0, A12 = 0, A22 = 0, B1 = 0, B2 = 0;
-  if constexpr (NOC == 1) {
-    const float Ix = p.Ix[0], Iy = p.Iy[0], Iz = p.Iz[0], Ixx = p.Ixx[0], Ixy = p.Ixy[0], Iyy = p.Iyy[0], Ixz = p.Ixz[0], Iyz = p.Iyz[0];
-    float tmp, tmp2, n1, n2;
-    if (half_delta_over3) {
-      tmp = Iz + Ix * u + Iy * v;
-      n1 = Ix * Ix + Iy * Iy + dnorm;
-      tmp = m * half_delta_over3 / sqrtf(3 * tmp * tmp / n1 + epsc);
-      tmp /= n1;
-      A11 += tmp * Ix * Ix;
-      A12 += tmp * Ix * Iy;
-      A22 += tmp * Iy * Iy;
-      B1 -= tmp * Iz * Ix;
-      B2 -= tmp * Iz * Iy;
-    }
-    n1 = Ixx * Ixx + Ixy * Ixy + dnorm;
-    n2 = Iyy * Iyy + Ixy * Ixy + dnorm;
-    tmp = Ixz + Ixx * u + Ixy * v;
-    tmp2 = Iyz + Ixy * u + Iyy * v;
-    tmp = m * half_gamma_over3 / sqrtf(3 * tmp * tmp / n1 + 3 * tmp2 * tmp2 / n2 + epsg);
-    tmp2 = tmp / n2; tmp /= n1;
-    A11 += tmp * Ixx * Ixx + tmp2 * Ixy * Ixy;
-    A12 += tmp * Ixx * Ixy + tmp2 * Ixy * Iyy;
-    A22 += tmp2 * Iyy * Iyy + tmp * Ixy * Ixy;
-    B1 -= tmp * Ixx * Ixz + tmp2 * Ixy * Iyz;
-    B2 -= tmp2 * Iyy * Iyz + tmp * Ixy * Ixz;
-    A11 *= 3; A12 *= 3; A22 *= 3; B1 *= 3; B2 *= 3;       // :420-426
-  } else {
-    float ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      ix[c] = p.Ix[c]; iy[c] = p.Iy[c]; iz[c] = p.Iz[c]; ixx[c] = p.Ixx[c]; ixy[c] = p.Ixy[c]; iyy[c] = p.Iyy[c];
-      ixz[c] = p.Ixz[c]; iyz[c] = p.Iyz[c];
-    }
-    if (half_delta_over3) {
-      float t[3], n[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { t[c] = iz[c] + ix[c] * u + iy[c] * v; n[c] = ix[c] * ix[c] + iy[c] * iy[c] + dnorm; }
-      float tmp = m * half_delta_over3 / sqrtf(t[0] * t[0] / n[0] + t[1] * t[1] / n[1] + t[2] * t[2] / n[2] + epsc);
-      const float k2 = tmp / n[2], k1 = tmp / n[1], k0 = tmp / n[0];
-      const float k[3] = {k0, k1, k2};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        A11 += k[c] * ix[c] * ix[c]; A12 += k[c] * ix[c] * iy[c]; A22 += k[c] * iy[c] * iy[c];
-        B1 -= k[c] * iz[c] * ix[c];  B2 -= k[c] * iz[c] * iy[c];
-      }
-    }
-    float n1[3], n2[3], t1[3], t2[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      n1[c] = ixx[c] * ixx[c] + ixy[c] * ixy[c] + dnorm; n2[c] = iyy[c] * iyy[c] + ixy[c] * ixy[c] + dnorm;
-      t1[c] = ixz[c] + ixx[c] * u + ixy[c] * v;           t2[c] = iyz[c] + ixy[c] * u + iyy[c] * v;
-    }
-    const float tmp = m * half_gamma_over3 / sqrtf(t1[0] * t1[0] / n1[0] + t2[0] * t2[0] / n2[0] + t1[1] * t1[1] / n1[1] +
-                                                   t2[1] * t2[1] / n2[1] + t1[2] * t1[2] / n1[2] + t2[2] * t2[2] / n2[2] + epsg);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float ka = tmp / n1[c], kb = tmp / n2[c];
-      A11 += ka * ixx[c] * ixx[c] + kb * ixy[c] * ixy[c];
-      A12 += ka * ixx[c] * ixy[c] + kb * ixy[c] * iyy[c];
-      A22 += kb * iyy[c] * iyy[c] + ka * ixy[c] * ixy[c];
-      B1 -= ka * ixx[c] * ixz[c] + kb * ixy[c] * iyz[c];
-      B2 -= kb * iyy[c] * iyz[c] + ka * ixy[c] * ixz[c];
-    }
-  }
-
-  // sub_laplacian (:172-199) for b1 (src wx) and b2 (src wy): -left, +right, -top, +bottom
-  if (i > 0)     { B1 -= hl * p.dxl(); B2 -= hl * p.dyl(); }
-  if (i < w - 1) { B1 += hr * p.dxr(); B2 += hr * p.dyr(); }
-  if (j > 0)     { B1 -= vt * p.dxt(); B2 -= vt * p.dyt(); }
-  if (j < h - 1) { B1 += vb * p.dxb(); B2 += vb * p.dyb(); }
-
-  if (a.point) {
-    // sor_coupled_slow_but_readable (solver.c:19-72) keeps the system as it is: A11 + sum_dpsis, A12, A22 + sum_dpsis with
-    // sum_dpsis accumulated top, left, bottom, right from 0 (:31-55)
-    float sum = 0.0f;
-    if (j > 0) sum += vt;
-    if (i > 0) sum += hl;
-    if (j < h - 1) sum += vb;
-    if (i < w - 1) sum += hr;
-    c0 = make_float4(A11 + sum, A12, B1, B2);
-    c1 = make_float4(A22 + sum, hr, vb, vt);
-    return;
-  }
-  // first sweep of sor_coupled inverts the 2x2 block (solver.c:115-120): dpsis = hl+hr(+vt)(+vb)
-  float dps = hl + hr;
-  if (j > 0) dps = dps + vt;
-  if (j < h - 1) dps = dps + vb;
-  const float M11 = A22 + dps, M22 = A11 + dps;
-  const float det = M11 * M22 - A12 * A12;
-  c0 = make_float4(M11 / det, A12 / -det, B1, B2);             // cell layout: (a11', a12', b1, b2 | a22', psi_r, psi_b, psi_t)
-  c1 = make_float4(M22 / det, hr, vb, vt);
+  if constexpr (FM) data_term_cell_fast<NOC>(a, i, j, p, hr, hl, vb, vt, u, v, half_delta_over3, half_gamma_over3, c0, c1);
+  else data_term_cell_exact<NOC>(a, i, j, p, hr, hl, vb, vt, u, v, half_delta_over3, half_gamma_over3, c0, c1);
 }
 
-template <int NOC>
+template <int NOC, bool FM = false>
 __device__ __forceinline__ void data_term_compute(const VrArgs &a, int pair, int i, int j, const PixIn<NOC> &p, float hr, float hl,
                                                   float vb, float vt, float u, float v, float half_delta_over3, float half_gamma_over3)
 {
   float4 c0, c1;
-  data_term_cell<NOC>(a, i, j, p, hr, hl, vb, vt, u, v, half_delta_over3, half_gamma_over3, c0, c1);
+  data_term_cell<NOC, FM>(a, i, j, p, hr, hl, vb, vt, u, v, half_delta_over3, half_gamma_over3, c0, c1);
   float4 *C = a.Cp(pair) + a.cidx(i, j);
   C[0] = c0;
   C[1] = c1;
 }
 
-template <int NOC>
+template <int NOC, bool FM = false>
 __device__ __forceinline__ void data_term_pixel(const VrArgs &a, int pair, int i, int j, float hr, float hl, float vb, float vt,
                                                 float u, float v, float half_delta_over3, float half_gamma_over3)
 {
   const PixIn<NOC> p = data_load<NOC>(a, pair, i, j);
-  data_term_compute<NOC>(a, pair, i, j, p, hr, hl, vb, vt, u, v, half_delta_over3, half_gamma_over3);
+  data_term_compute<NOC, FM>(a, pair, i, j, p, hr, hl, vb, vt, u, v, half_delta_over3, half_gamma_over3);
 }
 
 // One workgroup = one 32x8 pixel tile.  (uu,vv) of the tile + 2-pixel halo and the smoothness weight s of the tile +
@@ -443,7 +352,7 @@ __device__ __forceinline__ void data_term_pixel(const VrArgs &a, int pair, int i
 // per pixel instead of 13x.
 #define FOTG_TW 32
 #define FOTG_TH 8
-template <int NOC>
+template <int NOC, bool FM = false>
 __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_alpha, float half_delta_over3, float half_gamma_over3)
 {
   constexpr int UW = FOTG_TW + 4, UH = FOTG_TH + 4, SW = FOTG_TW + 2, SH = FOTG_TH + 2;
@@ -478,7 +387,7 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_al
   for (int k = threadIdx.x; k < SW * SH; k += 256) {
     const int sy = k / SW, sx = k % SW;
     const int c = (sy + 1) * UW + (sx + 1);
-    sm[k] = smooth_w(uv[c - 1], uv[c], uv[c + 1], uv[c - UW], uv[c + UW], y0 - 1 + sy, h, quarter_alpha);
+    sm[k] = smooth_w<FM>(uv[c - 1], uv[c], uv[c + 1], uv[c - UW], uv[c + UW], y0 - 1 + sy, h, quarter_alpha);
   }
   __syncthreads();
   if (i >= w || j >= h) return;
@@ -490,13 +399,13 @@ __global__ __launch_bounds__(256) void vr_data_kernel(VrArgs a, float quarter_al
   const float vb = (j < h - 1) ? s_o + sm[sc + SW] : 0.0f;
   const float vt = (j > 0) ? sm[sc - SW] + s_o : 0.0f;
 
-  data_term_compute<NOC>(a, pair, i, j, pin, hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
+  data_term_compute<NOC, FM>(a, pair, i, j, pin, hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
 }
 
 // vr_data_kernel's work for the first inner iteration of a level, on the tile of a set-up workgroup (same 32 x 8 tiles): (du,dv) is
 // zero, so (uu,vv) = (wx + 0, wy + 0) with (wx,wy) straight from the incoming flow (the neighbours' wx / wy planes belong to other
 // workgroups of this launch and may not be written yet; same values), the planes of the tile's own pixels from global memory.
-template <int NOC, int NCH>
+template <int NOC, int NCH, bool FM>
 __device__ __forceinline__ void first_data_term(const VrArgs &a, int pair, int x0, int y0, const float *__restrict__ flow, long flow_stride,
                                                 float quarter_alpha, float half_delta_over3, float half_gamma_over3)
 {
@@ -516,7 +425,7 @@ __device__ __forceinline__ void first_data_term(const VrArgs &a, int pair, int x
   for (int k = threadIdx.x; k < SW * SH; k += 256) {
     const int sy = k / SW, sx = k % SW;
     const int c = (sy + 1) * UW + (sx + 1);
-    sm[k] = smooth_w(uv[c - 1], uv[c], uv[c + 1], uv[c - UW], uv[c + UW], y0 - 1 + sy, h, quarter_alpha);
+    sm[k] = smooth_w<FM>(uv[c - 1], uv[c], uv[c + 1], uv[c - UW], uv[c + UW], y0 - 1 + sy, h, quarter_alpha);
   }
   __syncthreads();
   if (i >= w || j >= h) return;
@@ -537,7 +446,7 @@ __device__ __forceinline__ void first_data_term(const VrArgs &a, int pair, int x
   const float2 wc = W(i, j), wl = W(i > 0 ? i - 1 : i, j), wr = W(i < w - 1 ? i + 1 : i, j), wt = W(i, j > 0 ? j - 1 : j), wb = W(i, j < h - 1 ? j + 1 : j);
   p.wxc = wc.x; p.wxl = wl.x; p.wxr = wr.x; p.wxt = wt.x; p.wxb = wb.x;
   p.wyc = wc.y; p.wyl = wl.y; p.wyr = wr.y; p.wyt = wt.y; p.wyb = wb.y;
-  data_term_compute<NOC>(a, pair, i, j, p, hr, hl, vb, vt, 0.f, 0.f, half_delta_over3, half_gamma_over3);
+  data_term_compute<NOC, FM>(a, pair, i, j, p, hr, hl, vb, vt, 0.f, 0.f, half_delta_over3, half_gamma_over3);
 }
 
 // one pixel update of sor_coupled (solver.c:122-130 etc.).  du_l/du_t are the NEW left/top values, du_r/du_b the OLD
@@ -1120,7 +1029,8 @@ __device__ __forceinline__ void rb_sweeps_lds(const VrArgs &a, int pair, int swe
 // solver waves of the same workgroup.  Replaces 2*inner + 2 launches (and the LDS copy-in/out of D) per level.
 // CL (barrier-stepped waves only): the system cells C stay in LDS too -- the data phase writes them there and the solver
 // waves read them with ds_read_b128, so nothing but the level's input planes crosses the CU boundary inside the loop.
-template <int NOC, int P, int U, bool CL, bool RES = false, int NT = 512>
+// FM: the data term in the tolerance mode's arithmetic (fotg_params::fast_math, varref_dataterm.inc.h)
+template <int NOC, int P, int U, bool CL, bool RES = false, int NT = 512, bool FM = false>
 __global__ __launch_bounds__(NT) void vr_inner_fused_kernel(VrArgs a, int inner, float quarter_alpha, float half_delta_over3,
                                                              float half_gamma_over3, float omega, float *__restrict__ flow, long flow_stride,
                                                              const float *__restrict__ I0, const float *__restrict__ I1, long img_stride, int tw, int pad)
@@ -1234,7 +1144,7 @@ __global__ __launch_bounds__(NT) void vr_inner_fused_kernel(VrArgs a, int inner,
         const int ct = (f & (1 << 27)) ? c - RPD - 1 : c, cb = (f & (1 << 28)) ? c + RPD + 1 : c;
         const float2 d0 = lds_d_ld(c), dl = lds_d_ld(cl), dr = lds_d_ld(cr), dt = lds_d_ld(ct), db = lds_d_ld(cb);
         const int px = f & 0xFFFFFF, j = (f & (1 << 27)) ? ((f & (1 << 28)) ? 1 : h - 1) : 0;   // smooth_w only tests j == 0 / j == h-1
-        sm[px] = smooth_w(make_float2(r.wxl + dl.x, r.wyl + dl.y), make_float2(r.wxc + d0.x, r.wyc + d0.y), make_float2(r.wxr + dr.x, r.wyr + dr.y),
+        sm[px] = smooth_w<FM>(make_float2(r.wxl + dl.x, r.wyl + dl.y), make_float2(r.wxc + d0.x, r.wyc + d0.y), make_float2(r.wxr + dr.x, r.wyr + dr.y),
                           make_float2(r.wxt + dt.x, r.wyt + dt.y), make_float2(r.wxb + db.x, r.wyb + db.y), j, h, quarter_alpha);
       }
     } else
@@ -1267,7 +1177,7 @@ __global__ __launch_bounds__(NT) void vr_inner_fused_kernel(VrArgs a, int inner,
           const float2 d = lds_d_ld((ic[t] + jc[t]) * RPD + jc[t]);
           uvv[t] = make_float2(gx[q][t] + d.x, gy[q][t] + d.y);  // (uu,vv) = (wx+du, wy+dv)
         }
-        sm[j * w + i] = smooth_w(uvv[1], uvv[0], uvv[2], uvv[3], uvv[4], j, h, quarter_alpha);
+        sm[j * w + i] = smooth_w<FM>(uvv[1], uvv[0], uvv[2], uvv[3], uvv[4], j, h, quarter_alpha);
       }
     }
     __syncthreads();
@@ -1286,7 +1196,7 @@ __global__ __launch_bounds__(NT) void vr_inner_fused_kernel(VrArgs a, int inner,
         // data_term_cell only tests i > 0, i < w-1, j > 0, j < h-1: hand it border-equivalent coordinates
         const int ii = (f & (1 << 25)) ? ((f & (1 << 26)) ? 1 : w - 1) : 0, jj = (f & (1 << 27)) ? ((f & (1 << 28)) ? 1 : h - 1) : 0;
         float4 c0, c1;
-        data_term_cell<NOC>(a, ii, jj, rp[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3, c0, c1);
+        data_term_cell<NOC, FM>(a, ii, jj, rp[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3, c0, c1);
         lc[plc[q]] = c0;
         lc[plc[q] + a.SC * a.RP + 1] = c1;
       }
@@ -1311,11 +1221,11 @@ __global__ __launch_bounds__(NT) void vr_inner_fused_kernel(VrArgs a, int inner,
         const float2 duv = lds_d_ld((i + j) * RPD + j);
         if constexpr (CL) {
           float4 c0, c1;
-          data_term_cell<NOC>(a, i, j, pin[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3, c0, c1);
+          data_term_cell<NOC, FM>(a, i, j, pin[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3, c0, c1);
           lc[(i + j) * a.RP + j] = c0;
           lc[(i + j) * a.RP + j + a.SC * a.RP + 1] = c1;
         } else {
-          data_term_compute<NOC>(a, pair, i, j, pin[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
+          data_term_compute<NOC, FM>(a, pair, i, j, pin[q], hr, hl, vb, vt, duv.x, duv.y, half_delta_over3, half_gamma_over3);
         }
       }
     }

@@ -78,7 +78,7 @@ __device__ __forceinline__ void lp_report_timeout(const TileArgs &g)
 #ifndef FOTG_LP_MW
 #define FOTG_LP_MW (1 * FOTG_TW)
 #endif
-template <int NOC>
+template <int NOC, bool FM>
 __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g, const LevelPipeArgs &q, int pair, int kc, int ty, int half, int nsweeps, int ticket)
 {
   constexpr int MW = FOTG_LP_MW, NPX = MW / FOTG_TW, NPY = FOTG_LP_TH / 8, NP = NPX * NPY;      // pixels per thread: NPX x NPY (32 x 8 threads)
@@ -144,7 +144,7 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
     for (int k = threadIdx.x; k < SW * SH; k += 256) {
       const int sy = k / SW, sx = k % SW;
       const int c = (sy + 1) * UW + (sx + 1);
-      sm[k] = smooth_w(uv[c - 1], uv[c], uv[c + 1], uv[c - UW], uv[c + UW], y0 - 1 + sy, h, q.quarter_alpha);
+      sm[k] = smooth_w<FM>(uv[c - 1], uv[c], uv[c + 1], uv[c - UW], uv[c + UW], y0 - 1 + sy, h, q.quarter_alpha);
     }
     __syncthreads();
 #pragma unroll
@@ -158,7 +158,7 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
       const float vb = (j < h - 1) ? s_o + sm[sc + SW] : 0.0f;
       const float vt = (j > 0) ? sm[sc - SW] + s_o : 0.0f;
       float4 c0, c1;
-      data_term_cell<NOC>(a, i, j, pin[e], hr, hl, vb, vt, duv[e].x, duv[e].y, q.half_delta_over3, q.half_gamma_over3, c0, c1);
+      data_term_cell<NOC, FM>(a, i, j, pin[e], hr, hl, vb, vt, duv[e].x, duv[e].y, q.half_delta_over3, q.half_gamma_over3, c0, c1);
       const unsigned off = (unsigned)(a.cidx(i, j) * 16);
       const v4u u0 = {__float_as_uint(c0.x), __float_as_uint(c0.y), __float_as_uint(c0.z), __float_as_uint(c0.w)};
       const v4u u1 = {__float_as_uint(c1.x), __float_as_uint(c1.y), __float_as_uint(c1.z), __float_as_uint(c1.w)};
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   if (kc >= q.K) return;
   if (q.stamps && threadIdx.x == 0) { q.stamps[(long)t * 8] = wall_clock64(); q.stamps[(long)t * 8 + 2] = ((long long)(isdata ? 1 : 0) << 60) | ((long long)kc << 40) | idx; }
   if (isdata) {
-    lp_data_role<NOC>(a, g, q, pair, kc, idx / FOTG_LP_DW, idx % FOTG_LP_DW, nsweeps, t);
+    lp_data_role<NOC, FMA>(a, g, q, pair, kc, idx / FOTG_LP_DW, idx % FOTG_LP_DW, nsweeps, t);
     if (q.stamps && threadIdx.x == 0) q.stamps[(long)t * 8 + 1] = wall_clock64();
     return;
   }

@@ -48,7 +48,7 @@ class opt_params:
     use_fbcon: bool = False          # kroeger/oflow.h:44 usefbcon: forward-backward merge in the densification
     depth_mode: bool = False         # kroeger SELECTMODE=2 (run_DE_*): stereo depth, one displacement channel
     u8_color: int = 0                # channels == 1 only: 8-bit frames arrive with 3 channels (1: B,G,R as cv::imread delivers, 2: R,G,B), gray on load (kroeger/run_dense.cpp:199-209)
-    fast_math: bool = False          # tolerance mode of the patch loop (fotg_params::fast_math, csrc/lk_fast.hip.h); False = parity mode
+    fast_math: bool = False          # tolerance mode of the patch loop and the refinement's arithmetic (fotg_params::fast_math); False = parity mode
     min_iter: int = -1               # kroeger optparam.min_iter (oflow.h:38); < 0: = grad_descent_iter, as src/ and the operating points have it
     # derived (src/oflow.cpp:45-48)
     outlier_thresh: float = 0.0

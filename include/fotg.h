@@ -80,7 +80,10 @@ typedef struct fotg_params {
                           multiply-adds, free reduction order and a precomputed inverse Hessian (csrc/lk_fast.hip.h): about a third
                           of the instructions, flows within the north star's 1e-3 px mean endpoint error of the parity mode (the
                           tests state the measured distances).  Applies to L2 cost, min_iter == max_iter, res_thresh <= 0, optical
-                          flow -- every operating point; other configurations run the exact kernel regardless. */
+                          flow -- every operating point; other configurations run the exact patch kernel regardless.  The
+                          refinement's cell update (solvers of levels of more than 64 rows) uses fused multiply-adds and its data term
+                          (compute_data / compute_smoothness, FDF1.0.1/opticalflow_aux.c:123-165,310-438) v_rcp / v_rsq instead of
+                          the IEEE divisions and square roots (csrc/varref_dataterm.inc.h), optical flow only. */
 } fotg_params;
 
 typedef struct fotg_ctx fotg_ctx;

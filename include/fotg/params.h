@@ -53,7 +53,7 @@ typedef struct {
   int min_iter = -1; // kroeger optparam.min_iter (oflow.h:38); < 0: = grad_descent_iter (src/ and the operating points)
   int u8_color = 0;  // channels = 1 only: the 8-bit entry points take 3-channel frames (1: B,G,R as cv::imread delivers, 2: R,G,B) and
                      // convert to gray on load like cv::imread(IMREAD_GRAYSCALE) (kroeger/run_dense.cpp:199-209); fotg_params::u8_color
-  bool fast_math = false; // tolerance mode of the patch loop (fotg_params::fast_math): ~3x fewer instructions, flows within 1e-3 px (mean) of the parity mode
+  bool fast_math = false; // tolerance mode of the patch loop and the refinement's arithmetic (fotg_params::fast_math): flows within 1e-3 px (mean) of the parity mode
 } opt_params;
 
 inline fotg_params to_fotg(const opt_params &op)

@@ -1,4 +1,5 @@
-"""fast_math (fotg_params::fast_math, csrc/lk_fast.hip.h): the tolerance mode of the patch loop.  NOT bit-identical to the oracle by
+"""fast_math (fotg_params::fast_math): the tolerance mode of the patch loop (csrc/lk_fast.hip.h), of the refinement's data term
+(csrc/varref_dataterm.inc.h) and of the tall-level solvers' cell update.  NOT bit-identical to the oracle by
 design -- the north star's bound is a mean endpoint error of 1e-3 px against the kroeger CPU result.  These tests state the bound
 (mean EPE <= 1e-3 px on the full-resolution flow) on BASELINE configs[0]-[3] and print mean / p99 / max; the parity mode
 (tests/test_gpu_parity.py, ==) is untouched by the switch."""
@@ -6,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import synth_pair
-from test_gpu_parity import _mods, dev, epe, frames, oracle_params
+from test_gpu_parity import _mods, dev, epe, frames, load_fdf, oracle_params
 
 pytestmark = pytest.mark.gpu
 
@@ -136,13 +137,18 @@ def test_fast_math_patch_stage_against_the_oracle(case, op_point, alley):
 
 
 def test_fast_math_falls_back_to_the_exact_kernel(alley):
-    """configurations the fast kernel does not cover run the exact one with fast_math set: other cost functions, early termination
-    (min_iter < max_iter), depth mode -- bit-identical to the parity mode"""
+    """configurations the fast patch kernel does not cover run the exact one with fast_math set: other cost functions, early
+    termination (min_iter < max_iter) -- the patch stage (refinement off) is bit-identical to the parity mode; with the refinement,
+    whose data term and solvers have a tolerance-mode arithmetic of their own, the flows agree within the tolerance"""
     F, OFClass, _, O = _mods()
     f0, f1, _ = frames("alley", alley)
     for kw in ({"cost_func": 1}, {"min_iter": 3}):
-        (ex_lo, _), (fa_lo, _) = fast_and_exact(F, OFClass, f0, f1, 2, **kw)
+        (ex_lo, _), (fa_lo, _) = fast_and_exact(F, OFClass, f0, f1, 2, refine=False, **kw)
         assert np.array_equal(ex_lo, fa_lo), kw
+        (_, ex_full), (_, fa_full) = fast_and_exact(F, OFClass, f0, f1, 2, **kw)
+        mean, p99, mx = stats(fa_full[0], ex_full[0])
+        print("%s with refinement, fast_math vs parity mode: mean %.3g  p99 %.3g  max %.3g px" % (kw, mean, p99, mx))
+        assert mean <= TOL_MEAN
 
 
 @pytest.mark.parametrize("case,op_point,kw", [("alley_rgb", 2, {}), ("synth_rgb", 3, {}), ("alley", 2, {"patch_size": 4, "patch_stride": 0.5}),
@@ -203,3 +209,34 @@ def test_fast_math_large_motion_leaves_the_small_window():
     assert np.array_equal(res[("2", True)], res[("0", True)])
     assert float(np.abs(res[("0", False)]).mean()) > 0.5                       # the patches really moved
     assert epe(res[("2", True)], res[("0", False)]).mean() <= TOL_MEAN
+
+
+@pytest.mark.parametrize("noc", [1, 3])
+def test_fast_math_refinement_against_the_reference_fdf_vectors(noc):
+    """the refinement alone in the tolerance mode (v_rcp / v_rsq in compute_data / compute_smoothness / the block inverse, fused
+    multiply-adds in the solvers of levels of more than 64 rows) against the outputs of the reference's own FDF1.0.1 code
+    (tests/golden/fdf_ref_*.npz; the parity mode equals them bit for bit, tests/test_gpu_parity.py): the refined flow and the
+    right-hand sides of the last inner iteration"""
+    F, OFClass, VarRefClass, O = _mods()
+    for name, c in load_fdf(noc).items():
+        im1, im2, wx, wy, lvl = c["im1"], c["im2"], c["wx"], c["wy"], int(c["lvl"])
+        _, h, w = im1.shape
+        op = F.operating_point(2, 1024, noc)
+        op.coarsest_scale = op.finest_scale = lvl
+        op.fast_math = True
+        ofc = OFClass(op, F.img_params(width=w << lvl, height=h << lvl, padding=8))
+        padlvl = lambda a: np.pad(a.transpose(1, 2, 0), ((8, 8), (8, 8), (0, 0)), mode="edge")
+        flow = dev(np.stack([wx, wy], -1))[None].contiguous()
+        F.lib().fotg_enable_taps(ofc._h, 1)
+        VarRefClass(dev(padlvl(im1))[None], dev(padlvl(im2))[None], ofc.iparams[0], ofc.op, flow)
+        out = flow[0].cpu().numpy()
+        ref = np.stack([c["out_x"], c["out_y"]], -1)
+        e = np.sqrt(((out - ref) ** 2).sum(-1))
+        st = ((w + 3) // 4) * 4
+        b1 = np.zeros((1, h, st), np.float32)
+        F._lib.check(F.lib().fotg_varref_plane(ofc._h, 0, b"b1", lvl, b1.ctypes.data))
+        rel = np.abs(b1[0, :, :w] - c["b1"]).max() / max(1e-30, np.abs(c["b1"]).max())
+        print("%s (%d x %d, level %d): refined flow vs the reference's, mean %.3g  max %.3g px (flow magnitude %.3g); b1 max rel. diff %.3g"
+              % (name, w, h, lvl, e.mean(), e.max(), np.abs(ref).mean(), rel))
+        assert e.mean() <= 1e-4 and e.max() <= 1e-2, name          # (at the level's own resolution)
+        assert rel <= 1e-3, name          # (b1 is a difference of terms of opposite sign)
