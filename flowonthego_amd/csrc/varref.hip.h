@@ -339,14 +339,6 @@ __device__ __forceinline__ void data_term_compute(const VrArgs &a, int pair, int
   C[1] = c1;
 }
 
-template <int NOC, bool FM = false>
-__device__ __forceinline__ void data_term_pixel(const VrArgs &a, int pair, int i, int j, float hr, float hl, float vb, float vt,
-                                                float u, float v, float half_delta_over3, float half_gamma_over3)
-{
-  const PixIn<NOC> p = data_load<NOC>(a, pair, i, j);
-  data_term_compute<NOC, FM>(a, pair, i, j, p, hr, hl, vb, vt, u, v, half_delta_over3, half_gamma_over3);
-}
-
 // One workgroup = one 32x8 pixel tile.  (uu,vv) of the tile + 2-pixel halo and the smoothness weight s of the tile +
 // 1-pixel halo are staged in LDS, so each s is computed once (not once per neighbour) and the skewed D is read ~1.7x
 // per pixel instead of 13x.

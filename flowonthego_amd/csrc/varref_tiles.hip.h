@@ -72,20 +72,10 @@ __device__ __forceinline__ void st_sc1_f2(float2 *p, float2 v)
 {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float dpp_wave_shl1(float v)
-{
-  // lane L reads lane L+1 (wave_shl:1); lane 63 gets 0 (bound_ctrl)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
-}
-
-// lane L reads src of lane L-1 / L+1; the lane without a source lane (0 / 63) gets `old`
+// lane L reads src of lane L-1; lane 0 gets `old`
 __device__ __forceinline__ float dpp_wave_shr1_old(float old, float src)
 {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x138, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float dpp_wave_shl1_old(float old, float src)
-{
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x130, 0xF, 0xF, false));
 }
 
 // FMA (fotg_params::fast_math, the tolerance mode): the cell update with fused multiply-adds -- 9 packed instructions instead of 16,
