@@ -173,6 +173,47 @@ def test_depth_end_to_end(noc, op_point, fb):
     assert np.array_equal(gb[1], O.flow(O.pad_frame(f1, p.sc_f), O.pad_frame(f0, p.sc_f), p, 0))
 
 
+def test_depth_random_parameter_sweep():
+    """the stereo depth mode over random parameter combinations (patch size, overlap, scales, iteration counts, early termination,
+    thresholds, mean normalisation, cost function, refinement weights / iterations, gray / RGB, odd sizes): bit-identical to the oracle"""
+    F, OFClass, _, O = _mods()
+    rng = np.random.default_rng(31)
+    done = 0
+    for k in range(36):
+        noc = 1 + 2 * int(rng.integers(0, 2))
+        w, h = int(rng.integers(200, 520)), int(rng.integers(140, 340))
+        op = depth_op(F, 2, w, noc)
+        op.patch_size = int(rng.choice([4, 8, 12, 16]))
+        op.patch_stride = float(rng.choice([0.3, 0.4, 0.5, 0.65, 0.75]))
+        op.finest_scale = int(rng.integers(0, 3))
+        op.coarsest_scale = op.finest_scale + int(rng.integers(0, 3))
+        op.grad_descent_iter = int(rng.integers(2, 25))
+        op.min_iter = int(rng.integers(0, op.grad_descent_iter + 1)) if rng.random() < 0.5 else -1
+        op.dp_thresh, op.dr_thresh = float(rng.choice([0.05, 0.01, 0.2])), float(rng.choice([0.95, 0.8]))
+        op.res_thresh = float(rng.choice([0.0, 0.0, 0.5]))
+        op.use_mean_normalization = bool(rng.random() < 0.7)
+        op.cost_func = int(rng.choice([0, 0, 1, 2]))
+        op.use_var_ref = bool(rng.random() < 0.8)
+        op.var_ref_iter = int(rng.integers(1, 5))
+        op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta = float(rng.choice([10.0, 3.0, 25.0])), float(rng.choice([10.0, 0.5, 20.0])), float(rng.choice([5.0, 0.0, 12.0]))
+        op.var_ref_sor_weight = float(rng.choice([1.6, 1.0, 1.9]))
+        desc = dict(w=w, h=h, noc=noc, ps=op.patch_size, ov=op.patch_stride, sc=(op.coarsest_scale, op.finest_scale), it=(op.min_iter, op.grad_descent_iter),
+                    thr=(op.dp_thresh, op.dr_thresh, op.res_thresh), norm=op.use_mean_normalization, cost=op.cost_func,
+                    ref=(op.use_var_ref, op.var_ref_iter, op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta, op.var_ref_sor_weight))
+        try:
+            ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        except F.FotgError:
+            continue
+        f0, f1, _ = stereo_pair(h, w, seed=300 + k, noc=noc)
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        pr = oracle_params(O, op)
+        ref = O.flow(O.pad_frame(f0, pr.sc_f), O.pad_frame(f1, pr.sc_f), pr, 0)
+        assert np.array_equal(out, ref), (desc, float(np.abs(out - ref).max()))
+        ofc.close()
+        done += 1
+    assert done >= 24, done
+
+
 def test_depth_unsupported_combinations():
     F, OFClass, _, O = _mods()
     op = depth_op(F, 2, 640, 1)

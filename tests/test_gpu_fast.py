@@ -240,3 +240,34 @@ def test_fast_math_refinement_against_the_reference_fdf_vectors(noc):
               % (name, w, h, lvl, e.mean(), e.max(), np.abs(ref).mean(), rel))
         assert e.mean() <= 1e-4 and e.max() <= 1e-2, name          # (at the level's own resolution)
         assert rel <= 1e-3, name          # (b1 is a difference of terms of opposite sign)
+
+
+def test_fast_math_random_parameter_sweep():
+    """the tolerance mode over random parameter combinations (patch size, overlap, scales, iteration counts, thresholds, mean
+    normalisation, refinement weights and solver iterations, gray / RGB): mean endpoint error of the full-resolution flow against
+    the parity mode (== the oracle: tests/test_gpu_parity.py::test_random_parameter_sweep) within the north star's bound"""
+    F, OFClass, _, O = _mods()
+    rng = np.random.default_rng(99)
+    worst, done = (0.0, None), 0
+    for k in range(40):
+        noc = 1 + 2 * int(rng.integers(0, 2))
+        w, h = int(rng.integers(200, 640)), int(rng.integers(160, 420))
+        kw = dict(patch_size=int(rng.choice([4, 8, 12, 16])), patch_stride=float(rng.choice([0.3, 0.4, 0.5, 0.65, 0.75])),
+                  grad_descent_iter=int(rng.integers(4, 33)), use_mean_normalization=bool(rng.random() < 0.8),
+                  var_ref_iter=int(rng.integers(1, 5)), var_ref_alpha=float(rng.choice([10.0, 3.0, 25.0])),
+                  var_ref_gamma=float(rng.choice([10.0, 0.5, 20.0])), var_ref_delta=float(rng.choice([5.0, 0.0, 12.0])),
+                  var_ref_sor_weight=float(rng.choice([1.6, 1.0, 1.9])))
+        kw["finest_scale"] = int(rng.integers(0, 3))
+        kw["coarsest_scale"] = kw["finest_scale"] + int(rng.integers(1, 3))
+        f0, f1 = synth_pair(h, w, seed=700 + k, noc=noc)
+        try:
+            (ex_lo, ex_full), (fa_lo, fa_full) = fast_and_exact(F, OFClass, f0, f1, 2, noc=noc, refine=bool(rng.random() < 0.8), **kw)
+        except F.FotgError:
+            continue
+        mean, p99, mx = stats(fa_full[0], ex_full[0])
+        if mean > worst[0]:
+            worst = (mean, (w, h, noc, kw))
+        assert mean <= TOL_MEAN, (mean, p99, mx, w, h, noc, kw)
+        done += 1
+    print("fast_math over %d random parameter combinations: worst mean EPE %.3g px at %s" % (done, worst[0], worst[1]))
+    assert done >= 25, done

@@ -740,6 +740,57 @@ def test_random_sizes_sweep():
         ofc.close()
 
 
+def test_random_parameter_sweep():
+    """seeded sweep over the PARAMETERS kroeger's OFClass constructor takes (oflow.h:84-111), one random combination per case: patch
+    size 4 / 8 / 12 / 16, overlap, scale range, iteration counts with and without early termination, the three thresholds, mean
+    normalisation, cost function, forward-backward merge, refinement weights, solver iterations and relaxation weight, the three
+    solver orders, gray / RGB, odd frame sizes, with and without a second pair in the batch -- every flow bit-identical to the oracle"""
+    F, OFClass, _, O = _mods()
+    rng = np.random.default_rng(77)
+    done = 0
+    for k in range(90):
+        noc = 1 + 2 * int(rng.integers(0, 2))
+        w, h = int(rng.integers(160, 520)), int(rng.integers(120, 360))
+        op = F.operating_point(2, w, noc)
+        op.patch_size = int(rng.choice([4, 8, 12, 16]))
+        op.patch_stride = float(rng.choice([0.3, 0.4, 0.5, 0.65, 0.75]))
+        op.finest_scale = int(rng.integers(0, 3))
+        op.coarsest_scale = op.finest_scale + int(rng.integers(0, 3))
+        op.grad_descent_iter = int(rng.integers(2, 25))
+        op.min_iter = int(rng.integers(0, op.grad_descent_iter + 1)) if rng.random() < 0.5 else -1
+        op.dp_thresh = float(rng.choice([0.05, 0.01, 0.2]))
+        op.dr_thresh = float(rng.choice([0.95, 0.8, 0.99]))
+        op.res_thresh = float(rng.choice([0.0, 0.0, 0.5, 2.0]))
+        op.use_mean_normalization = bool(rng.random() < 0.7)
+        op.cost_func = int(rng.choice([0, 0, 1, 2]))
+        op.use_fbcon = bool(rng.random() < 0.25)
+        op.use_var_ref = bool(rng.random() < 0.8)
+        op.var_ref_iter = int(rng.integers(1, 6))
+        op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta = float(rng.choice([10.0, 3.0, 25.0])), float(rng.choice([10.0, 0.5, 20.0])), float(rng.choice([5.0, 0.0, 12.0]))
+        op.var_ref_sor_weight = float(rng.choice([1.6, 1.0, 1.25, 1.9]))
+        op.sor_mode = int(rng.choice([0, 0, 0, 2, 1]))
+        desc = dict(sor=op.sor_mode, w=w, h=h, noc=noc, ps=op.patch_size, ov=op.patch_stride, sc=(op.coarsest_scale, op.finest_scale), it=(op.min_iter, op.grad_descent_iter),
+                    thr=(op.dp_thresh, op.dr_thresh, op.res_thresh), norm=op.use_mean_normalization, cost=op.cost_func, fb=op.use_fbcon,
+                    ref=(op.use_var_ref, op.var_ref_iter, op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta, op.var_ref_sor_weight))
+        try:
+            ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        except F.FotgError:
+            continue                                          # (a coarsest level too small for the patch size: refused, like test_random_sizes_sweep)
+        f0, f1 = synth_pair(h, w, seed=500 + k, noc=noc)
+        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        pr = oracle_params(O, op)
+        ref = O.flow(O.pad_frame(f0, pr.sc_f), O.pad_frame(f1, pr.sc_f), pr, op.sor_mode)
+        assert np.array_equal(out, ref), (desc, float(np.abs(out - ref).max()))
+        ofc.close()
+        if k % 3 == 0:                                        # the same pair as the second of a batch of two (reversed pair first)
+            ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=2)
+            both = ofc.calc_batch(torch.stack([dev(f1), dev(f0)]), torch.stack([dev(f0), dev(f1)])).cpu().numpy()
+            assert np.array_equal(both[1], ref), desc
+            ofc.close()
+        done += 1
+    assert done >= 60, done
+
+
 def test_sequence_mode(alley):
     """video front end: n+1 consecutive frames -> n flows with every pyramid built once; each flow
     equals the oracle on its pair (float and 8-bit frames, gray and RGB, full max_batch)"""
