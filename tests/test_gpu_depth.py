@@ -177,9 +177,9 @@ def test_depth_random_parameter_sweep():
     """the stereo depth mode over random parameter combinations (patch size, overlap, scales, iteration counts, early termination,
     thresholds, mean normalisation, cost function, refinement weights / iterations, gray / RGB, odd sizes): bit-identical to the oracle"""
     F, OFClass, _, O = _mods()
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(int(os.environ.get("FOTG_TEST_SWEEP_SEED", "31")))
     done = 0
-    for k in range(36):
+    for k in range(int(os.environ.get("FOTG_TEST_SWEEP_CASES", "36"))):
         noc = 1 + 2 * int(rng.integers(0, 2))
         w, h = int(rng.integers(200, 520)), int(rng.integers(140, 340))
         op = depth_op(F, 2, w, noc)

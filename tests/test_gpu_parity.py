@@ -2,6 +2,8 @@
 vectors of the reference's own FDF code, and the reference's golden .flo.  Integer/bit work is compared with ==;
 the engine evaluates the oracle's f32 expressions in the same order (no FMA contraction), so floats are compared
 bit-for-bit as well (np.array_equal; +0 == -0)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -746,9 +748,9 @@ def test_random_parameter_sweep():
     normalisation, cost function, forward-backward merge, refinement weights, solver iterations and relaxation weight, the three
     solver orders, gray / RGB, odd frame sizes, with and without a second pair in the batch -- every flow bit-identical to the oracle"""
     F, OFClass, _, O = _mods()
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(int(os.environ.get("FOTG_TEST_SWEEP_SEED", "77")))
     done = 0
-    for k in range(90):
+    for k in range(int(os.environ.get("FOTG_TEST_SWEEP_CASES", "90"))):
         noc = 1 + 2 * int(rng.integers(0, 2))
         w, h = int(rng.integers(160, 520)), int(rng.integers(120, 360))
         op = F.operating_point(2, w, noc)
