@@ -793,6 +793,67 @@ def test_random_parameter_sweep():
     assert done >= 60, done
 
 
+def test_random_entry_point_sweep():
+    """seeded sweep over frame SIZES (the loaders' aligned / dword / padded paths, base levels, partial strips) x every front end of
+    the boundary: float frames, 8-bit gray, 8-bit colour converted on load (B,G,R and R,G,B), interleaved RGB -- alone (checked against
+    the oracle), in a batch with its neighbours, as a video sequence, through a pipe with batches in flight, with the device-side
+    upsample: all the same bits"""
+    F, OFClass, _, O = _mods()
+    from flowonthego_amd.pipeline import FlowPipeline
+    rng = np.random.default_rng(int(os.environ.get("FOTG_TEST_SWEEP_SEED", "123")))
+    for k in range(int(os.environ.get("FOTG_TEST_SWEEP_CASES", "12"))):
+        kind = ["f32", "u8", "bgr", "rgb8", "rgbf"][k % 5]               # float gray | 8-bit gray | 8-bit colour -> gray | 8-bit RGB | float RGB
+        noc = 3 if kind in ("rgb8", "rgbf") else 1
+        w = int(rng.integers(96, 900)) if rng.random() < 0.7 else 16 * int(rng.integers(8, 60))
+        h = int(rng.integers(80, 500))
+        op_point = int(rng.integers(1, 4))
+        if os.environ.get("FOTG_TEST_SWEEP_BIG"):                         # (tools/sweep_hunt.sh: HD .. 4K frames, all four operating points)
+            w, h, op_point = int(rng.integers(1000, 3900)), int(rng.integers(600, 2200)), int(rng.integers(1, 5))
+        n = int(rng.integers(2, 5))
+        op = F.operating_point(op_point, w, noc)
+        op.grad_descent_iter = min(op.grad_descent_iter, 16)
+        if kind == "bgr":
+            op.u8_color = int(rng.integers(1, 3))
+        try:
+            ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=n)
+        except F.FotgError:
+            continue
+        desc = (kind, w, h, op_point, n, op.u8_color)
+        # n + 1 frames of a "video": frame j+1 = frame j of another seed's pair (any content will do)
+        fr = [synth_pair(h, w, seed=2000 + 7 * k + j, noc=3 if kind == "bgr" else noc)[j & 1] for j in range(n + 1)]
+        if kind in ("u8", "bgr", "rgb8"):
+            dv = [torch.from_numpy(np.ascontiguousarray(f.astype(np.uint8))).cuda() for f in fr]
+            if kind == "bgr":
+                first, third = (1868, 4899) if op.u8_color == 1 else (4899, 1868)
+                host = [gray_cv(f.astype(np.uint8), first, third).astype(np.float32) for f in fr]
+            else:
+                host = [f.astype(np.uint8).astype(np.float32) for f in fr]
+            batch = lambda a, b: ofc.calc_batch_u8(torch.stack(a), torch.stack(b))
+        else:
+            dv = [dev(f) for f in fr]
+            host = fr
+            batch = lambda a, b: ofc.calc_batch(torch.stack(a), torch.stack(b))
+        pr = oracle_params(O, op)
+        ref0 = O.flow(O.pad_frame(host[0], pr.sc_f), O.pad_frame(host[1], pr.sc_f), pr, 0)
+        one = batch(dv[:1], dv[1:2])
+        assert np.array_equal(one[0].cpu().numpy(), ref0), desc
+        allb = batch(dv[:-1], dv[1:]).clone()
+        assert torch.equal(allb[0], one[0]), desc
+        seq = ofc.calc_sequence(torch.stack(dv))
+        assert torch.equal(seq, allb), desc
+        wp, hp, padw, padh = O.padded_size(w, h, pr.sc_f)
+        assert np.array_equal(ofc.upsample_crop(allb)[0].cpu().numpy(), O.upsample_crop(ref0, pr.sc_l, padw, padh, w, h)), desc
+        # the same pairs one per submit through a pipe, all in flight
+        pipe = FlowPipeline(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=1, depth=min(n, 4))
+        outs = [pipe.new_outflow(1) for _ in range(n)]
+        for j in range(n):
+            pipe.submit(dv[j][None], dv[j + 1][None], None, outs[j])
+        pipe.synchronize()
+        for j in range(n):
+            assert torch.equal(outs[j][0], allb[j]), (desc, j)
+        pipe.close(); ofc.close()
+
+
 def test_sequence_mode(alley):
     """video front end: n+1 consecutive frames -> n flows with every pyramid built once; each flow
     equals the oracle on its pair (float and 8-bit frames, gray and RGB, full max_batch)"""
