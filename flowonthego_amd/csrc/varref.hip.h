@@ -94,7 +94,9 @@ __device__ __forceinline__ PrepVal<NOC> prep_values(const VrArgs &a, int pair, i
   const int x = (int)floorf(xx), y = (int)floorf(yy);
   const float dx = xx - x, dy = yy - y;
   v.mask = (xx >= 0 && xx <= a.w - 1 && yy >= 0 && yy <= a.h - 1) ? 1.f : 0.f;
-  const int x1 = clampi(x, a.w), x2 = clampi(x + 1, a.w), y1 = clampi(y, a.h), y2 = clampi(y + 1, a.h);
+  // (a flow that has diverged -- a relaxation weight outside (0, 2), say -- saturates the conversion: x + 1 must not overflow)
+  const int xs = x < -2 ? -2 : (x > a.w ? a.w : x), ys = y < -2 ? -2 : (y > a.h ? a.h : y);
+  const int x1 = clampi(xs, a.w), x2 = clampi(xs + 1, a.w), y1 = clampi(ys, a.h), y2 = clampi(ys + 1, a.h);
   const float *s1 = I1 + (size_t)pair * img_stride, *s0 = I0 + (size_t)pair * img_stride;
 #pragma unroll
   for (int c = 0; c < NOC; ++c) {

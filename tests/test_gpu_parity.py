@@ -1179,6 +1179,34 @@ def test_degenerate_inputs():
         assert np.array_equal(out, ref, equal_nan=True), scale
 
 
+def test_diverged_flow_stays_inside_the_images():
+    """a flow that has left the float-to-int range (a relaxation weight outside (0, 2) makes the refinement diverge; a caller may
+    hand in any initflow) must not move the warp's taps out of the image: found by tools/fuzz_create.py as a GPU memory fault
+    (floor(x + wx) saturates at INT_MAX and x + 1 overflowed).  The reference's (int)floor is undefined there; here the taps clamp
+    like any other out-of-image position and the result is whatever the arithmetic gives (non-finite or huge), without a fault"""
+    F, OFClass, VarRefClass, O = _mods()
+    w, h = 352, 168
+    op = F.operating_point(2, 1024, 1)
+    op.coarsest_scale = op.finest_scale = 0
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=8))
+    im = (torch.rand((1, h + 16, w + 16, 1), device="cuda") * 255).floor()
+    for val in (1e30, float("inf"), 3e9, -3e9, -1e30, float("nan")):
+        flow = torch.full((1, h, w, 2), val, device="cuda")
+        VarRefClass(im, im.roll(2, 2), ofc.iparams[0], ofc.op, flow)
+        torch.cuda.synchronize()
+    ofc.close()
+    # end to end: a negative relaxation weight at every level of a four-level pyramid down to full resolution
+    for noc in (1, 3):
+        op = F.operating_point(3, 350, noc)
+        op.finest_scale, op.coarsest_scale, op.grad_descent_iter, op.var_ref_sor_weight = 0, 3, 16, -1.0
+        ofc = OFClass(op, F.img_params(width=350, height=165, padding=op.patch_size), max_batch=2)
+        f0 = (torch.rand((2, 165, 350) + ((3,) if noc == 3 else ()), device="cuda") * 255).floor()
+        out = ofc.calc_batch(f0, torch.roll(f0, 2, 2))
+        torch.cuda.synchronize()
+        assert out.shape[0] == 2
+        ofc.close()
+
+
 def test_errors():
     F, OFClass, _, O = _mods()
     op = F.operating_point(2, 512, 1)
