@@ -1207,6 +1207,18 @@ def test_diverged_flow_stays_inside_the_images():
         ofc.close()
 
 
+@pytest.mark.parametrize("tool,args", [("fuzz_create.py", ["120", "5"]), ("fuzz_values.py", ["60", "5"]), ("fuzz_api.py", ["8", "5"]), ("fuzz_cabi.py", ["12", "5"])])
+def test_fuzz_tools_short_run(tool, args):
+    """the four fuzzers of tools/ (odd configurations, poisoned inputs, random asynchronous call sequences, null / odd C-ABI
+    arguments) in a short run each, in a process of their own: a crash, a hang or a flow that differs from the single-context
+    result fails the test"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (tool, r.stdout[-2000:], r.stderr[-2000:])
+    assert "no crash" in r.stdout or "every one returned" in r.stdout, r.stdout[-500:]
+
+
 def test_errors():
     F, OFClass, _, O = _mods()
     op = F.operating_point(2, 512, 1)
