@@ -59,5 +59,9 @@ for k in range(cases):
         nonfinite += 0 if bool(torch.isfinite(out).all()) else 1
     except F.FotgError:
         refused += 1
+    if os.environ.get("FOTG_DEBUG_GUARD"):
+        from flowonthego_amd._lib import lib as _l
+        gv = _l().fotg_ctx_counter(ofc._h, b"guard_violations")
+        assert gv <= 0, ("guard violations", gv, k)
     ofc.close()
 print("fuzz: %d cases, %d refused with a status code, %d ran (%d of them to a non-finite flow: degenerate weights), no crash" % (cases, refused, ran, nonfinite))

@@ -59,5 +59,9 @@ for k in range(cases):
         ran += 1
     except F.FotgError:
         refused += 1
+    if os.environ.get("FOTG_DEBUG_GUARD"):
+        from flowonthego_amd._lib import lib as _l
+        gv = _l().fotg_ctx_counter(ofc._h, b"guard_violations")
+        assert gv <= 0, ("guard violations", gv, k)
     ofc.close()
 print("fuzz_values: %d cases, %d ran, %d refused, no crash" % (cases, ran, refused))
