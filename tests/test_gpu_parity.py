@@ -854,6 +854,32 @@ def test_random_entry_point_sweep():
         pipe.close(); ofc.close()
 
 
+@pytest.mark.parametrize("w,h,op_point,noc,kw", [(7680, 4320, 2, 1, {}), (72, 6000, 2, 1, {"finest_scale": 1, "coarsest_scale": 2}),
+                                                 (40, 40, 2, 1, {"finest_scale": 0, "coarsest_scale": 1}),
+                                                 (17, 33, 2, 3, {"finest_scale": 0, "coarsest_scale": 0, "patch_size": 4}),
+                                                 (4096, 4096, 4, 1, {"grad_descent_iter": 8}), (3000, 200, 2, 3, {"finest_scale": 2, "coarsest_scale": 4})])
+def test_extreme_shapes(w, h, op_point, noc, kw):
+    """8K frames, a level of 3 000 rows (the tile solver's bands beyond what the chip holds), square 4K at the quality preset, tiny
+    and one-patch levels, a very wide RGB strip: bit-identical to the oracle.  (Limits, refused with FOTG_ERR_UNSUPPORTED: the
+    lexicographic refinement of levels of more than 4096 rows, coarsest levels of fewer than 5 rows.)"""
+    F, OFClass, _, O = _mods()
+    op = F.operating_point(op_point, w, noc)
+    op.grad_descent_iter = min(op.grad_descent_iter, 12)
+    for k, v in kw.items():
+        setattr(op, k, v)
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    f0, f1 = synth_pair(h, w, seed=w + h, noc=noc)
+    out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    assert np.array_equal(out, ref), float(np.abs(out - ref).max())
+    ofc.close()
+    with pytest.raises(F.FotgError):                                   # the documented limit
+        big = F.operating_point(3, 64, 1)
+        big.finest_scale, big.coarsest_scale = 0, 1
+        OFClass(big, F.img_params(width=64, height=9000, padding=big.patch_size))
+
+
 def test_sequence_mode(alley):
     """video front end: n+1 consecutive frames -> n flows with every pyramid built once; each flow
     equals the oracle on its pair (float and 8-bit frames, gray and RGB, full max_batch)"""
