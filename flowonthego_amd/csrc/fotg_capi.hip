@@ -130,6 +130,7 @@ struct fotg_ctx {
   int x_rt[FOTG_MAXLEV];
   int *tileSync;
   long sync_total;                   // ints in tileSync in front of the time-out counter: max(tile_sync_words, level-pipe words) for max_batch pairs
+  int tile_nbs;                      // bands per (pair, sweep) in the progress words = the band count of the tallest tiled level (TileArgs::NBS)
   int lp_ntr;                        // tile rows of the data term the level-pipe words are sized for (the tallest tile level)
   // a bounded inter-workgroup wait that gave up (tile solver pipeline) sets this word of pinned host memory from the device;
   // fotg_calc, fotg_pipe_wait(host_wait) and fotg_pipe_sync read it after their synchronisation and return FOTG_ERR_STALL
@@ -310,9 +311,9 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   }
   if (p->usetvref) {
     const LevelGeom &g = c->geom[p->sc_l];
-    // lexicographic solver: up to 1024 rows any kernel, up to 4096 rows the tile pipeline (at most four sweeps per launch); the
+    // lexicographic solver: up to 1024 rows any kernel, up to 16384 rows the tile pipeline (at most four sweeps per launch); the
     // depth solver has one thread per row of a workgroup
-    if (g.h > (p->depth ? 1024 : 4096) && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
+    if (g.h > (p->depth ? 1024 : 16384) && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     if (g.h > 1024 && p->sor_mode == FOTG_SOR_POINT) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }      // (compatibility mode: single-wave solver only)
     if (g.w < 3 || c->geom[p->sc_f].h < 5 || c->geom[p->sc_f].w < 3) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc + (p->depth ? (int)DE_NPLANE : 0));
@@ -343,12 +344,14 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
       // (more than four sweeps -- the operating points use three -- run as consecutive launches of at most four: only levels of
       // more than 1024 rows, which no other solver reaches, pay for that)
       if (p->sor_mode == FOTG_SOR_LEXICOGRAPHIC && gl.h > 96 && p->tv_solverit >= 1 && (p->tv_solverit <= 4 || gl.h > 1024) &&
-          (gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS <= 64) {
+          (gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS <= 256) {
         {
           // every lane of every band has a cell of its own in a row (no two lanes share a store target)
           const int nbr = ((gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS) * FOTG_TILE_ROWS, need = ((gl.h + 2 + 15) / 16) * 16;
           c->x_rt[l] = nbr > need ? nbr : need;
         }
+        // (the tile kernels address a pair's arrays through buffer resources: 32-bit byte offsets)
+        if ((double)(a.S + 1) * a.RP * 32.0 >= 4294967296.0 || (double)(a.S + 1 + FOTG_TILE_DUMP) * c->x_rt[l] * 8.0 >= 4294967296.0) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
         c->x_pair_stride[l] = (long)(p->tv_solverit < 4 ? p->tv_solverit : 4) * (a.S + 1 + FOTG_TILE_DUMP) * c->x_rt[l];
         const size_t xb = B * c->x_pair_stride[l] * sizeof(float2);
         ALLOC(c->vrX[l], xb);
@@ -356,8 +359,9 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
         if (!c->tileSync) {
           // (the first level that gets here is the finest = tallest one: its tile rows size the level-pipe words)
           c->lp_ntr = (gl.h + FOTG_LP_TH - 1) / FOTG_LP_TH;
-          const long lp = lp_tile_words((int)B) + lp_data_words((int)B, c->lp_ntr);
-          c->sync_total = lp > tile_sync_words((int)B) ? lp : tile_sync_words((int)B);
+          c->tile_nbs = (gl.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS;
+          const long lp = lp_tile_words((int)B, c->tile_nbs) + lp_data_words((int)B, c->lp_ntr);
+          c->sync_total = lp > tile_sync_words((int)B, c->tile_nbs) ? lp : tile_sync_words((int)B, c->tile_nbs);
           ALLOC(c->tileSync, (c->sync_total + 32) * sizeof(int));
           if (hipMemset(c->tileSync, 0, (c->sync_total + 32) * sizeof(int)) != hipSuccess) { fotg_destroy(c); return FOTG_ERR_HIP; }
         }
@@ -958,6 +962,7 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
     g.NB = (a.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS;
     g.npairs = n;
     g.sync = c->tileSync;
+    g.NBS = c->tile_nbs;
     g.timeouts = g.sync + c->sync_total;
     g.stall_flag = c->stall_dev;
 #ifdef FOTG_TILE_STATS
@@ -970,7 +975,7 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
     for (int done = 0; done < sweeps; done += 4) {
       const int sw = sweeps - done < 4 ? sweeps - done : 4;
       // (the data-term launch in front of the call has cleared the words already when the caller arranged that: VrArgs::zsync)
-      if (!(sync_zeroed && done == 0)) (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n) * sizeof(int), s);
+      if (!(sync_zeroed && done == 0)) (void)hipMemsetAsync(g.sync, 0, (size_t)tile_sync_words(n, c->tile_nbs) * sizeof(int), s);
       if (c->p.fast_math) vr_sor_tile_kernel<FOTG_TILE_P, true><<<n * g.NB * sw, FOTG_TILE_THREADS, 0, s>>>(a, g, sw, omega);
       else vr_sor_tile_kernel<FOTG_TILE_P><<<n * g.NB * sw, FOTG_TILE_THREADS, 0, s>>>(a, g, sw, omega);
       ++g_tile_launches;
@@ -1020,14 +1025,14 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   // term) clears the pipeline's sync words
   VrArgs az = a;
   const bool tiles = c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->vrX[l] && c->tileSync && c->p.tv_solverit > 0 && c->tune.vr_setup;
-  if (tiles) { az.zsync = c->tileSync; az.zsync_n = (int)tile_sync_words(n); }
+  if (tiles) { az.zsync = c->tileSync; az.zsync_n = (int)tile_sync_words(n, c->tile_nbs); }
   // FOTG_VR_LEVELPIPE=1: the level's whole fixed-point loop as ONE pipeline launch behind the set-up launch (varref_levelpipe.hip.h).
   // At least two sweeps per call (what keeps a band's last sweep behind the data term of its neighbours), at most four (X buffers).
   const int ntr = (g.h + FOTG_LP_TH - 1) / FOTG_LP_TH;
   const bool levelpipe = tiles && c->tune.vr_levelpipe && n <= c->tune.lp_max_pairs && c->tune.vr_path == 0 && c->tune.vr_first_data && inner >= 1 && inner <= FOTG_LP_KMAX &&
-                         c->p.tv_solverit >= 2 && c->p.tv_solverit <= 4 && ntr <= c->lp_ntr && g.h <= 4096 &&
-                         lp_tile_words(n) + lp_data_words(n, ntr) <= c->sync_total;
-  if (levelpipe) { az.zsync_n = (int)(lp_tile_words(n) + lp_data_words(n, ntr)); }
+                         c->p.tv_solverit >= 2 && c->p.tv_solverit <= 4 && ntr <= c->lp_ntr &&
+                         lp_tile_words(n, c->tile_nbs) + lp_data_words(n, ntr) <= c->sync_total;
+  if (levelpipe) { az.zsync_n = (int)(lp_tile_words(n, c->tile_nbs) + lp_data_words(n, ntr)); }
   bool merged_first = false;
   if (c->tune.vr_setup) {
     // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
@@ -1059,11 +1064,12 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     tg.NB = (a.h + FOTG_TILE_ROWS - 1) / FOTG_TILE_ROWS;
     tg.npairs = n;
     tg.sync = c->tileSync;
+    tg.NBS = c->tile_nbs;
     tg.timeouts = tg.sync + c->sync_total;
     tg.stall_flag = c->stall_dev;
     LevelPipeArgs q;
     q.K = inner; q.ntr = ntr; q.tiles_x = (g.w + FOTG_TW - 1) / FOTG_TW;
-    q.dprog = c->tileSync + lp_tile_words(n);
+    q.dprog = c->tileSync + lp_tile_words(n, c->tile_nbs);
     q.quarter_alpha = quarter_alpha; q.half_delta_over3 = half_delta_over3; q.half_gamma_over3 = half_gamma_over3;
     q.dbg = c->tune.vr_levelpipe >> 4;       // (FOTG_VR_LEVELPIPE = 1 + 16 * dbg)
     q.stamps = nullptr;

@@ -38,7 +38,7 @@ struct LevelPipeArgs {
   long long *stamps;                         // diagnosis (dbg & 4): per ticket 8 words: start, end, role, first step / first publish (wall clock, 10 ns)
   int dbg;                                   // FOTG_VR_LEVELPIPE_DBG (diagnosis): 1 = the data term waits for the whole previous call, 2 = a call's first sweep for the whole data term
 };
-__host__ __device__ inline long lp_tile_words(int npairs) { return 32L * (1 + (long)npairs * FOTG_LP_KMAX * 4 * 64); }
+__host__ __device__ inline long lp_tile_words(int npairs, int nbs) { return 32L * (1 + (long)npairs * FOTG_LP_KMAX * 4 * nbs); }
 #ifndef FOTG_LP_TH
 #define FOTG_LP_TH 8                         // rows of a tile row of the data term (a multiple of FOTG_TH; FOTG_TILE_ROWS is a multiple of it)
 #endif
@@ -97,8 +97,8 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
   int *const myprog = q.dprog + 32 * ((((long)pair * FOTG_LP_KMAX + kc) * q.ntr + ty) * FOTG_LP_DW + half);
   // the last sweep of call kc - 1 in the bands whose rows this tile row reads (rows y0 - 2 .. y0 + FOTG_LP_TH + 1)
   const int blo = (y0 - 2 < 0 ? 0 : y0 - 2) / FOTG_TILE_ROWS, bhi0 = (y0 + FOTG_LP_TH + 1) / FOTG_TILE_ROWS, bhi = bhi0 > g.NB - 1 ? g.NB - 1 : bhi0;
-  const int *const p0 = g.sync + 32 * (1 + ((pair * FOTG_LP_KMAX + kc - 1) * 4 + nsweeps - 1) * 64 + blo);
-  const int *const p1 = g.sync + 32 * (1 + ((pair * FOTG_LP_KMAX + kc - 1) * 4 + nsweeps - 1) * 64 + bhi);
+  const int *const p0 = g.sync + 32 * (1 + ((pair * FOTG_LP_KMAX + kc - 1) * 4 + nsweeps - 1) * g.NBS + blo);
+  const int *const p1 = g.sync + 32 * (1 + ((pair * FOTG_LP_KMAX + kc - 1) * 4 + nsweeps - 1) * g.NBS + bhi);
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)a.Cp(pair), 0, (int)((size_t)a.c_pair_stride * 16), 0x00020000);
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   int seen0 = -1, seen1 = -1;
@@ -199,7 +199,7 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (wv == 3) return;                                            // (a barrier counts the waves that have not ended)
   const int S = a.S, RP = a.RP, RPD = a.RPD, h = a.h;
-  auto pw = [&](int kk, int nn, int bb) { return g.sync + 32 * (1 + ((pair * FOTG_LP_KMAX + kk) * 4 + nn) * 64 + bb); };
+  auto pw = [&](int kk, int nn, int bb) { return g.sync + 32 * (1 + ((pair * FOTG_LP_KMAX + kk) * 4 + nn) * g.NBS + bb); };
   int *const prog = pw(kc, n, b);
   const int *const prog_own = n > 0 ? pw(kc, n - 1, b) : nullptr;
   const int *const prog_bel = (n > 0 && b + 1 < g.NB) ? pw(kc, n - 1, b + 1) : nullptr;

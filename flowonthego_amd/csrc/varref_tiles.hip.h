@@ -39,14 +39,15 @@ struct TileArgs {
   int RT;                    // cells per row, multiple of 16
   int NB;                    // bands of FOTG_TILE_ROWS rows
   int npairs;
-  int *sync;                 // [0] ticket, progress of tile (pair, n, b) at [32 * (1 + (pair * 4 + n) * 64 + b)]; zeroed before every launch
+  int *sync;                 // [0] ticket, progress of tile (pair, n, b) at [32 * (1 + (pair * 4 + n) * NBS + b)]; zeroed before every launch
+  int NBS;                   // bands per (pair, sweep) in that array: the band count of the context's tallest tiled level
   int *timeouts;             // timed-out waits since the context was created
   int *stall_flag;           // host-visible word (pinned host memory): set on a time-out, read by the product API's host sync points
 #ifdef FOTG_TILE_STATS
   long long *stats;          // [ticket][16]: see the end of the solver / writer wave (diagnostic builds only)
 #endif
 };
-__host__ __device__ inline long tile_sync_words(int npairs) { return 32L * (1 + (long)npairs * 4 * 64); }
+__host__ __device__ inline long tile_sync_words(int npairs, int nbs) { return 32L * (1 + (long)npairs * 4 * nbs); }
 #define FOTG_TILE_ROWS 64      // rows of a band = lanes of the solver wave (one row per lane)
 #define FOTG_TILE_DUMP 16      // rows of the dump area behind the zero row of every X buffer
 #ifndef FOTG_TILE_G
@@ -108,10 +109,10 @@ __global__ __launch_bounds__(FOTG_TILE_THREADS) __attribute__((amdgpu_waves_per_
       }
   }
   if (n < 0) return;
-  int *const prog = g.sync + 32 * (1 + (pair * 4 + n) * 64 + b);
-  const int *const prog_own = n > 0 ? g.sync + 32 * (1 + (pair * 4 + n - 1) * 64 + b) : nullptr;                      // (b, n-1)
-  const int *const prog_bel = (n > 0 && b + 1 < g.NB) ? g.sync + 32 * (1 + (pair * 4 + n - 1) * 64 + b + 1) : nullptr;  // (b+1, n-1)
-  const int *const prog_top = b > 0 ? g.sync + 32 * (1 + (pair * 4 + n) * 64 + b - 1) : nullptr;                       // (b-1, n)
+  int *const prog = g.sync + 32 * (1 + (pair * 4 + n) * g.NBS + b);
+  const int *const prog_own = n > 0 ? g.sync + 32 * (1 + (pair * 4 + n - 1) * g.NBS + b) : nullptr;                      // (b, n-1)
+  const int *const prog_bel = (n > 0 && b + 1 < g.NB) ? g.sync + 32 * (1 + (pair * 4 + n - 1) * g.NBS + b + 1) : nullptr;  // (b+1, n-1)
+  const int *const prog_top = b > 0 ? g.sync + 32 * (1 + (pair * 4 + n) * g.NBS + b - 1) : nullptr;                       // (b-1, n)
   // ---- arrays: input = values of sweep n-1, output = values of sweep n
   float2 *const Dlev = a.Dp(pair);
   float2 *const Xp = g.X + (size_t)pair * g.x_pair_stride;

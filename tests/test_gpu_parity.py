@@ -857,11 +857,14 @@ def test_random_entry_point_sweep():
 @pytest.mark.parametrize("w,h,op_point,noc,kw", [(7680, 4320, 2, 1, {}), (72, 6000, 2, 1, {"finest_scale": 1, "coarsest_scale": 2}),
                                                  (40, 40, 2, 1, {"finest_scale": 0, "coarsest_scale": 1}),
                                                  (17, 33, 2, 3, {"finest_scale": 0, "coarsest_scale": 0, "patch_size": 4}),
-                                                 (4096, 4096, 4, 1, {"grad_descent_iter": 8}), (3000, 200, 2, 3, {"finest_scale": 2, "coarsest_scale": 4})])
+                                                 (4096, 4096, 4, 1, {"grad_descent_iter": 8}), (3000, 200, 2, 3, {"finest_scale": 2, "coarsest_scale": 4}),
+                                                 (64, 9000, 3, 1, {"finest_scale": 0, "coarsest_scale": 1}),
+                                                 (7680, 4320, 2, 1, {"finest_scale": 0, "coarsest_scale": 1, "grad_descent_iter": 3})])
 def test_extreme_shapes(w, h, op_point, noc, kw):
-    """8K frames, a level of 3 000 rows (the tile solver's bands beyond what the chip holds), square 4K at the quality preset, tiny
-    and one-patch levels, a very wide RGB strip: bit-identical to the oracle.  (Limits, refused with FOTG_ERR_UNSUPPORTED: the
-    lexicographic refinement of levels of more than 4096 rows, coarsest levels of fewer than 5 rows.)"""
+    """8K frames -- also refined at FULL resolution (a level of 4 320 rows) --, levels of 3 000 and 9 000 rows (the tile solver's bands
+    beyond what the chip holds), square 4K at the quality preset, tiny and one-patch levels, a very wide RGB strip: bit-identical to
+    the oracle.  (Limits, refused with FOTG_ERR_UNSUPPORTED: the lexicographic refinement of levels of more than 16 384 rows or
+    whose skewed arrays exceed 4 GB per pair, coarsest levels of fewer than 5 rows.)"""
     F, OFClass, _, O = _mods()
     op = F.operating_point(op_point, w, noc)
     op.grad_descent_iter = min(op.grad_descent_iter, 12)
@@ -877,7 +880,7 @@ def test_extreme_shapes(w, h, op_point, noc, kw):
     with pytest.raises(F.FotgError):                                   # the documented limit
         big = F.operating_point(3, 64, 1)
         big.finest_scale, big.coarsest_scale = 0, 1
-        OFClass(big, F.img_params(width=64, height=9000, padding=big.patch_size))
+        OFClass(big, F.img_params(width=64, height=20000, padding=big.patch_size))
 
 
 def test_sequence_mode(alley):
