@@ -742,6 +742,44 @@ def test_random_sizes_sweep():
         ofc.close()
 
 
+SWITCHES = {"FOTG_VR_PATH": ["0", "1", "2"], "FOTG_VR_STREAM": ["0", "1"], "FOTG_VR_CLDS": ["0", "1"], "FOTG_VR_SETUP": ["0", "1"],
+            "FOTG_VR_LEVELPIPE": ["0", "1"], "FOTG_VR_FIRST_DATA": ["0", "1"], "FOTG_VR_FUSED_NT": ["512", "1024"], "FOTG_PYR_SPLIT": ["1", "3", "16"],
+            "FOTG_PYR_PERSIST": ["0", "2"], "FOTG_LK_SHW": ["-1", "0", "1"], "FOTG_LK_LPP": ["0", "8", "16"], "FOTG_LK_LPP_MIN_WAVES": ["1", "2048"]}
+
+
+def test_random_switch_sweep(monkeypatch):
+    """every dispatch switch of the engine (read once at fotg_create; each selects among kernels that must agree: solver paths, set-up
+    variants, fused-kernel shapes, pyramid launch shapes, LK window / lanes-per-patch variants) drawn at random together with the
+    frame size, operating point, channels and batch: whatever path runs, the flow is the oracle's"""
+    F, OFClass, _, O = _mods()
+    rng = np.random.default_rng(int(os.environ.get("FOTG_TEST_SWEEP_SEED", "4242")))
+    for k in range(int(os.environ.get("FOTG_TEST_SWEEP_CASES", "24"))):
+        env = {name: str(rng.choice(vals)) for name, vals in SWITCHES.items() if rng.random() < 0.6}
+        for name in SWITCHES:
+            monkeypatch.delenv(name, raising=False)
+        for name, v in env.items():
+            monkeypatch.setenv(name, v)
+        noc = 1 + 2 * int(rng.integers(0, 2))
+        w, h = int(rng.integers(200, 1100)), int(rng.integers(160, 700))
+        op_point = int(rng.integers(1, 5))
+        op = F.operating_point(op_point, w, noc)
+        op.grad_descent_iter = min(op.grad_descent_iter, 10)
+        if rng.random() < 0.3:
+            op.finest_scale = max(0, op.finest_scale - int(rng.integers(1, 3)))      # taller finest levels
+        n = int(rng.integers(1, 4))
+        try:
+            ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size), max_batch=n)
+        except F.FotgError:
+            continue
+        prs = [synth_pair(h, w, seed=900 + 3 * k + j, noc=noc) for j in range(n)]
+        out = ofc.calc_batch(torch.stack([dev(q[0]) for q in prs]), torch.stack([dev(q[1]) for q in prs])).cpu().numpy()
+        pr = oracle_params(O, op)
+        for j in (0, n - 1):
+            ref = O.flow(O.pad_frame(prs[j][0], pr.sc_f), O.pad_frame(prs[j][1], pr.sc_f), pr, 0)
+            assert np.array_equal(out[j], ref), (env, w, h, op_point, noc, n, j, float(np.abs(out[j] - ref).max()))
+        ofc.close()
+
+
 def test_random_parameter_sweep():
     """seeded sweep over the PARAMETERS kroeger's OFClass constructor takes (oflow.h:84-111), one random combination per case: patch
     size 4 / 8 / 12 / 16, overlap, scale range, iteration counts with and without early termination, the three thresholds, mean
