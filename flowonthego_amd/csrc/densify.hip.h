@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256) void densify_kernel(const float *__restrict__ 
 // 16x16 pixel tile: it scans all complementary patches in id order, 256 at a time, compacts (in order) the ones whose
 // footprint touches the tile into an LDS list, and every pixel then walks the list -- the serial reference order
 // (patch id; inside a patch: window row, window column; taps cc, fc, cf, ff) is kept, so the sums are bit-identical.
+__device__ __forceinline__ int clamp_pos(int v) { return v < -(1 << 24) ? -(1 << 24) : (v > (1 << 24) ? (1 << 24) : v); }
+
 template <int PS, int NOC>
 __global__ __launch_bounds__(256) void densify_fb_kernel(const float *__restrict__ p_iter, const float *__restrict__ pweight,
                                                          const float *__restrict__ cg_p_iter, const float *__restrict__ cg_pweight,
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(256) void densify_fb_kernel(const float *__restrict
       const size_t pb = (size_t)pair * g.nop + ip;
       const int xi = ip / g.noph, yi = ip - xi * g.noph;
       const float rx = (float)(xi * g.steps + g.offw) + cg_p_iter[pb * 2], ry = (float)(yi * g.steps + g.offh) + cg_p_iter[pb * 2 + 1];
-      const int pos0 = (int)ceil((double)rx + .00001), pos1 = (int)ceil((double)ry + .00001);
+      // (positions of a diverged backward flow saturate the conversion: keep them where the sums below cannot overflow)
+      const int pos0 = clamp_pos((int)ceil((double)rx + .00001)), pos1 = clamp_pos((int)ceil((double)ry + .00001));
       hit = pos0 + UB >= tx0 && pos0 + LB - 1 <= tx0 + 15 && pos1 + UB >= ty0 && pos1 + LB - 1 <= ty0 + 15;
     }
     const unsigned long long m = __ballot(hit);
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void densify_fb_kernel(const float *__restrict
         const int xi = jp / g.noph, yi = jp - xi * g.noph;
         const float u = cg_p_iter[pb * 2], v = cg_p_iter[pb * 2 + 1];
         const float rx = (float)(xi * g.steps + g.offw) + u, ry = (float)(yi * g.steps + g.offh) + v;   // pt_iter (patch.cpp:214-221)
-        const int pos0 = (int)ceil((double)rx + .00001), pos1 = (int)ceil((double)ry + .00001);           // :302-305
+        const int pos0 = clamp_pos((int)ceil((double)rx + .00001)), pos1 = clamp_pos((int)ceil((double)ry + .00001));           // :302-305
         const int pos2 = (int)floorf(rx), pos3 = (int)floorf(ry);
         const float r0 = rx - pos2, r1 = ry - pos3;
         const float wb[4] = {r0 * r1, (1 - r0) * r1, r0 * (1 - r1), (1 - r0) * (1 - r1)};
