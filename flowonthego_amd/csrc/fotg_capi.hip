@@ -312,8 +312,8 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   if (p->usetvref) {
     const LevelGeom &g = c->geom[p->sc_l];
     // lexicographic solver: up to 1024 rows any kernel, up to 16384 rows the tile pipeline (at most four sweeps per launch); the
-    // depth solver has one thread per row of a workgroup
-    if (g.h > (p->depth ? 1024 : 16384) && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
+    // depth solver has one thread per row of a workgroup up to 1024 rows and loops over the rows beyond (one sweep per launch)
+    if (g.h > 16384 && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     if (g.h > 1024 && p->sor_mode == FOTG_SOR_POINT) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }      // (compatibility mode: single-wave solver only)
     if (g.w < 3 || c->geom[p->sc_f].h < 5 || c->geom[p->sc_f].w < 3) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc + (p->depth ? (int)DE_NPLANE : 0));
@@ -1183,7 +1183,10 @@ static int varref_depth_impl(fotg_ctx *c, int l, int n, const float *I0, const f
     LAUNCHCHK();
     // the sweeps are sequential passes over du, so `k` single-sweep launches equal one k-sweep launch bit for bit; the
     // operating points use 3.  (With 0 sweeps the clamped update still runs: uu = min/max(wx + du, 0).)
-    if (c->p.tv_solverit == 3 && 3 * threads <= 1024 && lds) {     // one wave group per sweep
+    if (g.h > 1024) {                                             // more rows than a workgroup has threads: one sweep per launch, rows looped
+      for (int k = 0; k < c->p.tv_solverit; ++k)
+        vr_de_sor_tall_kernel<<<n, 1024, 0, s>>>(a, c->p.tv_sor, camlr, k == c->p.tv_solverit - 1 ? 1 : 0);
+    } else if (c->p.tv_solverit == 3 && 3 * threads <= 1024 && lds) {     // one wave group per sweep
       if (lds == 2) vr_de_sor_kernel<3, 2, true><<<n, 3 * threads, lds_bytes, s>>>(a, c->p.tv_sor, camlr);
       else vr_de_sor_kernel<3, 1, true><<<n, 3 * threads, lds_bytes, s>>>(a, c->p.tv_sor, camlr);
     } else if (c->p.tv_solverit == 3) {

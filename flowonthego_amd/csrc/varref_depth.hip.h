@@ -233,6 +233,49 @@ __global__ __launch_bounds__(1024) void vr_de_sor_kernel(VrArgs a, float omega, 
   }
 }
 
+// Levels of more than 1024 rows (a full-resolution level of a large frame: no operating point gets there): ONE sweep of the same
+// wavefront per launch, one workgroup per pair, every thread walks the rows tid, tid + 1024, ... of a step.  Nothing is carried
+// between steps (the coefficient of the left neighbour is read back: sh of the previous pixel of the row), everything in global
+// memory; within a step the cells of diagonal t are written and those of t - 1 / t + 1 read, so the order inside a step is free.
+// k launches = k sweeps, bit for bit (the sweeps are sequential passes over du).  clamp: the update uu = min/max(wx + du, 0)
+// behind the LAST sweep (refine_variational.cpp:299-314).
+__global__ __launch_bounds__(1024) void vr_de_sor_tall_kernel(VrArgs a, float omega, int camlr, int clamp)
+{
+  const int pair = blockIdx.x, w = a.w, h = a.h, st = a.st;
+  const float *__restrict__ a11 = de_plane(a, pair, DE_A11), *__restrict__ b1 = de_plane(a, pair, DE_B1);
+  const float *__restrict__ sh = de_plane(a, pair, DE_SH), *__restrict__ sv = de_plane(a, pair, DE_SV);
+  float *du = de_plane(a, pair, DE_DU);
+  const float om1 = 1.0f - omega;
+  const int T = w + h - 1;
+  for (int t = 0; t < T; ++t) {
+    for (int j = threadIdx.x; j < h; j += blockDim.x) {
+      const int i = t - j;
+      if (i < 0 || i >= w) continue;
+      const int o = j * st + i;
+      const bool has_t = j > 0, has_b = j < h - 1, has_l = i > 0, has_r = i < w - 1;
+      const float ca = a11[o], cb = b1[o], ch = sh[o], cv = sv[o], cvt = sv[has_t ? o - st : o], hl = has_l ? sh[o - 1] : 0.f;
+      const float own = du[o], up = du[has_t ? o - st : o], lf = du[has_l ? o - 1 : o], dn = du[has_b ? o + st : o], rt = du[has_r ? o + 1 : o];
+      float sigma_u = 0.0f, sum_dpsis = 0.0f;
+      sigma_u = sigma_u - (has_t ? cvt * up : 0.0f);  sum_dpsis = sum_dpsis + (has_t ? cvt : 0.0f);
+      sigma_u = sigma_u - (has_l ? hl * lf : 0.0f);   sum_dpsis = sum_dpsis + (has_l ? hl : 0.0f);
+      sigma_u = sigma_u - (has_b ? cv * dn : 0.0f);   sum_dpsis = sum_dpsis + (has_b ? cv : 0.0f);
+      sigma_u = sigma_u - (has_r ? ch * rt : 0.0f);   sum_dpsis = sum_dpsis + (has_r ? ch : 0.0f);
+      const float A11 = ca + sum_dpsis;
+      const float B1 = cb - sigma_u;
+      du[o] = om1 * own + omega * (B1 / A11);
+    }
+    __syncthreads();
+  }
+  if (!clamp) return;
+  const float *wx = a.single(pair, P_WX);
+  float *uu = de_plane(a, pair, DE_UU);
+  for (int k = threadIdx.x; k < w * h; k += blockDim.x) {
+    const int o = (k / w) * st + k % w;
+    const float s = wx[o] + du[o];
+    uu[o] = camlr == 0 ? (s < 0.0f ? s : 0.0f) : (s > 0.0f ? s : 0.0f);
+  }
+}
+
 // The whole level after the set-up stage in ONE launch, one workgroup (1024 threads) per pair, for levels whose five planes
 // du, uu, s, a11, b1 fit in LDS (<= 8192 cells): per inner iteration the smoothness weights, the data term (per-pixel
 // phases, all threads), the three sweeps (the wave groups of vr_de_sor_kernel's SPLIT form; the other waves only keep the

@@ -117,11 +117,11 @@ def test_depth_varref_golden_reference_vectors(noc):
 
 @pytest.mark.parametrize("path", ["0", "2"])
 @pytest.mark.parametrize("w,h,solverit", [(37, 19, 3), (120, 68, 3), (64, 40, 2), (200, 110, 3), (200, 110, 2), (300, 170, 1), (300, 170, 3),
-                                          (20, 400, 3), (60, 400, 3)])
+                                          (20, 400, 3), (60, 400, 3), (24, 1500, 3), (40, 2100, 2)])
 def test_depth_varref_sizes(w, h, solverit, path, monkeypatch):
     """level sizes with stride padding; the three solver residencies (everything in LDS up to 8192 cells, du alone in LDS
     up to 128 KiB, global memory beyond: 300x170), one wave group per sweep (up to 341 rows) or all sweeps in each thread
-    (the 400-row cases), other sweep counts"""
+    (the 400-row cases), more rows than a workgroup has threads (1 500 / 2 100: rows looped, one sweep per launch), other sweep counts"""
     F, OFClass, VarRefClass, O = _mods()
     monkeypatch.setenv("FOTG_VR_PATH", path)        # 0: one launch per level where it applies (<= 8192 cells, 3 sweeps); 2: launch per stage
     lvl = 2
@@ -212,6 +212,20 @@ def test_depth_random_parameter_sweep():
         ofc.close()
         done += 1
     assert done >= 24, done
+
+
+def test_depth_tall_frame_end_to_end():
+    """a portrait stereo pair refined at FULL resolution (a level of 1 400 rows: beyond one thread per row) == the oracle"""
+    F, OFClass, _, O = _mods()
+    w, h = 300, 1400
+    f0, f1, _ = stereo_pair(h, w, seed=77)
+    op = depth_op(F, 2, w, 1)
+    op.finest_scale, op.coarsest_scale, op.grad_descent_iter = 0, 2, 6
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    assert np.array_equal(ofc.calc(dev(f0), dev(f1)).cpu().numpy(), ref)
+    ofc.close()
 
 
 def test_depth_unsupported_combinations():
