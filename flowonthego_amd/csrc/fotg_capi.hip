@@ -314,7 +314,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
     // lexicographic solver: up to 1024 rows any kernel, up to 16384 rows the tile pipeline (at most four sweeps per launch); the
     // depth solver has one thread per row of a workgroup up to 1024 rows and loops over the rows beyond (one sweep per launch)
     if (g.h > 16384 && p->sor_mode == FOTG_SOR_LEXICOGRAPHIC) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
-    if (g.h > 1024 && p->sor_mode == FOTG_SOR_POINT) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }      // (compatibility mode: single-wave solver only)
+    if (g.h > 16384 && p->sor_mode == FOTG_SOR_POINT) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     if (g.w < 3 || c->geom[p->sc_f].h < 5 || c->geom[p->sc_f].w < 3) { fotg_destroy(c); return FOTG_ERR_UNSUPPORTED; }
     c->vr_pair_stride = (long)g.st * g.h * (P_NSINGLE + C_NCOLOR * c->noc + (p->depth ? (int)DE_NPLANE : 0));
     ALLOC(c->vr, B * c->vr_pair_stride * sizeof(float));
@@ -825,6 +825,7 @@ static bool launch_sor_pipe(int n, float omega, hipStream_t s, const VrArgs &b)
 }
 
 static std::atomic<long> g_tile_launches{0};        // fotg_debug_counter("sor_tiles")
+static std::atomic<long> g_tall_launches{0};        // fotg_debug_counter("sor_tall")
 static std::atomic<long> g_levelpipe_launches{0};   // fotg_debug_counter("level_pipe")
 #ifndef FOTG_TILE_P
 #define FOTG_TILE_P 8                    // prefetch depth (diagonals) of the tile solver
@@ -938,6 +939,11 @@ static bool dispatch_inner_fused(const fotg_ctx *c, const VrArgs &a, int n, int 
 // FOTG_SOR_POINT (sor_coupled_slow_but_readable, a compatibility mode): the single-wave wavefront solver with the point update
 static void dispatch_sor_point(const VrArgs &a, int n, int sweeps, float omega, hipStream_t s)
 {
+  if (a.h > 1024) {                  // more rows than 64 lanes x 16: a sweep per launch, rows looped (vr_sor_tall_kernel)
+    for (int k = 0; k < sweeps; ++k) vr_sor_tall_kernel<true><<<n, 1024, 0, s>>>(a, omega);
+    ++g_tall_launches;
+    return;
+  }
   switch (a.K) {
 #define PT(K_) case K_: vr_sor_kernel<K_, 1, (K_ <= 4 ? 4 : 1), true><<<n, 64, 0, s>>>(a, sweeps, omega); break
     PT(1); PT(2); PT(3); PT(4); PT(6); PT(8); PT(12);
@@ -950,9 +956,16 @@ static void dispatch_sor(const fotg_ctx *c, const VrArgs &a, int n, int sweeps, 
 {
   const int path = c->tune.vr_path;    // 0 = automatic, 1 = single-wave global-memory solver only, 2 = no fused inner loop (tests)
   if (path != 1 && dispatch_sor_pipe(c, a, n, sweeps, omega, s)) return;
-  // levels too tall for the LDS solvers: tiles = (sweep, band of 128 rows), one single-wave workgroup each, pipelined through
-  // global memory (varref_tiles.hip.h); FOTG_VR_PATH=1 (tests) keeps levels of <= 1024 rows on the single-wave kernel below
-  if ((path != 1 || a.h > 1024) && c->vrX[a_level(c, a)] && c->tileSync) {
+  // FOTG_VR_PATH=1 -- tests, and the recompute of a stalled tile pipeline -- uses no inter-workgroup waits anywhere: levels of more than
+  // 1024 rows take the one-workgroup-per-pair wavefront (a sweep per launch), shorter ones the single-wave kernel below
+  if (path == 1 && a.h > 1024) {
+    for (int k = 0; k < sweeps; ++k) vr_sor_tall_kernel<false><<<n, 1024, 0, s>>>(a, omega);
+    ++g_tall_launches;
+    return;
+  }
+  // levels too tall for the LDS solvers: tiles = (sweep, band of 64 rows), one workgroup each, pipelined through global memory
+  // (varref_tiles.hip.h)
+  if (path != 1 && c->vrX[a_level(c, a)] && c->tileSync) {
     const int l = a_level(c, a);
     TileArgs g;
     g.X = c->vrX[l] + (size_t)(a.C - c->vrC[l]) / a.c_pair_stride * c->x_pair_stride[l];      // (views: same pair offset as C)
@@ -1714,6 +1727,7 @@ long fotg_debug_counter(const char *name)
 {
   if (name && !strcmp(name, "sor_stream")) return g_stream_launches;
   if (name && !strcmp(name, "sor_tiles")) return g_tile_launches;
+  if (name && !strcmp(name, "sor_tall")) return g_tall_launches;
   if (name && !strcmp(name, "level_pipe")) return g_levelpipe_launches;
   return -1;
 }

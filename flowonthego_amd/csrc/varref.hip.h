@@ -564,6 +564,34 @@ __global__ __launch_bounds__(64) void vr_sor_kernel(VrArgs a, int sweeps, float 
   }
 }
 
+// The same wavefront for levels of MORE rows than the single wave's 64 lanes x 16: one workgroup per pair, ONE sweep per launch,
+// every thread walks the rows tid, tid + 1024, ... of a step, a barrier per anti-diagonal.  Nothing is carried between steps: the new
+// left / top values are read back from diagonal d - 1, the weight towards the left neighbour from its cell.  Within a step only the
+// cells of diagonal d are written and d - 1 / d + 1 read.  Slow and simple: what FOTG_SOR_POINT runs beyond 1024 rows, and what the
+// self-healing recompute of a stalled tile pipeline runs there (no inter-workgroup waits).
+template <bool POINT>
+__global__ __launch_bounds__(1024) void vr_sor_tall_kernel(VrArgs a, float omega)
+{
+  const int pair = blockIdx.x, w = a.w, h = a.h, S = a.S, RP = a.RP, RPD = a.RPD;
+  const float4 *__restrict__ C = a.Cp(pair);
+  float2 *D = a.Dp(pair);
+  for (int d = 0; d < S; ++d) {
+    for (int j = threadIdx.x; j < h; j += blockDim.x) {
+      const int i = d - j;
+      if (i < 0 || i >= w) continue;
+      const float4 c0 = C[((size_t)d * RP + j) * 2], c1 = C[((size_t)d * RP + j) * 2 + 1];
+      const float hl = d > 0 ? C[((size_t)(d - 1) * RP + j) * 2 + 1].y : 0.f;        // (outside the image: a zero cell)
+      const float2 own = D[(size_t)d * RPD + j];
+      const float2 zero = make_float2(0.f, 0.f);
+      const float2 left = d > 0 ? D[(size_t)(d - 1) * RPD + j] : zero, top = (d > 0 && j > 0) ? D[(size_t)(d - 1) * RPD + j - 1] : zero;
+      const float2 right = D[(size_t)(d + 1) * RPD + j], bottom = D[(size_t)(d + 1) * RPD + j + 1];
+      D[(size_t)d * RPD + j] = POINT ? sor_update_point(own, c0, c1, hl, left, top, right, bottom, omega)
+                                     : sor_update(own, c0, c1, hl, left, top, right, bottom, omega);
+    }
+    __syncthreads();
+  }
+}
+
 // (du,dv) of a level in LDS, skewed like the global arrays (the LDS solvers below).
 //
 // LDS map (dynamic): u64[0..16) = header (unused), u64[16 ..) = float2 cells of D ((S+2) rows of RPD cells: row S stays zero,

@@ -27,8 +27,8 @@ extern "C" {
 #define FOTG_ERR_UNSUPPORTED  4   /* valid in the reference but not implemented here: patch sizes other than 4 / 8 / 12 / 16; a coarsest
                                      level of fewer than 5 rows or 3 columns; with the refinement on: levels of more than 16 384 rows or whose
                                      skewed system array (w + h) x h x 32 bytes reaches 4 GB per pair (lexicographic solver; an 8K frame at
-                                     full resolution is 1.7 GB; the depth mode to 16 384 rows), more than 1 024 rows with sor_coupled_slow_but_readable
-                                     (FOTG_SOR_POINT); red-black ordering in the depth mode */
+                                     full resolution is 1.7 GB; the depth mode and sor_coupled_slow_but_readable, FOTG_SOR_POINT, also run to 16 384 rows);
+                                     red-black ordering in the depth mode */
 #define FOTG_ERR_STALL        5   /* a bounded wait between workgroups of the tile solver (levels of more than 96 rows) timed out (preempted or
                                      starved producer) and the batch could not be recomputed.  The entry points that synchronise with the
                                      host and still have the call's inputs -- fotg_calc, fotg_pipe_wait(host_wait = 1), fotg_pipe_sync,

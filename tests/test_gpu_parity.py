@@ -447,23 +447,26 @@ def test_tile_solver_more_tiles_than_cus():
     ofc.close()
 
 
-@pytest.mark.parametrize("path", ["0", "1"])
-def test_levels_taller_than_1024_rows(path, monkeypatch):
-    """a refined level of more than 1024 rows (beyond 16 rows per lane of the single-wave solver) takes the tile pipeline (21
-    bands) -- also with FOTG_VR_PATH=1, which keeps every shorter level on the single-wave kernel.  op-pt 3 on a narrow tall
-    frame refines the full-resolution level (1304 rows)"""
+@pytest.mark.parametrize("path,sor_mode", [("0", 0), ("tiles", 0), ("1", 0), ("0", 2)])
+def test_levels_taller_than_1024_rows(path, sor_mode, monkeypatch):
+    """a refined level of more than 1024 rows (beyond 16 rows per lane of the single-wave solver): the level pipeline (21 bands),
+    the tile solver with one launch per call (FOTG_VR_LEVELPIPE=0), the one-workgroup-per-pair wavefront without inter-workgroup
+    waits (FOTG_VR_PATH=1: what the recompute of a stalled pipeline runs), and the same for sor_coupled_slow_but_readable.  op-pt 3 on
+    a narrow tall frame refines the full-resolution level (1304 rows)"""
     F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_VR_PATH", path)
+    monkeypatch.setenv("FOTG_VR_PATH", "0" if path == "tiles" else path)
+    if path == "tiles":
+        monkeypatch.setenv("FOTG_VR_LEVELPIPE", "0")
     w, h = 304, 1300
     f0, f1 = synth_pair(h, w, seed=8)
-    op = F.operating_point(3, w, 1)
+    op = F.operating_point(3, w, 1, sor_mode=sor_mode)
     assert op.finest_scale == 0
-    name = b"level_pipe" if path == "0" else b"sor_tiles"          # (FOTG_VR_PATH=0: the level's whole fixed-point loop as one pipeline launch)
+    name = b"sor_tall" if (path == "1" or sor_mode == 2) else b"level_pipe" if path == "0" else b"sor_tiles"
     before = F.lib().fotg_debug_counter(name)
     ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
     out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
     p = oracle_params(O, op)
-    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)
+    ref = O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, sor_mode)
     assert out.shape[0] > 1024 and np.array_equal(out, ref)
     assert F.lib().fotg_debug_counter(name) > before
     assert F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
