@@ -1382,6 +1382,37 @@ def test_context_lifecycle_and_host_threads():
     assert np.array_equal(serial[0][0], O.flow(O.pad_frame(pairs[0][0], pr.sc_f), O.pad_frame(pairs[0][1], pr.sc_f), pr, 0))
 
 
+def test_stalled_wait_heals_on_a_level_of_more_than_1024_rows(monkeypatch):
+    """the same recompute where no single wave reaches: a full-resolution level of 1 304 rows.  The first pass runs the level
+    pipeline, the recompute after an injected stall the one-workgroup-per-pair wavefront (vr_sor_tall_kernel: no inter-workgroup
+    waits) -- the oracle's bits, and no error for a valid call"""
+    import ctypes as C
+    F, OFClass, _, O = _mods()
+    L = F.lib()
+    monkeypatch.setenv("FOTG_TEST_TAPS", "1")
+    w, h = 304, 1300
+    op = F.operating_point(3, w, 1)
+    ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+    a, b = synth_pair(h, w, seed=8)
+    p = oracle_params(O, op)
+    ref = O.flow(O.pad_frame(a, p.sc_f), O.pad_frame(b, p.sc_f), p, 0)
+    A, B = dev(a), dev(b)
+    ow, oh = ofc.out_size()
+    host = np.zeros((oh, ow, 2), np.float32)
+    args = (ofc._h, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), None, host.ctypes.data_as(C.c_void_p))
+    waits = lambda: L.fotg_debug_counter(b"sor_tiles") + L.fotg_debug_counter(b"level_pipe")
+    w0, t0 = waits(), L.fotg_debug_counter(b"sor_tall")
+    assert L.fotg_calc(*args) == 0 and np.array_equal(host, ref)
+    w1 = waits()
+    assert w1 > w0 and L.fotg_debug_counter(b"sor_tall") == t0
+    L.fotg_ctx_counter(ofc._h, b"inject_stall")
+    host[:] = 0
+    assert L.fotg_calc(*args) == 0 and np.array_equal(host, ref)          # healed
+    assert L.fotg_debug_counter(b"sor_tall") > t0 and waits() - w1 == w1 - w0     # the second pass: tall kernel, no waiting kernels
+    assert L.fotg_ctx_counter(ofc._h, b"stalls") == 1
+    ofc.close()
+
+
 def test_stalled_wait_heals_at_the_host_sync_points(monkeypatch):
     """a bounded inter-workgroup wait that times out raises a word in pinned host memory.  The entry points that synchronise with
     the host and still have the call's inputs (fotg_calc, fotg_pipe_wait(host), fotg_pipe_sync) RECOMPUTE the batch on the solver
