@@ -49,6 +49,7 @@ SYMBOLS = [
     ("fotg_node_submit", C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_long)]),
     ("fotg_node_submit_u8", C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_long)]),
     ("fotg_node_submit_scatter", C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_long)]),
+    ("fotg_node_submit_scatter_u8", C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_long)]),
     ("fotg_node_wait", C.c_int, [vp, C.c_long]),
     ("fotg_node_sync", C.c_int, [vp]),
     ("fotg_node_last_hip_error", C.c_int, [vp]),

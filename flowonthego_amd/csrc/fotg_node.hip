@@ -111,7 +111,11 @@ int issue_scatter(fotg_node *nd, Slot &s, const Job &j)
 {
   int b = 0, cnt = 0;
   fotg_node_shard(j.n, nd->ndev, s.index, &b, &cnt);
-  const size_t fbytes = nd->frame_elems * sizeof(float);
+  const size_t fbytes = nd->frame_elems * (j.u8 ? (nd->u8_color ? 3 : 1) : 4);      // (8-bit frames travel as bytes: a quarter of the link traffic)
+  auto submit = [&](int m, const void *a, const void *bb, float *out, void *after, long *t) {
+    return j.u8 ? fotg_pipe_submit_u8(s.pipe, m, (const unsigned char *)a, (const unsigned char *)bb, nullptr, out, after, t)
+                : fotg_pipe_submit(s.pipe, m, (const float *)a, (const float *)bb, nullptr, out, after, t);
+  };
   const char *G0 = (const char *)j.I0[0] + (size_t)b * fbytes, *G1 = (const char *)j.I1[0] + (size_t)b * fbytes;
   float *GO = j.out[0] + (size_t)b * nd->flow_elems;
   const int src_dev = nd->slot[0].device, chunk = j.chunk;
@@ -121,8 +125,7 @@ int issue_scatter(fotg_node *nd, Slot &s, const Job &j)
     for (int o = 0; o < cnt; o += chunk) {
       const int m = cnt - o < chunk ? cnt - o : chunk;
       long t = -1;
-      const int st = fotg_pipe_submit(s.pipe, m, (const float *)(G0 + (size_t)o * fbytes), (const float *)(G1 + (size_t)o * fbytes), nullptr,
-                                      GO + (size_t)o * nd->flow_elems, FOTG_NO_STREAM, &t);
+      const int st = submit(m, G0 + (size_t)o * fbytes, G1 + (size_t)o * fbytes, GO + (size_t)o * nd->flow_elems, FOTG_NO_STREAM, &t);
       if (st != FOTG_OK) return st;
       tickets.push_back(t);
     }
@@ -148,7 +151,7 @@ int issue_scatter(fotg_node *nd, Slot &s, const Job &j)
     if (hipMemcpyPeerAsync(in0, s.device, G0 + (size_t)o * fbytes, src_dev, (size_t)m * fbytes, s.copy) != hipSuccess ||
         hipMemcpyPeerAsync(in1, s.device, G1 + (size_t)o * fbytes, src_dev, (size_t)m * fbytes, s.copy) != hipSuccess) return FOTG_ERR_HIP;
     long t = -1;
-    const int st = fotg_pipe_submit(s.pipe, m, (const float *)in0, (const float *)in1, nullptr, s.stage_out[bi], s.copy, &t);
+    const int st = submit(m, in0, in1, s.stage_out[bi], s.copy, &t);
     if (st != FOTG_OK) return st;
     tickets.push_back(t);
     piece_m.push_back(m);
@@ -293,7 +296,7 @@ int fotg_node_submit_u8(fotg_node *nd, int n, const unsigned char *const *I0, co
   return node_submit(nd, 0, 1, n, (const void *const *)I0, (const void *const *)I1, outflow, 0, ticket);
 }
 
-int fotg_node_submit_scatter(fotg_node *nd, int n, const float *I0, const float *I1, float *outflow, int chunk, long *ticket)
+static int node_scatter(fotg_node *nd, int u8, int n, const void *I0, const void *I1, float *outflow, int chunk, long *ticket)
 {
   if (!nd) return FOTG_ERR_ARG;
   // the staging buffers of the pulling slots, sized for max_batch pairs per chunk, on first use: all of a slot's buffers or none
@@ -325,7 +328,15 @@ int fotg_node_submit_scatter(fotg_node *nd, int n, const float *I0, const float 
   }
   const void *a[1] = {I0}, *b[1] = {I1};
   float *o[1] = {outflow};
-  return node_submit(nd, 1, 0, n, a, b, o, chunk, ticket);
+  return node_submit(nd, 1, u8, n, a, b, o, chunk, ticket);
+}
+int fotg_node_submit_scatter(fotg_node *nd, int n, const float *I0, const float *I1, float *outflow, int chunk, long *ticket)
+{
+  return node_scatter(nd, 0, n, I0, I1, outflow, chunk, ticket);
+}
+int fotg_node_submit_scatter_u8(fotg_node *nd, int n, const unsigned char *I0, const unsigned char *I1, float *outflow, int chunk, long *ticket)
+{
+  return node_scatter(nd, 1, n, I0, I1, outflow, chunk, ticket);
 }
 
 int fotg_node_wait(fotg_node *nd, long ticket)

@@ -69,20 +69,22 @@ class FlowNode:
         return ticket.value, outs
 
     def submit_scatter(self, I0, I1, outflow=None, chunk=None):
-        """the whole batch (n, h, w[, channels]) float32 on devices[0]; the other slots pull their shards in chunks of `chunk`
-        pairs while computing and write their flows back into outflow (n, h_l, w_l, nch) on devices[0]"""
+        """the whole batch (n, h, w[, channels]) float32 or uint8 on devices[0]; the other slots pull their shards in chunks of
+        `chunk` pairs while computing (8-bit frames travel as bytes) and write their flows back into outflow (n, h_l, w_l, nch) on
+        devices[0]"""
         dev = torch.device("cuda", self.devices[0])
-        I0, I1 = _dev_f32(I0, "I0", dev), _dev_f32(I1, "I1", dev)
+        u8 = I0.dtype == torch.uint8
+        I0, I1 = _dev_f32(I0, "I0", dev, dtype=torch.uint8 if u8 else torch.float32), _dev_f32(I1, "I1", dev, dtype=torch.uint8 if u8 else torch.float32)
         n = I0.shape[0]
-        if (tuple(I0.shape) != self._frame_shape(n) and tuple(I0.shape) != self._frame_shape(n) + (1,)) or I1.shape != I0.shape:
-            raise FotgError("frame shape %s does not match the configured %s" % (tuple(I0.shape), self._frame_shape(n)))
+        if (tuple(I0.shape) != self._frame_shape(n, u8) and tuple(I0.shape) != self._frame_shape(n, u8) + (1,)) or I1.shape != I0.shape:
+            raise FotgError("frame shape %s does not match the configured %s" % (tuple(I0.shape), self._frame_shape(n, u8)))
         w, h = self.out_size()
         if outflow is None:
             outflow = torch.empty((n, h, w, self.nch), dtype=torch.float32, device=dev)
             torch.cuda.current_stream(dev).synchronize()
         _dev_f32(outflow, "outflow", dev, (n, h, w, self.nch))
         ticket = C.c_long()
-        check(lib().fotg_node_submit_scatter(self._h, n, C.c_void_p(I0.data_ptr()), C.c_void_p(I1.data_ptr()), C.c_void_p(outflow.data_ptr()),
+        check((lib().fotg_node_submit_scatter_u8 if u8 else lib().fotg_node_submit_scatter)(self._h, n, C.c_void_p(I0.data_ptr()), C.c_void_p(I1.data_ptr()), C.c_void_p(outflow.data_ptr()),
                                              int(chunk or self.max_batch), ticket))
         return ticket.value, outflow
 

@@ -185,6 +185,8 @@ int fotg_node_submit_u8(fotg_node *node, int n, const unsigned char *const *I0, 
  * other slot pulls its shard over xGMI in chunks of `chunk` <= max_batch pairs (hipMemcpyPeerAsync into depth + 1 staging buffers
  * on a copy stream of its own), computes chunk t while chunk t + 1 travels, and writes its flows back into `outflow`. */
 int fotg_node_submit_scatter(fotg_node *node, int n, const float *I0, const float *I1, float *outflow, int chunk, long *ticket);
+/* the same with 8-bit frames (layout as in fotg_calc_batch_u8, three bytes per pixel with u8_color): the shards travel as bytes */
+int fotg_node_submit_scatter_u8(fotg_node *node, int n, const unsigned char *I0, const unsigned char *I1, float *outflow, int chunk, long *ticket);
 /* The calling thread waits for job `ticket` and every job before it on all devices.  A piece whose tile solver gave up a bounded
  * wait is recomputed where its frames are still in place (resident shards, the source slot of a scatter: the call then succeeds);
  * pulled pieces of a scatter cannot be (their staging buffers have been recycled): FOTG_ERR_STALL, re-submit the job.  Returns the

@@ -54,6 +54,13 @@ class FlowNode {
     fotgCheck(fotg_node_submit_scatter(node, n, I0, I1, outflow, chunk, &t), "FlowNode::submit_scatter");
     return t;
   }
+  // the same with 8-bit frames: the shards travel as bytes (a quarter of the link traffic; three bytes per pixel with u8_color)
+  long submit_scatter_u8(int n, const unsigned char *I0, const unsigned char *I1, float *outflow, int chunk)
+  {
+    long t = -1;
+    fotgCheck(fotg_node_submit_scatter_u8(node, n, I0, I1, outflow, chunk, &t), "FlowNode::submit_scatter_u8");
+    return t;
+  }
   void wait(long ticket) { fotgCheck(fotg_node_wait(node, ticket), "FlowNode::wait"); }
   void synchronize() { fotgCheck(fotg_node_sync(node), "FlowNode::synchronize"); }
   fotg_node *handle() { return node; }

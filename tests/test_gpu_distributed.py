@@ -209,7 +209,29 @@ def test_node_scatter_from_the_first_slot():
     assert torch.equal(oa, want) and torch.equal(ob, want)
     with pytest.raises(F.FotgError):
         node.submit_scatter(G0, G1, chunk=3)                                      # chunk > max_batch
+    # 8-bit frames: the shards travel as bytes (fotg_node_submit_scatter_u8); same flows (the frames hold integer values)
+    U0, U1 = G0.to(torch.uint8).contiguous(), G1.to(torch.uint8).contiguous()
+    assert torch.equal(U0.float(), G0)
+    torch.cuda.synchronize()
+    tu, ou = node.submit_scatter(U0, U1, chunk=2)
+    node.wait(tu)
+    assert torch.equal(ou, want)
     node.close()
+    # ... and three-channel 8-bit frames of a gray context (u8_color): three bytes per pixel on the wire
+    from flowonthego_amd.oflow import OFClass
+    opc = F.operating_point(2, ip.width, 1)
+    opc.u8_color = 1
+    C0 = torch.stack([U0, (U0 // 2), (255 - U0)], -1).contiguous()
+    C1 = torch.stack([U1, (U1 // 2), (255 - U1)], -1).contiguous()
+    ofc = OFClass(opc, ip, max_batch=2)
+    wantc = torch.cat([ofc.calc_batch_u8(C0[k:k + 2], C1[k:k + 2]).clone() for k in range(0, C0.shape[0], 2)])
+    ofc.close()
+    nodec = FlowNode(opc, ip, devices=[0, 0], max_batch=2, depth=2)
+    torch.cuda.synchronize()
+    tc, oc = nodec.submit_scatter(C0, C1, chunk=2)
+    nodec.wait(tc)
+    assert torch.equal(oc, wantc)
+    nodec.close()
 
 
 def test_cpp_multi_gpu_example(tmp_path):

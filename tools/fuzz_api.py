@@ -87,7 +87,7 @@ for r in range(rounds):
             if rng.random() < 0.65 or not pending:
                 n = int(rng.integers(1, 2 * mb + 1))
                 ids = [int(x) for x in rng.integers(0, len(pool), n)]
-                if rng.random() < 0.5 and not u8:
+                if rng.random() < 0.5:
                     I0 = torch.stack([pool[i][0] for i in ids]); I1 = torch.stack([pool[i][1] for i in ids])
                     torch.cuda.synchronize()
                     t, out = node.submit_scatter(I0, I1, None, chunk=int(rng.integers(1, mb + 1)))
