@@ -57,8 +57,17 @@ sys.path.insert(0, ROOT)
 W, H, OP_POINT = 1920, 1080, 2
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak
-TRAFFIC_FILE = next((f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
-                     if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f))), "r02_pmc_traffic.json")
+def latest_profile(suffix):
+    """newest profiles/rNN_<suffix> that exists (None if there is none)"""
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for n in range(9, 0, -1):
+        if os.path.exists(os.path.join(d, "r%02d_%s" % (n, suffix))):
+            return "r%02d_%s" % (n, suffix)
+    return None
+
+
+TRAFFIC_FILE = latest_profile("pmc_traffic.json") or "r02_pmc_traffic.json"
+TRAFFIC_FILE_4K = latest_profile("4k_pmc_traffic.json")
 TRAFFIC_NOTE = ("L2-MISS bytes per launch (requests that left an XCD's L2: Infinity-Cache hits are INCLUDED, so this is an upper bound of the HBM "
                 "traffic) from profiles/%s: separate rocprofv3 --pmc passes of this command, bytes = 2 x FETCH_SIZE + WRITE_SIZE -- the x 2 is the guide's "
                 "gfx950 correction, established for 16-byte-per-lane streaming reads (pyr_base_kernel); kernels that read with dword loads (lk, densify, "
@@ -109,6 +118,30 @@ class HipEvents:
         self.hip.hipEventElapsedTime(ms, a, b)
         return ms.value / reps
 
+    def time_each_ms(self, fn, stream, reps):
+        """mean over `reps` launches, EACH between its own pair of events: the events are barrier packets, so no launch overlaps the
+        tail of the one before it -- the duration a profiler reports for the kernel (begin to end of one dispatch).  time_ms() above
+        brackets a train of back-to-back launches instead: there the next dispatch starts filling CUs while the last workgroups of
+        the previous one drain, so its per-launch figure is the launch INTERVAL, a few per cent shorter than the kernel duration
+        (round 5: 154-158 us against rocprofv3's 164 us for pyr_base_kernel)."""
+        evs = []
+        for _ in range(2 * reps):
+            e = C.c_void_p()
+            self.hip.hipEventCreate(e)
+            evs.append(e)
+        fn()
+        for i in range(reps):
+            self.hip.hipEventRecord(evs[2 * i], stream)
+            fn()
+            self.hip.hipEventRecord(evs[2 * i + 1], stream)
+        self.hip.hipEventSynchronize(evs[-1])
+        tot = 0.0
+        for i in range(reps):
+            ms = C.c_float()
+            self.hip.hipEventElapsedTime(ms, evs[2 * i], evs[2 * i + 1])
+            tot += ms.value
+        return tot / reps
+
 
 def stage_breakdown(ofc, I0, I1, out, lib, stream_ptr, reps=5):
     """per-stage GPU time of one step, each stage launched alone between HIP events on the launch stream"""
@@ -140,7 +173,9 @@ def roofline(ofc, I0, I1, lib, stream_ptr, batch):
     from flowonthego_amd._lib import check
     ev = HipEvents()
     p = lambda t: C.c_void_p(t.data_ptr())
-    ms = ev.time_ms(lambda: check(lib.fotg_pyramid_pair(ofc._h, batch, p(I0), p(I1), 1, stream_ptr)), stream_ptr, 20)
+    launch = lambda: check(lib.fotg_pyramid_pair(ofc._h, batch, p(I0), p(I1), 1, stream_ptr))
+    ms_train = ev.time_ms(launch, stream_ptr, 20)          # launch interval of a back-to-back train (what rounds 1-5 reported)
+    ms = ev.time_each_ms(launch, stream_ptr, 20)           # duration of one launch, comparable with rocprofv3's kernel duration
     lw, lh = ofc.width >> 4, ofc.height >> 4
     alg = batch * (2 * W * H * 4 + 2 * lw * lh * 4)
     traffic = None
@@ -155,7 +190,10 @@ def roofline(ofc, I0, I1, lib, stream_ptr, batch):
     gbs = alg / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,1,4,true,1> (frames -> pyramid level 4, both frames of the batch in one launch)",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_semantics": "L2-miss bytes (Infinity-Cache hits included)",
-            "traffic_source": TRAFFIC_NOTE, "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms,
+            "traffic_source": TRAFFIC_NOTE, "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "ms_per_launch_back_to_back": ms_train,
+            "timing": "ms_per_launch: each launch between its own pair of HIP events on the launch stream (no overlap with its neighbours: the figure "
+                      "rocprofv3 reports as the kernel's duration, profiles/); ms_per_launch_back_to_back: 20 launches in a train / 20 = the launch "
+                      "interval, shorter because consecutive dispatches overlap head to tail; achieved / frac use ms_per_launch",
             "measured": "one launch at a time on an otherwise idle GPU; with %s batches in flight the same kernel stretches (profiles/)" % "several"}
 
 
@@ -265,13 +303,13 @@ def synth_frame_pair(h, w, seed, device):
     return f0, f1
 
 
-def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=None):
+def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=None, sor_mode=0):
     """BASELINE configs[3]: ONE 3840x2160 pair at operating point 4 (ps 12, stride 3, scales 7..2, 128 LK iterations, refinement on
     every level up to 960x544): ms per pair one at a time and with four pairs in flight, and the rooflines of its two dominant
     kernels, each timed alone with HIP events on the launch stream."""
     from flowonthego_amd.pipeline import FlowPipeline
     w4, h4 = 3840, 2160
-    op = F.operating_point(4, w4, 1)
+    op = F.operating_point(4, w4, 1, sor_mode=sor_mode)
     op.fast_math = bool(fast)
     ip = F.img_params(width=w4, height=h4, padding=op.patch_size)
     ofc = OFClass(op, ip, max_batch=1, device=local)
@@ -281,7 +319,8 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=
     ms1 = timed(lambda: ofc.calc_batch(f0, f1, None, out), sync, 5) * 1e3
     st = stage_breakdown(ofc, f0, f1, out, lib, stream_ptr, reps=3)
     res = {"workload": "BASELINE configs[3]: one 3840x2160 gray f32 pair, DIS op-pt 4 (ps 12, stride 3, scales %d..%d, %d LK iterations, refinement, "
-                       "lexicographic SOR); inputs resident in HBM, output = finest-scale flow 960x544x2" % (op.coarsest_scale, op.finest_scale, op.grad_descent_iter),
+                       "%s SOR); inputs resident in HBM, output = finest-scale flow 960x544x2" % (op.coarsest_scale, op.finest_scale, op.grad_descent_iter,
+                        "lexicographic" if sor_mode == 0 else "RED-BLACK (the ordering of the reference's CUDA path, src/kernels/flowUtil.cu:297-362; not the parity mode)"),
            "ms_per_pair": ms1, "value": 1e3 / ms1, "unit": "frame-pairs/s",
            "stage_ms": {k: round(v, 4) for k, v in st.items()},
            "reference_point": "19 ms on a GTX 1080 for the reference's CUDA build at this preset (/root/reference/docs/index.md:167-175; other hardware, "
@@ -306,6 +345,8 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=
                                   "three waves per SIMD do not speed it up: docs/EXPERIMENTS.md)")}]
     # one sor_coupled call of the finest level through the tile pipeline
     try:
+        if sor_mode != 0:
+            raise RuntimeError("red-black: no tile pipeline")
         ev = HipEvents()
         from flowonthego_amd._lib import check
         mss = ev.time_ms(lambda: check(lib.fotg_bench_sor_call(ofc._h, lvl, 1, stream_ptr)), stream_ptr, 5)
@@ -314,13 +355,13 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=
         inner = lvl + 1
         traffic4k, src4k = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r05_4k_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_4k_pmc_traffic.json")) else "r04_4k_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE_4K)) as f:
                 tk = json.load(f)["kernels"]
             cand = [v["hbm_bytes_per_launch_corrected"] for k, v in tk.items() if "vr_sor_tile_kernel" in k]
             if cand:
                 traffic4k = int(max(cand))                       # (the largest tile launch = the finest level)
-                src4k = ("L2-miss bytes per launch (Infinity-Cache hits included) from profiles/r0x_4k_pmc_traffic.json (separate rocprofv3 --pmc passes of "
-                         "tools/time_4k_op4.py; bytes = 2 x FETCH_SIZE + WRITE_SIZE) -- NOT measured in this run")
+                src4k = ("L2-miss bytes per launch (Infinity-Cache hits included) from profiles/%s (separate rocprofv3 --pmc passes of "
+                         "tools/time_4k_op4.py; bytes = 2 x FETCH_SIZE + WRITE_SIZE) -- NOT measured in this run" % TRAFFIC_FILE_4K)
         except Exception:
             pass
         res["rooflines"].append({"bound": "hbm", "bound_note": "nearest roof the contract names; the kernel is a pipeline of dependency chains (bound_by)",
@@ -337,14 +378,26 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=
     # as one launch): algorithmic bytes of the finest level = inner x (3 sweeps x 48 B per cell) + (inner - 1) x 84 B per cell for the
     # data terms (11 planes, (du,dv), the 32-byte system cell), over the stage time of that level (set-up and final w + d included)
     try:
+        if sor_mode != 0:
+            raise RuntimeError("red-black: no level pipeline")
         inner = lvl + 1
         alg_lp = lw * lh * (inner * op.var_ref_iter * 48 + (inner - 1) * 84)
         ms_lp = st["varref[%d]" % lvl]
+        traffic_lp = None
+        try:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE_4K)) as f:
+                tk = json.load(f)["kernels"]
+            cand = [v["hbm_bytes_per_launch_corrected"] for k, v in tk.items() if "vr_level_pipe_kernel" in k]
+            if cand and not fast:
+                traffic_lp = int(max(cand))                      # (the largest level-pipe launch = the finest level)
+        except Exception:
+            pass
         res["rooflines"].append({"bound": "hbm", "bound_note": "nearest roof the contract names; the launch is a pipeline of dependency chains",
                                  "kernel": "fotg::vr_level_pipe_kernel (level %d, %dx%d: %d inner iterations x %d sweeps + %d data terms as one launch; FOTG_VR_LEVELPIPE=0 "
                                            "runs one vr_sor_tile_kernel launch per call instead)" % (lvl, lw, lh, inner, op.var_ref_iter, inner - 1),
                                  "achieved": alg_lp / (ms_lp * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_lp / (ms_lp * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "traffic": None, "algorithmic_bytes_per_launch": alg_lp, "ms_per_launch": ms_lp,
+                                 "traffic": traffic_lp, "traffic_semantics": "L2-miss bytes per launch (Infinity-Cache hits included), profiles/%s, not measured in this run" % TRAFFIC_FILE_4K,
+                                 "algorithmic_bytes_per_launch": alg_lp, "ms_per_launch": ms_lp,
                                  "level_pipe_launches_per_process": int(lib.fotg_debug_counter(b"level_pipe")),
                                  "bound_by": "S = %d anti-diagonal steps of the first call + the lag of %d pipeline stages behind it" % (lw + lh - 1, inner * op.var_ref_iter + inner - 1)})
     except Exception as e:
@@ -502,6 +555,7 @@ def cpu_baseline(I0, I1, budget_s=12.0):
             "scaling_vs_single_thread": {"with_pyramid": nall / el / single, "flow_only": nflow / el_flow / (1e3 / flow_ms)},
             "single_thread": single, "single_thread_flow_only": 1e3 / flow_ms,
             "single_thread_stage_ms_per_pair": {k: round(v, 3) for k, v in st.items()}, "time_lines": time_lines,
+            "sample_short": "%d flow-only runs (LK + densify + refinement, 3 scales) of the batch's 1080p pairs, one per thread on %d threads, %.1f s" % (nflow, threads, el_flow),
             "sample": "`value`: %d runs of the flow (kroeger/oflow.cpp:184-337: LK, densification, refinement of the three scales) on pairs of the "
                       "batch (every thread keeps the pyramids of one pair, built outside the timed region like the reference's O.Flow Run-Time "
                       "excludes them, kroeger/oflow.cpp:355-360), op-pt 2 + refinement, one pair per thread on %d pthreads in %.1f s (dis_flow_many: "
@@ -509,6 +563,129 @@ def cpu_baseline(I0, I1, budget_s=12.0):
                       "padding + both pyramids in the loop (kroeger/run_dense.cpp:130-178, scalar in the port) in %.1f s; single thread: %d pairs at "
                       "%.1f pairs/s with the pyramid, %.1f pairs/s flow only; the survey's probe of the real kroeger build (Eigen, -O3 -msse4) "
                       "measured ~130 pairs/s/core flow only on a 2.1 GHz Xeon" % (nflow, threads, el_flow, flags, nall, el, n1, single, 1e3 / flow_ms)}
+
+
+def guard(res, name, fn):
+    """run one informational leg; a failure there must not cost the headline line (the leg's entry says what went wrong)"""
+    try:
+        fn()
+    except Exception as e:
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        res.setdefault(name, {})
+        res[name]["unavailable"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+
+
+SHORT_LINE_MAX = 6000          # bytes; the driver keeps an 8 KB tail of stdout (round 5's 23 KB line could not be parsed)
+
+
+def _r(x, n=4):
+    """float -> n significant digits (keeps the line short); everything else unchanged"""
+    if isinstance(x, float):
+        return float("%.*g" % (n, x)) if x == x and abs(x) != float("inf") else None
+    return x
+
+
+def _pick(d, keys, n=4):
+    return {k: _r(d[k], n) for k in keys if isinstance(d, dict) and k in d}
+
+
+def short_line(res):
+    """The ONE line bench.py prints on stdout: the contract's keys, one roofline, the CPU baseline and one-number summaries of the
+    other legs.  Everything else (stage tables, notes, the list of rooflines, the baseline's sample prose) is in bench_detail.json /
+    on stderr.  tests/test_host.py::test_bench_line_is_short holds it under SHORT_LINE_MAX bytes, also for --gpus 8."""
+    s = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data"), 6)
+    cfg = res.get("config", {})
+    s["config"] = {"workload": "BASELINE configs[2]: batch %s synthetic 1920x1080 gray f32 pairs per GPU resident in HBM, DIS op-pt 2 + variational refinement "
+                               "(%s SOR), output = finest-scale flow 120x68x2" % (cfg.get("batch_per_gpu"), cfg.get("sor")),
+                   "global_batch": cfg.get("global_batch"), "pairs_in_flight": cfg.get("pairs_in_flight"),
+                   "batches_in_flight_per_gpu": res.get("batches_in_flight"),
+                   "parallelism": "frame-pair sharding x%s, no collective" % res.get("n_gpus")}
+    s["one_batch_at_a_time"] = _pick(res.get("one_batch_at_a_time", {}), ("value", "ms_per_step"), 6)
+    if "roofline" in res:
+        s["roofline"] = _pick(res["roofline"], ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                                "ms_per_launch", "ms_per_launch_back_to_back", "unavailable"), 5)
+        if "kernel" in s["roofline"]:
+            s["roofline"]["kernel"] = s["roofline"]["kernel"].split(" (")[0]
+    if "whole_path_hbm_frac" in res:
+        s["whole_path_hbm_frac"] = _r(res["whole_path_hbm_frac"])
+    if "time_dominant_stage" in res:
+        s["time_dominant_stage"] = res["time_dominant_stage"]
+    cb = res.get("cpu_baseline")
+    if cb:
+        s["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "single_thread", "single_thread_flow_only", "unavailable"))
+        if "sample" in cb:
+            s["cpu_baseline"]["sample"] = cb.get("sample_short", cb["sample"][:120])
+        if "parity" in cb:
+            s["cpu_baseline"]["parity"] = _pick(cb["parity"], ("pairs_checked", "mean_epe_px", "bit_identical"))
+    # one-number summaries of the other legs
+    for k in ("fast_math", "u8_frames", "u8_bgr_gray", "rgb_frames"):
+        if k in res:
+            s[k] = _pick(res[k], ("value", "unavailable"))
+            if isinstance(res[k].get("in_flight"), dict):
+                s[k]["in_flight"] = _r(res[k]["in_flight"].get("value"))
+            if "epe_vs_parity_mode_px" in res[k]:
+                s[k]["mean_epe_px"] = _r(res[k]["epe_vs_parity_mode_px"].get("mean"), 3)
+    for k in ("single_pair_no_refine", "full_resolution_output", "sequence_mode", "node_api", "depth_mode"):
+        if k in res:
+            s[k] = _pick(res[k], ("value", "ms_per_pair", "unavailable"))
+    if "redblack" in res:
+        s["redblack"] = _pick(res["redblack"], ("value", "mean_epe_px_vs_lexicographic", "unavailable"))
+    for k in ("config_4k_op4", "config_4k_op4_fast_math", "config_4k_op4_redblack"):
+        if k in res:
+            d = res[k]
+            s[k] = _pick(d, ("ms_per_pair", "unavailable"))
+            if isinstance(d.get("throughput"), dict) and "value" in d["throughput"]:
+                s[k]["throughput"] = _r(d["throughput"]["value"])
+            if isinstance(d.get("in_flight"), dict) and "value" in d["in_flight"]:
+                s[k]["in_flight"] = _r(d["in_flight"]["value"])
+            if "epe_vs_parity_mode_px" in d:
+                s[k]["mean_epe_px"] = _r(d["epe_vs_parity_mode_px"].get("mean"), 3)
+            for rf in d.get("rooflines", []):
+                if "vr_level_pipe" in rf.get("kernel", ""):
+                    s[k]["level_pipe"] = _pick(rf, ("frac", "traffic", "algorithmic_bytes_per_launch", "ms_per_launch"))
+                if "lk_" in rf.get("kernel", "") and rf.get("bound") == "valu":
+                    s[k]["lk_valu_frac"] = _r(rf.get("frac"), 3)
+    if res.get("rccl_ranks") is not None or res.get("n_gpus", 1) > 1:
+        s["rccl_ranks"] = res.get("rccl_ranks")
+    if res.get("shared_gpu_test"):
+        s["shared_gpu_test"] = True
+    if "ms_per_step_per_rank" in res:
+        pr = res["ms_per_step_per_rank"]
+        s["ms_per_step_per_rank"] = {"min": _r(min(pr)), "max": _r(max(pr))}
+    pl = res.get("rank_placement") or []
+    s["gpus_distinct"] = len({p.get("pci_bus_id") for p in pl})
+    sg = res.get("scatter_gather")
+    if sg:
+        s["scatter_gather"] = _pick(sg, ("scatter_plus_compute_ms", "gather_ms", "end_to_end_pairs_per_s", "gathered_flows_match_single_context", "unavailable"))
+    s["detail"] = res.get("detail_file", "bench_detail.json (+ stderr)")
+    return s
+
+
+def emit(res):
+    """detail -> bench_detail.json (gpurun_out/ when it can be created, else the working directory) and stderr; the short line ->
+    stdout, last"""
+    detail = json.dumps(res)
+    for d in (os.path.join(ROOT, "gpurun_out"), os.getcwd()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                f.write(detail + "\n")
+            res["detail_file"] = os.path.relpath(os.path.join(d, "bench_detail.json"), ROOT)
+            break
+        except OSError:
+            continue
+    print("bench.py detail: " + detail, file=sys.stderr)
+    line = json.dumps(short_line(res), separators=(",", ":"))
+    if len(line) > SHORT_LINE_MAX:           # never print a line the driver cannot parse: drop the summaries, keep the contract
+        s = short_line({k: v for k, v in res.items() if k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                                                "scaling", "vs_baseline", "dtype", "data", "config", "batches_in_flight", "one_batch_at_a_time",
+                                                                "roofline", "cpu_baseline", "whole_path_hbm_frac", "rccl_ranks")})
+        s["truncated"] = True
+        line = json.dumps(s, separators=(",", ":"))
+    sys.stdout.flush()
+    print(line, flush=True)
 
 
 def _free_port():
@@ -722,6 +899,7 @@ def main():
                                   "(ps=8, stride 4, scales 6-5-4, 12 LK iterations) + variational refinement on, "
                                   "%s SOR; inputs resident in HBM, output = finest-scale flow 120x68x2" %
                                   (a.batch, "lexicographic (reference order)" if a.sor_mode == 0 else "red-black"),
+                      "batch_per_gpu": a.batch, "sor": "lexicographic, the reference's order" if a.sor_mode == 0 else "red-black",
                       "global_batch": world * a.batch,
                       "pairs_in_flight": world * a.batch * D,
                       "pairs_in_flight_note": "`value` is measured with %d complete batches of %d pairs resident and overlapping per GPU; "
@@ -766,229 +944,261 @@ def main():
             # the whole path against the same roof: pairs/s x 16 654 080 B / 8 TB/s
             res["whole_path_hbm_frac"] = value / world * (2 * W * H * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS
             res["time_dominant_stage"] = max(st, key=st.get)
-            # the tolerance mode (fotg_params::fast_math: patch loop csrc/lk_fast.hip.h, data term csrc/varref_dataterm.inc.h) on the headline workload -- NOT `value`
-            # (the default / parity mode): same steps, one batch at a time and in flight, with the endpoint error against the parity
-            # mode's flows (which are bit-identical to the CPU oracle)
-            opf = F.operating_point(OP_POINT, W, 1, sor_mode=a.sor_mode)
-            opf.fast_math = True
-            ofcf = OFClass(opf, F.img_params(width=W, height=H, padding=opf.patch_size), max_batch=a.batch, device=local)
-            outf = ofcf.new_outflow(a.batch)
-            tff = timed(lambda: ofcf.calc_batch(I0, I1, None, outf), torch.cuda.synchronize, a.steps)
-            stf = stage_breakdown(ofcf, I0, I1, outf, lib, stream_ptr)
-            ofc.calc_batch(I0, I1, None, out); ofcf.calc_batch(I0, I1, None, outf)
-            ef = torch.cat([torch.sqrt(((ofcf.upsample_crop(outf[k:k + 8]) - ofc.upsample_crop(out[k:k + 8])) ** 2).sum(-1)).flatten() for k in range(0, a.batch, 8)])
-            res["fast_math"] = {"value": a.batch / tff, "unit": "frame-pairs/s", "ms_per_step": tff * 1e3,
-                                "note": "fotg_params::fast_math = 1 (tolerance mode of the patch loop and of the refinement's data term), one batch at a time; `value` above is the parity mode",
-                                "lk_stage_ms": {k: round(v, 4) for k, v in stf.items() if k.startswith("lk[")},
-                                "lk_stage_ms_parity_mode": {k: round(v, 4) for k, v in st.items() if k.startswith("lk[")},
-                                "epe_vs_parity_mode_px": {"mean": float(ef.mean()), "p99": float(torch.quantile(ef[::64], 0.99)), "max": float(ef.max()),
-                                                          "note": "full-resolution flows (1920x1080) of all %d pairs against the parity mode's (== the CPU oracle)" % a.batch}}
-            del ef
-            if pipe:
-                pipef = FlowPipeline(opf, F.img_params(width=W, height=H, padding=opf.patch_size), max_batch=a.batch, depth=D, device=local)
-                torch.cuda.synchronize()
-                k = [0]
-
-                def subf():
-                    f0, f1, o = slots[k[0] % D]
-                    pipef.submit(f0, f1, None, o, after_current_stream=False)
-                    k[0] += 1
-                tfi = timed(subf, pipef.synchronize, a.steps, warm=2 * D)
-                res["fast_math"]["in_flight"] = {"value": a.batch / tfi, "unit": "frame-pairs/s", "ms_per_step": tfi * 1e3, "batches_in_flight": D}
-                pipef.close()
-            ofcf.close()
-            del outf
-            # the same batch handed over as 8-bit frames (fotg_calc_batch_u8) -- NOT the headline value:
-            # the reference's API takes float32 frames (src/run_dense.cpp:144-162)
-            U0, U1 = I0.to(torch.uint8), I1.to(torch.uint8)
-            for _ in range(2):
-                ofc.calc_batch_u8(U0, U1, None, out)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(a.steps):
-                ofc.calc_batch_u8(U0, U1, None, out)
-            torch.cuda.synchronize()
-            res["u8_frames"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
-                                "note": "same workload with uint8 input frames (exact conversion on load), one batch at a time; informational"}
-            if pipe:
-                u8 = [(f0.to(torch.uint8), f1.to(torch.uint8), o) for f0, f1, o in slots]
-                torch.cuda.synchronize()
-                for i in range(2 * D):
-                    pipe.submit(u8[i % D][0], u8[i % D][1], None, u8[i % D][2], after_current_stream=False)
-                pipe.synchronize()
-                t1 = time.perf_counter()
-                for i in range(a.steps):
-                    pipe.submit(u8[i % D][0], u8[i % D][1], None, u8[i % D][2], after_current_stream=False)
-                pipe.synchronize()
-                res["u8_frames"]["in_flight"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s", "batches_in_flight": D,
-                                                 "note": "fotg_pipe_submit_u8: the product mode for 8-bit video (SURVEY 8f row 2), %d batches in flight" % D}
-                del u8
-            # three-channel 8-bit frames of a GRAY context (fotg_params::u8_color = 1: B,G,R as cv::imread delivers; SURVEY 8f row 2
-            # "RGB -> gray on device", kroeger/run_dense.cpp:199-209): OpenCV's fixed-point BGR2GRAY on load in the pyramid kernel
-            opc = F.operating_point(OP_POINT, W, 1, sor_mode=a.sor_mode)
-            opc.u8_color = 1
-            C0 = torch.stack([I0.to(torch.uint8), torch.roll(I0, 1, 2).to(torch.uint8), torch.roll(I0, 2, 1).to(torch.uint8)], -1).contiguous()
-            C1 = torch.stack([I1.to(torch.uint8), torch.roll(I1, 1, 2).to(torch.uint8), torch.roll(I1, 2, 1).to(torch.uint8)], -1).contiguous()
-            ofcc = OFClass(opc, F.img_params(width=W, height=H, padding=opc.patch_size), max_batch=a.batch, device=local)
-            outc = ofcc.new_outflow(a.batch)
-            G0 = ((C0[..., 0].to(torch.int32) * 1868 + C0[..., 1].to(torch.int32) * 9617 + C0[..., 2].to(torch.int32) * 4899 + 8192) >> 14).to(torch.uint8)
-            G1 = ((C1[..., 0].to(torch.int32) * 1868 + C1[..., 1].to(torch.int32) * 9617 + C1[..., 2].to(torch.int32) * 4899 + 8192) >> 14).to(torch.uint8)
-            same_c = torch.equal(ofcc.calc_batch_u8(C0, C1, None, outc), ofc.calc_batch_u8(G0, G1))
-            del G0, G1
-            tcg = timed(lambda: ofcc.calc_batch_u8(C0, C1, None, outc), torch.cuda.synchronize, a.steps)
-            evc = HipEvents()
-            from flowonthego_amd._lib import check as _chkc
-            msc = evc.time_ms(lambda: _chkc(lib.fotg_pyramid_pair_u8(ofcc._h, a.batch, C.c_void_p(C0.data_ptr()), C.c_void_p(C1.data_ptr()), 1, stream_ptr)), stream_ptr, 10)
-            algc = a.batch * (2 * W * H * 3 + 2 * 120 * 68 * 4)
-            res["u8_bgr_gray"] = {"value": a.batch / tcg, "unit": "frame-pairs/s", "equals_gray_u8_path": bool(same_c),
-                                  "note": "uint8 B,G,R frames (n x 1080 x 1920 x 3), gray on load like cv::imread(IMREAD_GRAYSCALE) (kroeger/run_dense.cpp:199-209), one batch at a time; informational",
-                                  "roofline": {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<unsigned char,1,4,true,3> (both frames of %d pairs)" % a.batch,
-                                               "achieved": algc / (msc * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algc / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                               "traffic": None, "algorithmic_bytes_per_launch": algc, "ms_per_launch": msc}}
-            if pipe:
-                pipec = FlowPipeline(opc, F.img_params(width=W, height=H, padding=opc.patch_size), max_batch=a.batch, depth=D, device=local)
-                outs_c = [ofcc.new_outflow(a.batch) for _ in range(D)]
-                torch.cuda.synchronize()
-                for i in range(2 * D):
-                    pipec.submit(C0, C1, None, outs_c[i % D], after_current_stream=False)
-                pipec.synchronize()
-                t1 = time.perf_counter()
-                for i in range(a.steps):
-                    pipec.submit(C0, C1, None, outs_c[i % D], after_current_stream=False)
-                pipec.synchronize()
-                res["u8_bgr_gray"]["in_flight"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s", "batches_in_flight": D}
-                pipec.close()
-                del outs_c
-            ofcc.close()
-            del C0, C1, outc
-            # BASELINE configs[1]: ONE 1080p pair, op-pt 2's patch parameters (ps 8, stride 4, 3 scales), no variational refinement:
-            # the latency of a single call (informational; the headline value is configs[2])
-            op1 = F.operating_point(OP_POINT, W, 1)
-            op1.use_var_ref = False
-            ofc1 = OFClass(op1, F.img_params(width=W, height=H, padding=op1.patch_size), max_batch=1, device=local)
-            o1 = ofc1.new_outflow(1)
-            for _ in range(5):
-                ofc1.calc_batch(I0[:1], I1[:1], None, o1)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(100):
-                ofc1.calc_batch(I0[:1], I1[:1], None, o1)
-            torch.cuda.synchronize()
-            ms1 = (time.perf_counter() - t1) * 10.0
-            alg1 = 2 * W * H * 4 + 2 * 120 * 68 * 4
-            res["single_pair_no_refine"] = {"ms_per_pair": ms1, "value": 1e3 / ms1, "unit": "frame-pairs/s",
-                                            "note": "BASELINE configs[1]: one 1080p pair per call, 3 scales, no refinement; informational",
-                                            "roofline": {"bound": "hbm", "kernel": "whole call (8 launches: pyramid 2, LK 3, densify 3)", "achieved": alg1 / (ms1 * 1e-3) / 1e9,
-                                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                                         "algorithmic_bytes_per_launch": alg1, "ms_per_launch": ms1,
-                                                         "bound_by": "latency: eight dependent launches of one pair's work (a 1080p pair fills 2 % of the chip at the coarse levels)"}}
-            ofc1.close()
             sync = torch.cuda.synchronize
             nst = max(5, min(a.steps, 20))
-            # the reference's post-processing on the device (kroeger/run_dense.cpp:407-414: x 2^finest, bilinear upsample, crop): the
-            # full-resolution flow of the batch; SURVEY 8d counts 2 W H 4 more bytes per pair for it
-            full = torch.empty((a.batch, H, W, 2), device=dev)
-            sync()
-            ev = HipEvents()
-            from flowonthego_amd._lib import check as _chk
-            msu = ev.time_ms(lambda: _chk(lib.fotg_upsample_crop(ofc._h, a.batch, C.c_void_p(out.data_ptr()), C.c_void_p(full.data_ptr()), stream_ptr)), stream_ptr, 10)
-            algu = a.batch * (2 * W * H * 4 + 2 * 120 * 68 * 4)
-            tfu = timed(lambda: (ofc.calc_batch(I0, I1, None, out), ofc.upsample_crop(out, full)), sync, nst)
-            res["full_resolution_output"] = {"value": a.batch / tfu, "unit": "frame-pairs/s", "ms_per_step": tfu * 1e3,
-                                             "note": "fotg_calc_batch + fotg_upsample_crop (the reference's post-processing on the device), one batch at a time",
-                                             "roofline": {"bound": "hbm", "kernel": "fotg::upsample_crop_kernel (120x68x2 flow -> 1920x1080x2, %d pairs)" % a.batch,
-                                                          "achieved": algu / (msu * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                          "frac": algu / (msu * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                                          "algorithmic_bytes_per_launch": algu, "ms_per_launch": msu}}
-            del full
-            # video mode (fotg_calc_sequence): batch + 1 consecutive frames -> batch flows, every pyramid built once
-            seq = torch.cat([I0, I1[-1:]]).contiguous()
-            tsq = timed(lambda: ofc.calc_sequence(seq, None, out), sync, nst)
-            res["sequence_mode"] = {"value": a.batch / tsq, "unit": "frame-pairs/s", "ms_per_step": tsq * 1e3,
-                                    "note": "%d consecutive f32 frames -> %d flows, one pyramid per frame (fotg_calc_sequence), one batch at a time" % (a.batch + 1, a.batch)}
-            del seq
-            # red-black SOR (the ordering north_star names; not reference-equivalent): same workload, own context
-            if a.sor_mode == 0:
-                oprb = F.operating_point(OP_POINT, W, 1, sor_mode=1)
-                ofcrb = OFClass(oprb, F.img_params(width=W, height=H, padding=oprb.patch_size), max_batch=a.batch, device=local)
-                outrb = ofcrb.new_outflow(a.batch)
-                trb = timed(lambda: ofcrb.calc_batch(I0, I1, None, outrb), sync, nst)
-                ofc.calc_batch(I0, I1, None, out)
-                sync()
-                d = (outrb - out) * float(1 << op.finest_scale)            # full-resolution pixels
-                res["redblack"] = {"value": a.batch / trb, "unit": "frame-pairs/s", "ms_per_step": trb * 1e3,
-                                   "mean_epe_px_vs_lexicographic": float(torch.sqrt((d ** 2).sum(-1)).mean().item()),
-                                   "note": "FOTG_SOR_REDBLACK: red-black ordering of the same 2x2 block update, one batch at a time; the parity mode is the "
-                                           "lexicographic order of the reference's sor_coupled (`value` above)"}
-                ofcrb.close()
-                del outrb
-            # the reference's own input layout: 3-channel interleaved f32 frames (src/run_dense.cpp:147), own context, same batch
-            op3 = F.operating_point(OP_POINT, W, 3, sor_mode=a.sor_mode)
-            ofc3 = OFClass(op3, F.img_params(width=W, height=H, padding=op3.patch_size), max_batch=a.batch, device=local)
-            R0 = torch.stack([I0, I0.roll(3, 2), I0.roll(5, 1)], -1).contiguous()
-            R1 = torch.stack([I1, I1.roll(3, 2), I1.roll(5, 1)], -1).contiguous()
-            t3 = timed(lambda: ofc3.calc_batch(R0, R1, None, out), sync, nst)
-            ev = HipEvents()
-            p3 = lambda t: C.c_void_p(t.data_ptr())
-            from flowonthego_amd._lib import check as _check
-            ms3 = ev.time_ms(lambda: _check(lib.fotg_pyramid_pair(ofc3._h, a.batch, p3(R0), p3(R1), 1, stream_ptr)), stream_ptr, 10)
-            alg3 = a.batch * (2 * W * H * 3 * 4 + 2 * 120 * 68 * 3 * 4)
-            res["rgb_frames"] = {"value": a.batch / t3, "unit": "frame-pairs/s", "ms_per_step": t3 * 1e3,
-                                 "note": "same workload with 3-channel interleaved f32 frames, the layout the reference's src/ path feeds (src/run_dense.cpp:147); "
-                                         "3x the input bytes; one batch at a time",
-                                 "whole_path_hbm_frac": a.batch / t3 * (2 * W * H * 3 * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS,
-                                 "roofline": {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,3,4,true> (RGB frames -> pyramid level 4)", "achieved": alg3 / (ms3 * 1e-3) / 1e9,
-                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                              "algorithmic_bytes_per_launch": alg3, "ms_per_launch": ms3}}
-            if pipe:
-                from flowonthego_amd.pipeline import FlowPipeline as _FP
-                pipe3 = _FP(op3, F.img_params(width=W, height=H, padding=op3.patch_size), max_batch=a.batch, depth=D, device=local)
-                o3 = [pipe3.new_outflow(a.batch) for _ in range(D)]
-                sync()
-                k3 = [0]
 
-                def sub3():
-                    pipe3.submit(R0, R1, None, o3[k3[0] % D], after_current_stream=False)      # (the same frames for every slot: 3.2 GB per step, far beyond any cache)
-                    k3[0] += 1
-                t3f = timed(sub3, pipe3.synchronize, max(nst, 4 * D), warm=2 * D)
-                res["rgb_frames"]["in_flight"] = {"value": a.batch / t3f, "unit": "frame-pairs/s", "ms_per_step": t3f * 1e3, "batches_in_flight": D,
-                                                  "same_bits_as_one_at_a_time": bool(torch.equal(o3[0], ofc3.calc_batch(R0, R1)))}
-                pipe3.close()
-                del o3
-            ofc3.close()
-            del R0, R1
-            # the one-process multi-GPU entry (fotg_node_*: one pipe + one issuing host thread per device slot) on this rank's GPU alone:
-            # the same steps through the C-ABI a C++ host would use; must not be slower than the pipe it wraps
-            if pipe:
-                from flowonthego_amd.node import FlowNode
-                node = FlowNode(op, F.img_params(width=W, height=H, padding=op.patch_size), devices=[local], max_batch=a.batch, depth=D)
-                sync()
-                outs_n = [[o] for (_, _, o) in slots]
-                tickets = []
+            def leg_fast_math():
+                # the tolerance mode (fotg_params::fast_math: patch loop csrc/lk_fast.hip.h, data term csrc/varref_dataterm.inc.h) on the headline workload -- NOT `value`
+                # (the default / parity mode): same steps, one batch at a time and in flight, with the endpoint error against the parity
+                # mode's flows (which are bit-identical to the CPU oracle)
+                opf = F.operating_point(OP_POINT, W, 1, sor_mode=a.sor_mode)
+                opf.fast_math = True
+                ofcf = OFClass(opf, F.img_params(width=W, height=H, padding=opf.patch_size), max_batch=a.batch, device=local)
+                outf = ofcf.new_outflow(a.batch)
+                tff = timed(lambda: ofcf.calc_batch(I0, I1, None, outf), torch.cuda.synchronize, a.steps)
+                stf = stage_breakdown(ofcf, I0, I1, outf, lib, stream_ptr)
+                ofc.calc_batch(I0, I1, None, out); ofcf.calc_batch(I0, I1, None, outf)
+                ef = torch.cat([torch.sqrt(((ofcf.upsample_crop(outf[k:k + 8]) - ofc.upsample_crop(out[k:k + 8])) ** 2).sum(-1)).flatten() for k in range(0, a.batch, 8)])
+                res["fast_math"] = {"value": a.batch / tff, "unit": "frame-pairs/s", "ms_per_step": tff * 1e3,
+                                    "note": "fotg_params::fast_math = 1 (tolerance mode of the patch loop and of the refinement's data term), one batch at a time; `value` above is the parity mode",
+                                    "lk_stage_ms": {k: round(v, 4) for k, v in stf.items() if k.startswith("lk[")},
+                                    "lk_stage_ms_parity_mode": {k: round(v, 4) for k, v in st.items() if k.startswith("lk[")},
+                                    "epe_vs_parity_mode_px": {"mean": float(ef.mean()), "p99": float(torch.quantile(ef[::64], 0.99)), "max": float(ef.max()),
+                                                              "note": "full-resolution flows (1920x1080) of all %d pairs against the parity mode's (== the CPU oracle)" % a.batch}}
+                del ef
+                if pipe:
+                    pipef = FlowPipeline(opf, F.img_params(width=W, height=H, padding=opf.patch_size), max_batch=a.batch, depth=D, device=local)
+                    torch.cuda.synchronize()
+                    k = [0]
 
-                def node_steps(n):
-                    for i in range(n):
-                        f0, f1, _ = slots[i % D]
-                        tickets.append(node.submit(a.batch, [f0], [f1], outs_n[i % D])[0])
-                        if len(tickets) > 8:
-                            node.wait(tickets.pop(0))
-                    node.synchronize()
-                    tickets.clear()
-                node_steps(2 * D)
+                    def subf():
+                        f0, f1, o = slots[k[0] % D]
+                        pipef.submit(f0, f1, None, o, after_current_stream=False)
+                        k[0] += 1
+                    tfi = timed(subf, pipef.synchronize, a.steps, warm=2 * D)
+                    res["fast_math"]["in_flight"] = {"value": a.batch / tfi, "unit": "frame-pairs/s", "ms_per_step": tfi * 1e3, "batches_in_flight": D}
+                    pipef.close()
+                ofcf.close()
+                del outf
+            guard(res, 'fast_math', leg_fast_math)
+
+            def leg_u8_frames():
+                # the same batch handed over as 8-bit frames (fotg_calc_batch_u8) -- NOT the headline value:
+                # the reference's API takes float32 frames (src/run_dense.cpp:144-162)
+                U0, U1 = I0.to(torch.uint8), I1.to(torch.uint8)
+                for _ in range(2):
+                    ofc.calc_batch_u8(U0, U1, None, out)
+                torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                node_steps(a.steps)
-                tn = (time.perf_counter() - t1) / a.steps
-                ofc.calc_batch(slots[0][0], slots[0][1], None, out)
+                for _ in range(a.steps):
+                    ofc.calc_batch_u8(U0, U1, None, out)
+                torch.cuda.synchronize()
+                res["u8_frames"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s",
+                                    "note": "same workload with uint8 input frames (exact conversion on load), one batch at a time; informational"}
+                if pipe:
+                    u8 = [(f0.to(torch.uint8), f1.to(torch.uint8), o) for f0, f1, o in slots]
+                    torch.cuda.synchronize()
+                    for i in range(2 * D):
+                        pipe.submit(u8[i % D][0], u8[i % D][1], None, u8[i % D][2], after_current_stream=False)
+                    pipe.synchronize()
+                    t1 = time.perf_counter()
+                    for i in range(a.steps):
+                        pipe.submit(u8[i % D][0], u8[i % D][1], None, u8[i % D][2], after_current_stream=False)
+                    pipe.synchronize()
+                    res["u8_frames"]["in_flight"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s", "batches_in_flight": D,
+                                                     "note": "fotg_pipe_submit_u8: the product mode for 8-bit video (SURVEY 8f row 2), %d batches in flight" % D}
+                    del u8
+            guard(res, 'u8_frames', leg_u8_frames)
+
+            def leg_u8_bgr_gray():
+                # three-channel 8-bit frames of a GRAY context (fotg_params::u8_color = 1: B,G,R as cv::imread delivers; SURVEY 8f row 2
+                # "RGB -> gray on device", kroeger/run_dense.cpp:199-209): OpenCV's fixed-point BGR2GRAY on load in the pyramid kernel
+                opc = F.operating_point(OP_POINT, W, 1, sor_mode=a.sor_mode)
+                opc.u8_color = 1
+                C0 = torch.stack([I0.to(torch.uint8), torch.roll(I0, 1, 2).to(torch.uint8), torch.roll(I0, 2, 1).to(torch.uint8)], -1).contiguous()
+                C1 = torch.stack([I1.to(torch.uint8), torch.roll(I1, 1, 2).to(torch.uint8), torch.roll(I1, 2, 1).to(torch.uint8)], -1).contiguous()
+                ofcc = OFClass(opc, F.img_params(width=W, height=H, padding=opc.patch_size), max_batch=a.batch, device=local)
+                outc = ofcc.new_outflow(a.batch)
+                G0 = ((C0[..., 0].to(torch.int32) * 1868 + C0[..., 1].to(torch.int32) * 9617 + C0[..., 2].to(torch.int32) * 4899 + 8192) >> 14).to(torch.uint8)
+                G1 = ((C1[..., 0].to(torch.int32) * 1868 + C1[..., 1].to(torch.int32) * 9617 + C1[..., 2].to(torch.int32) * 4899 + 8192) >> 14).to(torch.uint8)
+                same_c = torch.equal(ofcc.calc_batch_u8(C0, C1, None, outc), ofc.calc_batch_u8(G0, G1))
+                del G0, G1
+                tcg = timed(lambda: ofcc.calc_batch_u8(C0, C1, None, outc), torch.cuda.synchronize, a.steps)
+                evc = HipEvents()
+                from flowonthego_amd._lib import check as _chkc
+                msc = evc.time_ms(lambda: _chkc(lib.fotg_pyramid_pair_u8(ofcc._h, a.batch, C.c_void_p(C0.data_ptr()), C.c_void_p(C1.data_ptr()), 1, stream_ptr)), stream_ptr, 10)
+                algc = a.batch * (2 * W * H * 3 + 2 * 120 * 68 * 4)
+                res["u8_bgr_gray"] = {"value": a.batch / tcg, "unit": "frame-pairs/s", "equals_gray_u8_path": bool(same_c),
+                                      "note": "uint8 B,G,R frames (n x 1080 x 1920 x 3), gray on load like cv::imread(IMREAD_GRAYSCALE) (kroeger/run_dense.cpp:199-209), one batch at a time; informational",
+                                      "roofline": {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<unsigned char,1,4,true,3> (both frames of %d pairs)" % a.batch,
+                                                   "achieved": algc / (msc * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algc / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                   "traffic": None, "algorithmic_bytes_per_launch": algc, "ms_per_launch": msc}}
+                if pipe:
+                    pipec = FlowPipeline(opc, F.img_params(width=W, height=H, padding=opc.patch_size), max_batch=a.batch, depth=D, device=local)
+                    outs_c = [ofcc.new_outflow(a.batch) for _ in range(D)]
+                    torch.cuda.synchronize()
+                    for i in range(2 * D):
+                        pipec.submit(C0, C1, None, outs_c[i % D], after_current_stream=False)
+                    pipec.synchronize()
+                    t1 = time.perf_counter()
+                    for i in range(a.steps):
+                        pipec.submit(C0, C1, None, outs_c[i % D], after_current_stream=False)
+                    pipec.synchronize()
+                    res["u8_bgr_gray"]["in_flight"] = {"value": a.batch * a.steps / (time.perf_counter() - t1), "unit": "frame-pairs/s", "batches_in_flight": D}
+                    pipec.close()
+                    del outs_c
+                ofcc.close()
+                del C0, C1, outc
+            guard(res, 'u8_bgr_gray', leg_u8_bgr_gray)
+
+            def leg_single_pair_no_refine():
+                # BASELINE configs[1]: ONE 1080p pair, op-pt 2's patch parameters (ps 8, stride 4, 3 scales), no variational refinement:
+                # the latency of a single call (informational; the headline value is configs[2])
+                op1 = F.operating_point(OP_POINT, W, 1)
+                op1.use_var_ref = False
+                ofc1 = OFClass(op1, F.img_params(width=W, height=H, padding=op1.patch_size), max_batch=1, device=local)
+                o1 = ofc1.new_outflow(1)
+                for _ in range(5):
+                    ofc1.calc_batch(I0[:1], I1[:1], None, o1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(100):
+                    ofc1.calc_batch(I0[:1], I1[:1], None, o1)
+                torch.cuda.synchronize()
+                ms1 = (time.perf_counter() - t1) * 10.0
+                alg1 = 2 * W * H * 4 + 2 * 120 * 68 * 4
+                res["single_pair_no_refine"] = {"ms_per_pair": ms1, "value": 1e3 / ms1, "unit": "frame-pairs/s",
+                                                "note": "BASELINE configs[1]: one 1080p pair per call, 3 scales, no refinement; informational",
+                                                "roofline": {"bound": "hbm", "kernel": "whole call (8 launches: pyramid 2, LK 3, densify 3)", "achieved": alg1 / (ms1 * 1e-3) / 1e9,
+                                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                             "algorithmic_bytes_per_launch": alg1, "ms_per_launch": ms1,
+                                                             "bound_by": "latency: eight dependent launches of one pair's work (a 1080p pair fills 2 % of the chip at the coarse levels)"}}
+                ofc1.close()
+            guard(res, 'single_pair_no_refine', leg_single_pair_no_refine)
+
+            def leg_full_resolution_output():
+                # the reference's post-processing on the device (kroeger/run_dense.cpp:407-414: x 2^finest, bilinear upsample, crop): the
+                # full-resolution flow of the batch; SURVEY 8d counts 2 W H 4 more bytes per pair for it
+                full = torch.empty((a.batch, H, W, 2), device=dev)
                 sync()
-                res["node_api"] = {"value": a.batch / tn, "unit": "frame-pairs/s", "ms_per_step": tn * 1e3, "devices": [local], "batches_in_flight": D,
-                                   "same_bits_as_single_context": bool(torch.equal(outs_n[0][0], out)),
-                                   "note": "fotg_node_submit / fotg_node_wait (include/fotg.h) with one device slot: K steps, one window"}
-                node.close()
-            # BASELINE configs[3]
-            res["config_4k_op4"] = config_4k_op4(F, OFClass, lib, local, dev, stream_ptr)
-            ref4k = res["config_4k_op4"].pop("_full_flow")
-            res["config_4k_op4_fast_math"] = config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=True, ref_flow=ref4k)
-            del ref4k
+                ev = HipEvents()
+                from flowonthego_amd._lib import check as _chk
+                msu = ev.time_ms(lambda: _chk(lib.fotg_upsample_crop(ofc._h, a.batch, C.c_void_p(out.data_ptr()), C.c_void_p(full.data_ptr()), stream_ptr)), stream_ptr, 10)
+                algu = a.batch * (2 * W * H * 4 + 2 * 120 * 68 * 4)
+                tfu = timed(lambda: (ofc.calc_batch(I0, I1, None, out), ofc.upsample_crop(out, full)), sync, nst)
+                res["full_resolution_output"] = {"value": a.batch / tfu, "unit": "frame-pairs/s", "ms_per_step": tfu * 1e3,
+                                                 "note": "fotg_calc_batch + fotg_upsample_crop (the reference's post-processing on the device), one batch at a time",
+                                                 "roofline": {"bound": "hbm", "kernel": "fotg::upsample_crop_kernel (120x68x2 flow -> 1920x1080x2, %d pairs)" % a.batch,
+                                                              "achieved": algu / (msu * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                              "frac": algu / (msu * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                              "algorithmic_bytes_per_launch": algu, "ms_per_launch": msu}}
+                del full
+            guard(res, 'full_resolution_output', leg_full_resolution_output)
+
+            def leg_sequence_mode():
+                # video mode (fotg_calc_sequence): batch + 1 consecutive frames -> batch flows, every pyramid built once
+                seq = torch.cat([I0, I1[-1:]]).contiguous()
+                tsq = timed(lambda: ofc.calc_sequence(seq, None, out), sync, nst)
+                res["sequence_mode"] = {"value": a.batch / tsq, "unit": "frame-pairs/s", "ms_per_step": tsq * 1e3,
+                                        "note": "%d consecutive f32 frames -> %d flows, one pyramid per frame (fotg_calc_sequence), one batch at a time" % (a.batch + 1, a.batch)}
+                del seq
+            guard(res, 'sequence_mode', leg_sequence_mode)
+
+            def leg_redblack():
+                # red-black SOR (the ordering north_star names; not reference-equivalent): same workload, own context
+                if a.sor_mode == 0:
+                    oprb = F.operating_point(OP_POINT, W, 1, sor_mode=1)
+                    ofcrb = OFClass(oprb, F.img_params(width=W, height=H, padding=oprb.patch_size), max_batch=a.batch, device=local)
+                    outrb = ofcrb.new_outflow(a.batch)
+                    trb = timed(lambda: ofcrb.calc_batch(I0, I1, None, outrb), sync, nst)
+                    ofc.calc_batch(I0, I1, None, out)
+                    sync()
+                    d = (outrb - out) * float(1 << op.finest_scale)            # full-resolution pixels
+                    res["redblack"] = {"value": a.batch / trb, "unit": "frame-pairs/s", "ms_per_step": trb * 1e3,
+                                       "mean_epe_px_vs_lexicographic": float(torch.sqrt((d ** 2).sum(-1)).mean().item()),
+                                       "note": "FOTG_SOR_REDBLACK: red-black ordering of the same 2x2 block update, one batch at a time; the parity mode is the "
+                                               "lexicographic order of the reference's sor_coupled (`value` above)"}
+                    ofcrb.close()
+                    del outrb
+            guard(res, 'redblack', leg_redblack)
+
+            def leg_rgb_frames():
+                # the reference's own input layout: 3-channel interleaved f32 frames (src/run_dense.cpp:147), own context, same batch
+                op3 = F.operating_point(OP_POINT, W, 3, sor_mode=a.sor_mode)
+                ofc3 = OFClass(op3, F.img_params(width=W, height=H, padding=op3.patch_size), max_batch=a.batch, device=local)
+                R0 = torch.stack([I0, I0.roll(3, 2), I0.roll(5, 1)], -1).contiguous()
+                R1 = torch.stack([I1, I1.roll(3, 2), I1.roll(5, 1)], -1).contiguous()
+                t3 = timed(lambda: ofc3.calc_batch(R0, R1, None, out), sync, nst)
+                ev = HipEvents()
+                p3 = lambda t: C.c_void_p(t.data_ptr())
+                from flowonthego_amd._lib import check as _check
+                ms3 = ev.time_ms(lambda: _check(lib.fotg_pyramid_pair(ofc3._h, a.batch, p3(R0), p3(R1), 1, stream_ptr)), stream_ptr, 10)
+                alg3 = a.batch * (2 * W * H * 3 * 4 + 2 * 120 * 68 * 3 * 4)
+                res["rgb_frames"] = {"value": a.batch / t3, "unit": "frame-pairs/s", "ms_per_step": t3 * 1e3,
+                                     "note": "same workload with 3-channel interleaved f32 frames, the layout the reference's src/ path feeds (src/run_dense.cpp:147); "
+                                             "3x the input bytes; one batch at a time",
+                                     "whole_path_hbm_frac": a.batch / t3 * (2 * W * H * 3 * 4 + 2 * 120 * 68 * 4) / 1e9 / HBM_PEAK_GBS,
+                                     "roofline": {"bound": "hbm", "kernel": "fotg::pyr_base_kernel<float,3,4,true> (RGB frames -> pyramid level 4)", "achieved": alg3 / (ms3 * 1e-3) / 1e9,
+                                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                  "algorithmic_bytes_per_launch": alg3, "ms_per_launch": ms3}}
+                if pipe:
+                    from flowonthego_amd.pipeline import FlowPipeline as _FP
+                    pipe3 = _FP(op3, F.img_params(width=W, height=H, padding=op3.patch_size), max_batch=a.batch, depth=D, device=local)
+                    o3 = [pipe3.new_outflow(a.batch) for _ in range(D)]
+                    sync()
+                    k3 = [0]
+
+                    def sub3():
+                        pipe3.submit(R0, R1, None, o3[k3[0] % D], after_current_stream=False)      # (the same frames for every slot: 3.2 GB per step, far beyond any cache)
+                        k3[0] += 1
+                    t3f = timed(sub3, pipe3.synchronize, max(nst, 4 * D), warm=2 * D)
+                    res["rgb_frames"]["in_flight"] = {"value": a.batch / t3f, "unit": "frame-pairs/s", "ms_per_step": t3f * 1e3, "batches_in_flight": D,
+                                                      "same_bits_as_one_at_a_time": bool(torch.equal(o3[0], ofc3.calc_batch(R0, R1)))}
+                    pipe3.close()
+                    del o3
+                ofc3.close()
+                del R0, R1
+            guard(res, 'rgb_frames', leg_rgb_frames)
+
+            def leg_node_api():
+                # the one-process multi-GPU entry (fotg_node_*: one pipe + one issuing host thread per device slot) on this rank's GPU alone:
+                # the same steps through the C-ABI a C++ host would use; must not be slower than the pipe it wraps
+                if pipe:
+                    from flowonthego_amd.node import FlowNode
+                    node = FlowNode(op, F.img_params(width=W, height=H, padding=op.patch_size), devices=[local], max_batch=a.batch, depth=D)
+                    sync()
+                    outs_n = [[o] for (_, _, o) in slots]
+                    tickets = []
+
+                    def node_steps(n):
+                        for i in range(n):
+                            f0, f1, _ = slots[i % D]
+                            tickets.append(node.submit(a.batch, [f0], [f1], outs_n[i % D])[0])
+                            if len(tickets) > 8:
+                                node.wait(tickets.pop(0))
+                        node.synchronize()
+                        tickets.clear()
+                    node_steps(2 * D)
+                    t1 = time.perf_counter()
+                    node_steps(a.steps)
+                    tn = (time.perf_counter() - t1) / a.steps
+                    ofc.calc_batch(slots[0][0], slots[0][1], None, out)
+                    sync()
+                    res["node_api"] = {"value": a.batch / tn, "unit": "frame-pairs/s", "ms_per_step": tn * 1e3, "devices": [local], "batches_in_flight": D,
+                                       "same_bits_as_single_context": bool(torch.equal(outs_n[0][0], out)),
+                                       "note": "fotg_node_submit / fotg_node_wait (include/fotg.h) with one device slot: K steps, one window"}
+                    node.close()
+            guard(res, 'node_api', leg_node_api)
+
+            def leg_config_4k_op4():
+                # BASELINE configs[3]
+                res["config_4k_op4"] = config_4k_op4(F, OFClass, lib, local, dev, stream_ptr)
+                ref4k = res["config_4k_op4"].pop("_full_flow")
+                res["config_4k_op4_fast_math"] = config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=True, ref_flow=ref4k)
+                # the ordering north_star names (red-black at every size, src/kernels/flowUtil.cu:297-362): ms per pair + distance to the parity mode
+                res["config_4k_op4_redblack"] = config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, ref_flow=ref4k, sor_mode=1)
+                del ref4k
+            guard(res, 'config_4k_op4', leg_config_4k_op4)
         if a.extras:
             # stereo depth mode (kroeger SELECTMODE=2): same frames as a rectified pair, one displacement channel
             opd = F.operating_point(OP_POINT, W, 1, sor_mode=0)
@@ -1007,17 +1217,18 @@ def main():
             ofcd.close()
             del outd
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(I0, I1)
-            # the same leg also checks the timed batch's result against the oracle ("EPE vs kroeger CPU")
-            from oracle import oracle as O
-            p = O.op_point(OP_POINT, W, 1)
-            ofc.calc_batch(I0, I1, None, out)
-            got = out[:2].cpu().numpy()
-            ref = [O.flow(O.pad_frame(I0[k].cpu().numpy(), p.sc_f), O.pad_frame(I1[k].cpu().numpy(), p.sc_f), p, a.sor_mode) for k in range(2)]
-            d = np.stack(ref) - got
-            res["cpu_baseline"]["parity"] = {"pairs_checked": 2, "mean_epe_px": float(np.sqrt((d ** 2).sum(-1)).mean()),
-                                             "max_abs_diff": float(np.abs(d).max()), "bit_identical": bool((d == 0).all())}
-        print(json.dumps(res))
+            def leg_cpu_baseline():
+                res["cpu_baseline"] = cpu_baseline(I0, I1)
+                # the same leg also checks the timed batch's result against the oracle ("EPE vs kroeger CPU")
+                from oracle import oracle as O
+                p = O.op_point(OP_POINT, W, 1)
+                ofc.calc_batch(I0, I1, None, out)
+                got = out[:2].cpu().numpy()
+                ref = [O.flow(O.pad_frame(I0[k].cpu().numpy(), p.sc_f), O.pad_frame(I1[k].cpu().numpy(), p.sc_f), p, a.sor_mode) for k in range(2)]
+                d = np.stack(ref) - got
+                res["cpu_baseline"]["parity"] = {"pairs_checked": 2, "mean_epe_px": float(np.sqrt((d ** 2).sum(-1)).mean()),
+                                                 "max_abs_diff": float(np.abs(d).max()), "bit_identical": bool((d == 0).all())}
+            guard(res, "cpu_baseline", leg_cpu_baseline)
     if dist and a.scatter_gather and not shared:
         # end to end with the frames starting on rank 0 and the flows ending there (RCCL over xGMI: scatter + gather only)
         # chunked, double-buffered: chunk t+1 travels (grouped ncclSend/ncclRecv) while chunk t is computed; nothing is padded
@@ -1045,9 +1256,9 @@ def main():
             want = ofc.calc_batch(I0, I1)
             torch.cuda.synchronize()
             ok = all(torch.equal(full[r * a.batch:(r + 1) * a.batch], want) for r in range(world))
-            print(json.dumps({"scatter_gather": {"scatter_plus_compute_ms": (t2 - t0) * 1e3, "gather_ms": (t3 - t2) * 1e3, "chunk_pairs": chunk,
-                                                 "end_to_end_pairs_per_s": world * a.batch / (t3 - t0), "gathered_shape": list(full.shape),
-                                                 "gathered_flows_match_single_context": bool(ok)}}))
+            res["scatter_gather"] = {"scatter_plus_compute_ms": (t2 - t0) * 1e3, "gather_ms": (t3 - t2) * 1e3, "chunk_pairs": chunk,
+                                     "end_to_end_pairs_per_s": world * a.batch / (t3 - t0), "gathered_shape": list(full.shape),
+                                     "gathered_flows_match_single_context": bool(ok)}
         flag = torch.tensor([0 if ok else 1], device=dev)
         td.all_reduce(flag)
         if int(flag.item()):
@@ -1058,6 +1269,8 @@ def main():
     if dist:
         td.barrier()
         td.destroy_process_group()
+    if rank == 0:
+        emit(res)                # the ONE stdout line, last
 
 
 if __name__ == "__main__":

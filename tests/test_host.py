@@ -241,6 +241,63 @@ def test_bench_gpus_flag_cannot_print_a_line_for_another_n():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and '"metric"' not in r.stdout
 
 
+def test_bench_line_is_short(capsys, tmp_path, monkeypatch):
+    """the driver keeps an 8 KB tail of stdout and round 5's 23 KB line could not be parsed.  bench.py's ONE stdout
+    line is built by short_line() from the detailed result: here from round 5's real 23 KB result (profiles/r05_bench_line.json), also
+    blown up to --gpus 8 (8 placements, per-rank times, scatter/gather totals) and with absurdly long notes -- always under
+    SHORT_LINE_MAX bytes, always with the contract's keys, the roofline and the CPU baseline; the detail goes to a side file"""
+    import json
+    B = _load_bench()
+    res = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    assert len(json.dumps(res)) > 20000                                # (the canned result really is the long one)
+    res["config"].update(batch_per_gpu=64, sor="lexicographic")
+    res["config_4k_op4_redblack"] = dict(res["config_4k_op4"], epe_vs_parity_mode_px={"mean": 0.05, "p99": 0.2, "max": 1.0})
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "one_batch_at_a_time", "roofline", "cpu_baseline", "whole_path_hbm_frac")
+
+    def check(r):
+        s = B.short_line(r)
+        line = json.dumps(s, separators=(",", ":"))
+        assert len(line) < B.SHORT_LINE_MAX <= 6000, len(line)
+        for k in contract:
+            assert k in s, k
+        assert s["value"] == pytest.approx(r["value"], rel=1e-5) and s["ms_per_step"] == pytest.approx(r["ms_per_step"], rel=1e-5)
+        assert set(s["config"]) >= {"workload", "global_batch", "pairs_in_flight"} and "model" not in s["config"]
+        assert set(s["roofline"]) >= {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "ms_per_launch"}
+        assert s["roofline"]["frac"] == pytest.approx(r["roofline"]["achieved"] / r["roofline"]["peak"], rel=1e-3)
+        assert set(s["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "single_thread", "parity"}
+        assert set(s["one_batch_at_a_time"]) == {"value", "ms_per_step"}
+        for k in ("config_4k_op4", "config_4k_op4_fast_math", "config_4k_op4_redblack"):
+            assert set(s[k]) >= {"ms_per_pair", "throughput"}
+        return s, line
+
+    s1, line1 = check(res)
+    assert s1["n_gpus"] == 1 and s1["gpus_distinct"] == 1
+    # --gpus 8
+    r8 = json.loads(json.dumps(res))
+    r8.update(n_gpus=8, rccl_ranks=8, ms_per_step_per_rank=[0.34 + 0.001 * k for k in range(8)],
+              rank_placement=[{"rank": k, "local_rank": k, "pci_bus_id": "0000:%02x:00.0" % (5 + 8 * k)} for k in range(8)],
+              scatter_gather={"scatter_plus_compute_ms": 12.5, "gather_ms": 0.4, "chunk_pairs": 16, "end_to_end_pairs_per_s": 39000.0,
+                              "gathered_shape": [512, 68, 120, 2], "gathered_flows_match_single_context": True})
+    s8, _ = check(r8)
+    assert s8["rccl_ranks"] == 8 and s8["gpus_distinct"] == 8 and s8["ms_per_step_per_rank"] == {"min": 0.34, "max": 0.347}
+    assert all(not isinstance(v, (list, dict)) for v in s8["scatter_gather"].values())          # scalars only
+    # prose in the detail does not leak into the line
+    rl = json.loads(json.dumps(r8))
+    for k, v in rl.items():
+        if isinstance(v, dict):
+            v["note"] = "x" * 5000
+    check(rl)
+    # emit(): detail to the side file, the short line is the LAST (and only) stdout line
+    monkeypatch.setattr(B, "ROOT", str(tmp_path))
+    B.emit(json.loads(json.dumps(res)))
+    out = capsys.readouterr()
+    lines = out.out.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 6000 and json.loads(lines[0])["metric"] == res["metric"]
+    det = json.load(open(tmp_path / "gpurun_out" / "bench_detail.json"))
+    assert det["stage_ms"] == res["stage_ms"] and "rooflines" in det and "bench.py detail: " in out.err
+
+
 def test_cpp_flow_writers_match_the_python_ones(tmp_path):
     """include/fotg/flowio.h: OFC::SaveFlowFile / OFC::SavePFMFile (kroeger/run_dense.cpp:16-81) write the bytes flowonthego_amd.flo
     writes (whose .flo layout is pinned against the reference's golden file in tests/test_oracle.py)"""
