@@ -598,7 +598,7 @@ def short_line(res):
                     "dtype", "data"), 6)
     cfg = res.get("config", {})
     s["config"] = {"workload": "BASELINE configs[2]: batch %s synthetic 1920x1080 gray f32 pairs per GPU resident in HBM, DIS op-pt 2 + variational refinement "
-                               "(%s SOR), output = finest-scale flow 120x68x2" % (cfg.get("batch_per_gpu"), cfg.get("sor")),
+                               "(SOR order: %s), output = finest-scale flow 120x68x2" % (cfg.get("batch_per_gpu"), cfg.get("sor")),
                    "global_batch": cfg.get("global_batch"), "pairs_in_flight": cfg.get("pairs_in_flight"),
                    "batches_in_flight_per_gpu": res.get("batches_in_flight"),
                    "parallelism": "frame-pair sharding x%s, no collective" % res.get("n_gpus")}
@@ -899,7 +899,7 @@ def main():
                                   "(ps=8, stride 4, scales 6-5-4, 12 LK iterations) + variational refinement on, "
                                   "%s SOR; inputs resident in HBM, output = finest-scale flow 120x68x2" %
                                   (a.batch, "lexicographic (reference order)" if a.sor_mode == 0 else "red-black"),
-                      "batch_per_gpu": a.batch, "sor": "lexicographic, the reference's order" if a.sor_mode == 0 else "red-black",
+                      "batch_per_gpu": a.batch, "sor": "lexicographic = the reference's order" if a.sor_mode == 0 else "red-black",
                       "global_batch": world * a.batch,
                       "pairs_in_flight": world * a.batch * D,
                       "pairs_in_flight_note": "`value` is measured with %d complete batches of %d pairs resident and overlapping per GPU; "

@@ -39,6 +39,7 @@ SYMBOLS = [
     ("fotg_pipe_destroy", None, [vp]),
     ("fotg_pipe_submit", C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_long)]),
     ("fotg_pipe_submit_u8", C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_long)]),
+    ("fotg_pipe_submit_ex", C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_long)]),
     ("fotg_pipe_wait", C.c_int, [vp, C.c_long, vp, C.c_int]),
     ("fotg_pipe_sync", C.c_int, [vp]),
     ("fotg_pipe_ticket_event", C.c_int, [vp, C.c_long, C.POINTER(vp)]),

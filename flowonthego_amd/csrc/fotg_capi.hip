@@ -241,6 +241,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   if (p->max_iter < 0 || p->tv_solverit < 0 || p->tv_innerit < 0) return FOTG_ERR_ARG;
   if (p->costfct < 0 || p->costfct > 2 || (p->costfct == 2 && !(p->normoutlier > 0))) return FOTG_ERR_ARG;
   if (p->depth && p->usetvref && p->sor_mode != FOTG_SOR_LEXICOGRAPHIC) return FOTG_ERR_UNSUPPORTED;
+  if (p->sor_mode < FOTG_SOR_LEXICOGRAPHIC || p->sor_mode > FOTG_SOR_POINT) return FOTG_ERR_ARG;      // (an unknown value would run the lexicographic arithmetic without its buffers)
   if (p->u8_color < 0 || p->u8_color > 2 || (p->u8_color && p->noc != 1)) return FOTG_ERR_ARG;
   ON_DEVICE(device);
   fotg_ctx *c = new (std::nothrow) fotg_ctx();
@@ -1484,9 +1485,14 @@ struct fotg_pipe {
   // it set cannot tell which of the context's batches raised it, so it recomputes every batch of that context that has not been
   // verified yet -- on the solver path without inter-workgroup waits (FOTG_VR_PATH=1's) -- from the arguments kept here.  The caller's
   // contract (frames and outflow untouched until the ticket has been waited for) is what makes that legal.
-  struct Args { int n, u8; const void *I0, *I1; const float *initflow; float *out; } args[4 * FOTG_PIPE_MAX_DEPTH];
+  // A ticket is HEALABLE only while its buffers are contractually still in place: submitted without FOTG_SUBMIT_NO_RECOMPUTE and not yet
+  // handed out through fotg_pipe_wait(host_wait = 0) / fotg_pipe_ticket_event (whoever waits that way may free or reuse the frames and the
+  // outflow as soon as THEIR wait returns, without the pipe knowing).  Suspects that are not healable are reported, never recomputed.
+  struct Args { int n, u8, healable; const void *I0, *I1; const float *initflow; float *out; } args[4 * FOTG_PIPE_MAX_DEPTH];
   signed char tstatus[4 * FOTG_PIPE_MAX_DEPTH];      // per ticket (of the last nring): 0 unknown, 1 good, 2 stalled and not recomputed
-  long verified[FOTG_PIPE_MAX_DEPTH];                // per slot: tickets below this one are known good (or have their status in tstatus)
+  long verified[FOTG_PIPE_MAX_DEPTH];                // per slot: tickets below this one are known good (or have their status in tstatus / lost_*)
+  long lost_lo[FOTG_PIPE_MAX_DEPTH], lost_hi[FOTG_PIPE_MAX_DEPTH];   // per slot: tickets of [lost_lo, lost_hi) were suspects of a flagged stall when the ring
+                                                     // (the last 4 * depth submissions) no longer described them: never recomputed, FOTG_ERR_STALL on every wait
   long healed;                                       // batches recomputed so far
   std::mutex *mu;                                    // submit / verification (fotg_node waits from another thread than the one that submits)
 };
@@ -1555,8 +1561,8 @@ int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int
 }
 
 extern "C++" {
-// one batch again on context c, synchronously, on the solver path that has no inter-workgroup waits (single-wave solver; levels of
-// more than 1024 rows have only the tile pipeline: those are simply tried again); FOTG_OK = the flow is in place and valid
+// one batch again on context c, synchronously, on the solver paths that have no inter-workgroup waits (FOTG_VR_PATH = 1: the single-wave
+// solver; levels of more than 1024 rows run vr_sor_tall_kernel, one workgroup per pair); FOTG_OK = the flow is in place and valid
 template <typename T>
 static int recompute_safe(fotg_ctx *c, int n, const T *I0, const T *I1, const float *initflow, float *outflow, hipStream_t s)
 {
@@ -1581,7 +1587,12 @@ static int pipe_verify(fotg_pipe *q, long t, int heal, int *newly_stalled = null
   const int k = (int)(t % q->depth);
   fotg_ctx *c = q->ctx[k];
   auto known = [&](long u) { return u >= q->submitted - q->nring; };       // (the ring still describes ticket u)
-  if (t < q->verified[k]) return known(t) && q->tstatus[t % q->nring] == 2 ? FOTG_ERR_STALL : FOTG_OK;
+  // status of a ticket that has been classified: from the ring while it is there, afterwards from the slot's range of lost suspects
+  auto status_of = [&](long u) {
+    if (known(u)) return q->tstatus[u % q->nring] == 2 ? FOTG_ERR_STALL : FOTG_OK;
+    return u >= q->lost_lo[k] && u < q->lost_hi[k] ? FOTG_ERR_STALL : FOTG_OK;
+  };
+  if (t < q->verified[k]) return status_of(t);
   const bool flagged = c->stall_host && *(volatile int *)c->stall_host != 0;
   if (!flagged) {
     // everything of this slot that has completed so far is good: at least the tickets up to t
@@ -1595,10 +1606,17 @@ static int pipe_verify(fotg_pipe *q, long t, int heal, int *newly_stalled = null
   ++c->stalls;
   for (long u = q->verified[k]; u < q->submitted; ++u) {
     if (u % q->depth != k) continue;
-    if (!known(u)) continue;                                              // (more than 4 * depth submissions ago: nothing is known about it any more)
+    if (!known(u)) {
+      // more than 4 * depth submissions ago: its arguments are gone, so it can be neither recomputed nor cleared -- it stays a suspect
+      // (a node submits an unbounded number of pieces per job; ADVICE round 5: such a ticket used to be waited for as FOTG_OK)
+      if (q->lost_hi[k] <= q->lost_lo[k]) { q->lost_lo[k] = u; q->lost_hi[k] = u + 1; }
+      else { if (u < q->lost_lo[k]) q->lost_lo[k] = u; if (u + 1 > q->lost_hi[k]) q->lost_hi[k] = u + 1; }
+      if (newly_stalled) ++*newly_stalled;
+      continue;
+    }
     int st = FOTG_ERR_STALL;
-    if (heal) {
-      const fotg_pipe::Args &ar = q->args[u % q->nring];
+    const fotg_pipe::Args &ar = q->args[u % q->nring];
+    if (heal && ar.healable) {
       st = ar.u8 ? recompute_safe<unsigned char>(c, ar.n, (const unsigned char *)ar.I0, (const unsigned char *)ar.I1, ar.initflow, ar.out, q->stream[k])
                  : recompute_safe<float>(c, ar.n, (const float *)ar.I0, (const float *)ar.I1, ar.initflow, ar.out, q->stream[k]);
       if (st == FOTG_OK) ++q->healed;
@@ -1608,11 +1626,11 @@ static int pipe_verify(fotg_pipe *q, long t, int heal, int *newly_stalled = null
     if (st != FOTG_OK && newly_stalled) ++*newly_stalled;
   }
   q->verified[k] = q->submitted;
-  return known(t) && q->tstatus[t % q->nring] == 2 ? FOTG_ERR_STALL : FOTG_OK;
+  return status_of(t);
 }
 
 template <typename T>
-static int pipe_submit(fotg_pipe *q, int n, const T *I0, const T *I1, const float *initflow, float *outflow, void *after_stream, long *ticket)
+static int pipe_submit(fotg_pipe *q, int n, const T *I0, const T *I1, const float *initflow, float *outflow, void *after_stream, long *ticket, int flags = 0)
 {
   if (!q || !I0 || !I1 || !outflow) return FOTG_ERR_ARG;
   std::lock_guard<std::mutex> lock(*q->mu);
@@ -1631,6 +1649,7 @@ static int pipe_submit(fotg_pipe *q, int n, const T *I0, const T *I1, const floa
   {
     fotg_pipe::Args &ar = q->args[q->submitted % q->nring];
     ar.n = n; ar.u8 = sizeof(T) == 1; ar.I0 = I0; ar.I1 = I1; ar.initflow = initflow; ar.out = outflow;
+    ar.healable = !(flags & FOTG_SUBMIT_NO_RECOMPUTE);
     q->tstatus[q->submitted % q->nring] = 0;
   }
   if (ticket) *ticket = q->submitted;
@@ -1649,6 +1668,14 @@ int fotg_pipe_submit_u8(fotg_pipe *q, int n, const unsigned char *I0, const unsi
   return pipe_submit<unsigned char>(q, n, I0, I1, initflow, outflow, after_stream, ticket);
 }
 
+int fotg_pipe_submit_ex(fotg_pipe *q, int n, const void *I0, const void *I1, int u8, const float *initflow, float *outflow, void *after_stream,
+                        int flags, long *ticket)
+{
+  if (flags & ~FOTG_SUBMIT_NO_RECOMPUTE) return FOTG_ERR_ARG;
+  return u8 ? pipe_submit<unsigned char>(q, n, (const unsigned char *)I0, (const unsigned char *)I1, initflow, outflow, after_stream, ticket, flags)
+            : pipe_submit<float>(q, n, (const float *)I0, (const float *)I1, initflow, outflow, after_stream, ticket, flags);
+}
+
 int fotg_pipe_wait(fotg_pipe *q, long ticket, void *stream, int host_wait)
 {
   if (!q || ticket < 0) return FOTG_ERR_ARG;
@@ -1663,6 +1690,11 @@ int fotg_pipe_wait(fotg_pipe *q, long ticket, void *stream, int host_wait)
     return pipe_verify(q, ticket, host_wait != 2);
   }
   HIPCHK(hipStreamWaitEvent((hipStream_t)stream, q->done[e], 0));
+  {
+    // the caller's stream owns the result from here on and may free / reuse the buffers behind this wait: never recompute into them
+    std::lock_guard<std::mutex> lock(*q->mu);
+    if (ticket >= q->submitted - q->nring) q->args[ticket % q->nring].healable = 0;
+  }
   return FOTG_OK;
 }
 
@@ -1676,6 +1708,7 @@ int fotg_pipe_ticket_event(fotg_pipe *q, long ticket, void **event)
   std::lock_guard<std::mutex> lock(*q->mu);
   if (ticket >= q->submitted) return FOTG_ERR_ARG;      // (an event of the ring that was never recorded, or belongs to an older batch)
   *event = (void *)q->done[ticket % q->nring];
+  if (ticket >= q->submitted - q->nring) q->args[ticket % q->nring].healable = 0;       // (handed out: the pipe cannot know when its buffers go)
   return FOTG_OK;
 }
 

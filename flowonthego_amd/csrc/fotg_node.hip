@@ -112,9 +112,10 @@ int issue_scatter(fotg_node *nd, Slot &s, const Job &j)
   int b = 0, cnt = 0;
   fotg_node_shard(j.n, nd->ndev, s.index, &b, &cnt);
   const size_t fbytes = nd->frame_elems * (j.u8 ? (nd->u8_color ? 3 : 1) : 4);      // (8-bit frames travel as bytes: a quarter of the link traffic)
+  // pulled pieces live in staging buffers that are recycled behind device-side waits: never recomputed (FOTG_SUBMIT_NO_RECOMPUTE at
+  // SUBMIT, not only at the wait: a host wait of another job on this pipe may verify the slot while the piece is still in flight)
   auto submit = [&](int m, const void *a, const void *bb, float *out, void *after, long *t) {
-    return j.u8 ? fotg_pipe_submit_u8(s.pipe, m, (const unsigned char *)a, (const unsigned char *)bb, nullptr, out, after, t)
-                : fotg_pipe_submit(s.pipe, m, (const float *)a, (const float *)bb, nullptr, out, after, t);
+    return fotg_pipe_submit_ex(s.pipe, m, a, bb, j.u8, nullptr, out, after, s.index == 0 ? 0 : FOTG_SUBMIT_NO_RECOMPUTE, t);
   };
   const char *G0 = (const char *)j.I0[0] + (size_t)b * fbytes, *G1 = (const char *)j.I1[0] + (size_t)b * fbytes;
   float *GO = j.out[0] + (size_t)b * nd->flow_elems;

@@ -1,6 +1,6 @@
 """FlowNode: one process, several GPUs (fotg_node_* of include/fotg.h; SURVEY.md 8e "one process per node with one host thread
-+ stream set per GPU").  A batch of n frame pairs is cut into contiguous shards, pair k -> slot k * ndev / n (the same ranges as
-flowonthego_amd.shard.shard_range), every slot runs its shard through a pipe (fotg_pipe_*) on its device.  Results are
++ stream set per GPU").  A batch of n frame pairs is cut into contiguous shards -- slot d gets n // ndev pairs, the first n % ndev slots
+one more: fotg_node_shard, the same ranges as flowonthego_amd.shard.shard_range --, every slot runs its shard through a pipe (fotg_pipe_*) on its device.  Results are
 bit-identical to OFClass.calc_batch.  The reference drives one device (src/run_dense.cpp:277-289)."""
 import ctypes as C
 

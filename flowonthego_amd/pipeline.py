@@ -34,9 +34,13 @@ class FlowPipeline:
         w, h = self.out_size()
         return torch.empty((n, h, w, self.nch), dtype=torch.float32, device=self.device)
 
-    def submit(self, I0, I1, initflow=None, outflow=None, after_current_stream=True):
+    def submit(self, I0, I1, initflow=None, outflow=None, after_current_stream=True, no_recompute=False):
         """enqueue one batch (n, h, w[, channels]) float32 or uint8 behind the current torch stream's work; returns
         (ticket, outflow).  I0, I1 and outflow must stay alive and untouched until wait(ticket) / synchronize().
+        Recompute contract (include/fotg.h): a host wait that finds a stall flag recomputes only batches that have NOT been handed
+        to a stream through wait(ticket) -- after wait(ticket) the waiting stream owns the result and the tensors may be freed or
+        reused; such a batch is reported (FotgError: FOTG_ERR_STALL) by wait(ticket, host=True) / synchronize(), or through
+        take_stalls().  no_recompute=True says at submit that the buffers will not stay in place.
         after_current_stream=False starts at once: the caller then guarantees that nothing still enqueued on a torch stream
         writes the frames or touches `outflow` -- including earlier users of memory that torch's caching allocator has
         recycled into these tensors (the pipe's streams are not torch's; synchronize once after allocating the buffers).
@@ -59,9 +63,12 @@ class FlowPipeline:
             sc = self.op.coarsest_scale + 1
             _dev_f32(initflow, "initflow", self.device, (n, self.height >> sc, self.width >> sc, self.nch))
         ticket = C.c_long()
-        fn = lib().fotg_pipe_submit_u8 if u8 else lib().fotg_pipe_submit
         after = _stream(self.device) if after_current_stream else C.c_void_p(-1)      # FOTG_NO_STREAM
-        check(fn(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(outflow), after, ticket))
+        if no_recompute:
+            check(lib().fotg_pipe_submit_ex(self._h, n, _ptr(I0), _ptr(I1), int(u8), _ptr(initflow), _ptr(outflow), after, 1, ticket))     # FOTG_SUBMIT_NO_RECOMPUTE
+        else:
+            fn = lib().fotg_pipe_submit_u8 if u8 else lib().fotg_pipe_submit
+            check(fn(self._h, n, _ptr(I0), _ptr(I1), _ptr(initflow), _ptr(outflow), after, ticket))
         return ticket.value, outflow
 
     def wait(self, ticket, host=False):

@@ -1,5 +1,6 @@
 """Frame-pair sharding across ranks: pairs are independent, so a batch is cut into contiguous
-ranges, pair k -> rank k*world/n; no collective is on the data path.  RCCL/gloo is only used by callers for the
+ranges -- rank r gets n // world pairs, the first n % world ranks one more (shard_range below == fotg_node_shard of include/fotg.h);
+no collective is on the data path.  RCCL/gloo is only used by callers for the
 barrier and to reduce timings."""
 
 

@@ -144,13 +144,27 @@ int fotg_pipe_submit(fotg_pipe *pipe, int n, const float *I0, const float *I1, c
                      void *after_stream, long *ticket);
 int fotg_pipe_submit_u8(fotg_pipe *pipe, int n, const unsigned char *I0, const unsigned char *I1, const float *initflow,
                         float *outflow, void *after_stream, long *ticket);
-/* host_wait = 0: `stream` (NULL = default stream) waits for batch `ticket` on the device, the call returns at once;
+/* The same with the element type as an argument (u8 = 0: float32 frames, 1: 8-bit frames) and flags:
+ * FOTG_SUBMIT_NO_RECOMPUTE  the batch's frames or outflow may be gone before the host waits for the ticket (staging buffers that are
+ *                           recycled behind a device-side wait): a flagged stall is reported for it (FOTG_ERR_STALL), never recomputed. */
+#define FOTG_SUBMIT_NO_RECOMPUTE 1
+int fotg_pipe_submit_ex(fotg_pipe *pipe, int n, const void *I0, const void *I1, int u8, const float *initflow, float *outflow,
+                        void *after_stream, int flags, long *ticket);
+/* RECOMPUTE CONTRACT.  A host wait that finds a context's stall word set recomputes the unverified batches of that context from the
+ * pointers of their submits.  That is legal only for tickets whose buffers are still in place, so a ticket is recomputed only if it was
+ * submitted without FOTG_SUBMIT_NO_RECOMPUTE AND has not been handed out through fotg_pipe_wait(host_wait = 0) or
+ * fotg_pipe_ticket_event: after such a hand-over the waiting stream owns the result and the caller may free or reuse I0 / I1 /
+ * outflow as soon as its own wait is over.  Suspects that cannot be recomputed -- those, and tickets older than the 4 * depth
+ * submissions the pipe keeps arguments for -- are reported: FOTG_ERR_STALL from every host wait for that ticket and from
+ * fotg_pipe_sync (their flows are not valid; re-submit).
+ * host_wait = 0: `stream` (NULL = default stream) waits for batch `ticket` on the device, the call returns at once;
  * host_wait = 1: the calling thread waits; if the context of the batch has flagged a timed-out inter-workgroup wait, the batches of
  *   that context that have not been verified yet are recomputed (from the arguments of their submits -- which the caller keeps in
  *   place until a ticket has been waited for) and the call succeeds;
  * host_wait = 2: the calling thread waits; a flagged batch is reported (FOTG_ERR_STALL, on every wait for that ticket) instead of
  *   recomputed -- for callers whose frames are not in place any more.
- * Per-ticket state is kept for the last 4 * depth submissions.  May be called from another thread than the one that submits. */
+ * Per-ticket state is kept for the last 4 * depth submissions; a suspect older than that keeps FOTG_ERR_STALL (per-slot range).  May be
+ * called from another thread than the one that submits. */
 int fotg_pipe_wait(fotg_pipe *pipe, long ticket, void *stream, int host_wait);
 /* the calling thread waits for everything submitted so far */
 int fotg_pipe_sync(fotg_pipe *pipe);

@@ -8,6 +8,7 @@ exactly where an RCCL request's wait() orders the current stream behind the tran
 the contract: submits behind the current stream, device-side engine.wait() in front of a buffer's reuse, one output slice per
 submit."""
 import os
+import time
 import socket
 import sys
 
@@ -328,4 +329,20 @@ def test_node_heals_or_reports_a_stalled_wait_per_job(monkeypatch):
     assert torch.equal(o2, want)
     assert L.fotg_node_wait(node._h, t1) == 5 and L.fotg_node_wait(node._h, t0) == 0 and L.fotg_node_wait(node._h, t2) == 0
     assert L.fotg_node_last_hip_error(node._h) == 0
+    node.close()
+    # a job with MORE pieces per slot than the pipe keeps arguments for (4 * depth = 8): 24 pairs on two slots in pieces of one pair =
+    # 12 tickets per pipe.  A stall flagged when the host gets to them makes the four that have dropped out of the ring suspects that
+    # can be neither recomputed nor cleared: the job reports FOTG_ERR_STALL (it used to return FOTG_OK with a
+    # possibly invalid flow); the next job is clean
+    node = FlowNode(op, ip, devices=[0, 0], max_batch=1, depth=2)
+    R0 = [G0.repeat(3, 1, 1).contiguous() for _ in range(2)]; R1 = [G1.repeat(3, 1, 1).contiguous() for _ in range(2)]
+    torch.cuda.synchronize()
+    assert L.fotg_node_pipe(node._h, 1, pipe) == 0 and L.fotg_pipe_context(pipe, 0, ctx) == 0
+    t, o = node.submit(24, R0, R1)
+    time.sleep(0.5); torch.cuda.synchronize()                      # (issued and run; nothing verified yet)
+    assert L.fotg_ctx_counter(ctx, b"inject_stall") == 0
+    assert L.fotg_node_wait(node._h, t) == 5 and L.fotg_node_wait(node._h, t) == 5
+    t2, o2 = node.submit(24, R0, R1)
+    node.wait(t2)
+    assert torch.equal(torch.cat(o2), want.repeat(6, 1, 1, 1))
     node.close()

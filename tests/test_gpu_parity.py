@@ -1503,6 +1503,82 @@ def test_stalled_wait_heals_at_the_host_sync_points(monkeypatch):
     pipe.close()
 
 
+def test_recompute_only_where_the_buffers_are_still_in_place(monkeypatch):
+    """ADVICE round 5.  The self-healing host wait recomputes a suspect batch from the pointers of its submit -- legal only while the
+    caller still holds the buffers.  (1) a ticket handed to a stream (wait(ticket), host=False) or out as an event is never
+    recomputed: it is REPORTED (FOTG_ERR_STALL on every host wait for it) and its outflow is left alone; (2) the same for a submit
+    with no_recompute (FOTG_SUBMIT_NO_RECOMPUTE: what the node uses for pulled scatter pieces); (3) a suspect older than the
+    4 * depth submissions the pipe keeps arguments for is reported too (it used to be waited for as FOTG_OK), while the younger
+    suspects of the same slot are recomputed."""
+    import ctypes as C
+    F, OFClass, _, O = _mods()
+    from flowonthego_amd.pipeline import FlowPipeline
+    L = F.lib()
+    w, h = 1024, 1024
+    op = F.operating_point(2, w, 1)
+    ip = F.img_params(width=w, height=h, padding=8)
+    monkeypatch.setenv("FOTG_TEST_TAPS", "1")
+    a, b = synth_pair(h, w, seed=5)
+    A, B = dev(a), dev(b)
+    ref = OFClass(op, ip, max_batch=1).calc_batch(A[None], B[None])[0].cpu().numpy()
+    STALL = 5
+    pipe = FlowPipeline(op, ip, max_batch=1, depth=2)
+    outs = [pipe.new_outflow(1) for _ in range(4)]
+    torch.cuda.synchronize()
+    # (1) ticket 0 handed to the current stream, ticket 2 (same slot) not
+    ts = [pipe.submit(A[None], B[None], None, outs[k])[0] for k in range(4)]
+    pipe.wait(ts[0], host=False)
+    torch.cuda.synchronize()
+    L.fotg_ctx_counter(pipe.context(0), b"inject_stall")
+    for o in outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    assert L.fotg_pipe_wait(pipe._h, ts[2], None, 1) == 0                    # ticket 2: recomputed
+    assert np.array_equal(outs[2][0].cpu().numpy(), ref)
+    assert float(outs[0].abs().max()) == 0                                   # ticket 0: NOT written again (the caller may have recycled it)
+    assert L.fotg_pipe_wait(pipe._h, ts[0], None, 1) == STALL and L.fotg_pipe_wait(pipe._h, ts[0], None, 2) == STALL
+    assert L.fotg_pipe_wait(pipe._h, ts[1], None, 1) == 0 and L.fotg_pipe_wait(pipe._h, ts[3], None, 1) == 0
+    pipe.synchronize()                                                       # nothing new to report
+    # ... and through the event hand-out
+    t, o = pipe.submit(A[None], B[None], None, outs[0])
+    ev = C.c_void_p()
+    assert L.fotg_pipe_ticket_event(pipe._h, t, ev) == 0
+    torch.cuda.synchronize()
+    L.fotg_ctx_counter(pipe.context(t % 2), b"inject_stall")
+    o.zero_(); torch.cuda.synchronize()
+    with pytest.raises(F.FotgError):
+        pipe.synchronize()                                                   # reported by the sync as well
+    assert float(o.abs().max()) == 0 and L.fotg_pipe_wait(pipe._h, t, None, 1) == STALL
+    # (2) FOTG_SUBMIT_NO_RECOMPUTE
+    t, o = pipe.submit(A[None], B[None], None, outs[1], no_recompute=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(o[0].cpu().numpy(), ref)                           # (an ordinary submit otherwise)
+    L.fotg_ctx_counter(pipe.context(t % 2), b"inject_stall")
+    o.zero_(); torch.cuda.synchronize()
+    assert L.fotg_pipe_wait(pipe._h, t, None, 1) == STALL and float(o.abs().max()) == 0
+    assert L.fotg_pipe_submit_ex(pipe._h, 1, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), 0, None, C.c_void_p(o.data_ptr()), C.c_void_p(-1), 2, None) == 1   # unknown flag
+    pipe.close()
+    # (3) more than 4 * depth submissions outstanding when the flag is found
+    pipe = FlowPipeline(op, ip, max_batch=1, depth=2)
+    outs = [pipe.new_outflow(1) for _ in range(10)]
+    torch.cuda.synchronize()
+    ts = [pipe.submit(A[None], B[None], None, outs[k])[0] for k in range(10)]        # ring = 8 tickets: 0 and 1 have dropped out
+    torch.cuda.synchronize()
+    L.fotg_ctx_counter(pipe.context(0), b"inject_stall")
+    for o in outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    assert L.fotg_pipe_wait(pipe._h, ts[0], None, 1) == STALL                # nothing is known about it any more: a suspect for good
+    assert float(outs[0].abs().max()) == 0
+    for k in (2, 4, 6, 8):                                                   # the slot's younger suspects were recomputed by that wait
+        assert np.array_equal(outs[k][0].cpu().numpy(), ref), k
+        assert L.fotg_pipe_wait(pipe._h, ts[k], None, 1) == 0
+    for k in (1, 3, 5, 7, 9):                                                # the other slot: no flag, no suspects -- also the one older than the ring
+        assert L.fotg_pipe_wait(pipe._h, ts[k], None, 1) == 0 and float(outs[k].abs().max()) == 0
+    assert L.fotg_pipe_wait(pipe._h, ts[0], None, 1) == STALL
+    pipe.close()
+
+
 def test_cpp_shim_run_dense_example(tmp_path):
     """examples/run_dense_min.cpp: raw frames -> OFClass::calc through the C++ shim -> device-side upsample + crop -> .flo,
     compared bit for bit with the oracle's full-resolution flow (the shape of src/run_dense.cpp:120-305)"""

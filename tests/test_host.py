@@ -51,6 +51,14 @@ def test_status_strings_and_bad_arguments():
     assert L.fotg_padded_size(0, 10, 3, None, None, None, None) == 1
     with pytest.raises(F.FotgError):
         F._lib.check(1)
+    # fotg_create's argument checks run before it touches a device (the sor_mode range check had been dropped, so 3 or -1
+    # ran the lexicographic arithmetic without its buffers -- silently wrong flow on levels of more than 1024 rows)
+    h = C.c_void_p()
+    for field, bad in (("sor_mode", 3), ("sor_mode", -1), ("u8_color", 3), ("costfct", 3), ("noc", 2), ("tv_innerit", -1)):
+        c = F._lib.FotgParams()
+        assert L.fotg_op_point(2, 640, 1, c) == 0
+        setattr(c, field, bad)
+        assert L.fotg_create(C.byref(c), 640, 480, 0, 1, C.byref(h)) == 1, (field, bad)     # FOTG_ERR_ARG, whatever the box has for GPUs
 
 
 def test_product_package_does_not_import_oracle():
