@@ -3,7 +3,8 @@
 // the reference holds them after cv::imread + convertTo(CV_32F) (src/run_dense.cpp:137-145).
 //
 //   hipcc -O2 -Iinclude examples/run_dense_min.cpp -Lflowonthego_amd -lfotg -Wl,-rpath,$PWD/flowonthego_amd -o examples/run_dense_min
-//   examples/run_dense_min frame0.raw frame1.raw W H C out.flo [op-point 1..4] [depth]
+//   examples/run_dense_min frame0.raw frame1.raw W H C out.flo [op-point 1..4] [depth] [innerit=N]
+// innerit=N: kroeger's tv_innerit command-line parameter (kroeger/run_dense.cpp:288; inner iterations = N * (level + 1)), default 1
 // With the 8th argument "depth" it is the reference's run_DE_* binary instead (kroeger SELECTMODE=2): a rectified stereo pair in,
 // one displacement channel out, written as a PFM file (SavePFMFile, kroeger/run_dense.cpp:60-81).
 #include <hip/hip_runtime.h>
@@ -25,9 +26,14 @@ static std::vector<float> read_raw(const char *path, size_t n)
 
 int main(int argc, char **argv)
 {
-  if (argc < 7) { fprintf(stderr, "usage: %s frame0.raw frame1.raw W H C out.flo|out.pfm [op-point] [depth]\n", argv[0]); return 2; }
+  if (argc < 7) { fprintf(stderr, "usage: %s frame0.raw frame1.raw W H C out.flo|out.pfm [op-point] [depth] [innerit=N]\n", argv[0]); return 2; }
   const int W = atoi(argv[3]), H = atoi(argv[4]), C = atoi(argv[5]), oppt = argc > 7 ? atoi(argv[7]) : 2;
-  const bool depth = argc > 8 && !strcmp(argv[8], "depth");
+  bool depth = false;
+  int innerit = 1;
+  for (int k = 8; k < argc; ++k) {
+    if (!strcmp(argv[k], "depth")) depth = true;
+    else if (!strncmp(argv[k], "innerit=", 8)) innerit = atoi(argv[k] + 8);
+  }
   const int nch = depth ? 1 : 2;
   const size_t n = (size_t)W * H * C;
   const std::vector<float> f0 = read_raw(argv[1], n), f1 = read_raw(argv[2], n);
@@ -42,6 +48,7 @@ int main(int argc, char **argv)
   op.use_var_ref = p.usetvref != 0; op.var_ref_iter = p.tv_solverit; op.var_ref_alpha = p.tv_alpha; op.var_ref_gamma = p.tv_gamma;
   op.var_ref_delta = p.tv_delta; op.var_ref_sor_weight = p.tv_sor; op.verbosity = 0; op.channels = C;
   op.depth_mode = depth;
+  op.var_ref_inner_iter = innerit;                                                  // kroeger/run_dense.cpp:288 -> refine_variational.cpp:36
   OFC::img_params iparams;
   iparams.width = W; iparams.height = H; iparams.padding = op.patch_size;       // unpadded: the library pads inside its pyramid kernel
 

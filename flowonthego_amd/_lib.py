@@ -94,10 +94,18 @@ class FotgError(RuntimeError):
 def lib():
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATH
+        exp = os.environ.get("FOTG_EXPERIMENTAL_LIB")
+        if exp:
+            # A/B timing of experimental builds (tools/exp_*.sh): the variant is NAMED, the product library is never overwritten.  Loud,
+            # because such a build may be one that is documented as producing wrong results.
+            import sys
+            print("flowonthego_amd: FOTG_EXPERIMENTAL_LIB=%s replaces %s in this process" % (exp, LIB_PATH), file=sys.stderr)
+            path = exp
+        if not os.path.exists(path):
             raise FotgError("libfotg.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
-                            "or `make -C flowonthego_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+                            "or `make -C flowonthego_amd/csrc`.  There is no CPU fallback." % path)
+        L = C.CDLL(path)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
             fn.restype = res

@@ -48,6 +48,7 @@ class opt_params:
     use_fbcon: bool = False          # kroeger/oflow.h:44 usefbcon: forward-backward merge in the densification
     depth_mode: bool = False         # kroeger SELECTMODE=2 (run_DE_*): stereo depth, one displacement channel
     u8_color: int = 0                # channels == 1 only: 8-bit frames arrive with 3 channels (1: B,G,R as cv::imread delivers, 2: R,G,B), gray on load (kroeger/run_dense.cpp:199-209)
+    var_ref_inner_iter: int = 1      # kroeger tv_innerit (oflow.h:50, run_dense.cpp:288): inner iterations = var_ref_inner_iter * (level + 1); src/ hard-codes 1
     fast_math: bool = False          # tolerance mode of the patch loop and the refinement's arithmetic (fotg_params::fast_math); False = parity mode
     min_iter: int = -1               # kroeger optparam.min_iter (oflow.h:38); < 0: = grad_descent_iter, as src/ and the operating points have it
     # derived (src/oflow.cpp:45-48)
@@ -75,7 +76,7 @@ class opt_params:
         p.patove, p.patnorm, p.noc = self.patch_stride, int(self.use_mean_normalization), self.channels
         p.usetvref = int(self.use_var_ref)
         p.tv_alpha, p.tv_gamma, p.tv_delta = self.var_ref_alpha, self.var_ref_gamma, self.var_ref_delta
-        p.tv_innerit, p.tv_solverit, p.tv_sor = 1, self.var_ref_iter, self.var_ref_sor_weight
+        p.tv_innerit, p.tv_solverit, p.tv_sor = int(self.var_ref_inner_iter), self.var_ref_iter, self.var_ref_sor_weight
         p.sor_mode = self.sor_mode
         p.costfct, p.normoutlier, p.usefbcon = self.cost_func, self.norm_outlier, int(self.use_fbcon)
         p.depth = int(self.depth_mode)

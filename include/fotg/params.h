@@ -53,6 +53,8 @@ typedef struct {
   int min_iter = -1; // kroeger optparam.min_iter (oflow.h:38); < 0: = grad_descent_iter (src/ and the operating points)
   int u8_color = 0;  // channels = 1 only: the 8-bit entry points take 3-channel frames (1: B,G,R as cv::imread delivers, 2: R,G,B) and
                      // convert to gray on load like cv::imread(IMREAD_GRAYSCALE) (kroeger/run_dense.cpp:199-209); fotg_params::u8_color
+  int var_ref_inner_iter = 1; // kroeger tv_innerit (oflow.h:50, run_dense.cpp:288): inner fixed-point iterations = var_ref_inner_iter * (level + 1)
+                     // (refine_variational.cpp:36); src/ hard-codes 1 (src/refine_variational.cpp:41)
   bool fast_math = false; // tolerance mode of the patch loop and the refinement's arithmetic (fotg_params::fast_math): flows within 1e-3 px (mean) of the parity mode
 } opt_params;
 
@@ -67,7 +69,7 @@ inline fotg_params to_fotg(const opt_params &op)
   p.res_thresh = op.res_thresh;
   p.patove = op.patch_stride; p.patnorm = op.use_mean_normalization; p.noc = op.channels;
   p.usetvref = op.use_var_ref; p.tv_alpha = op.var_ref_alpha; p.tv_gamma = op.var_ref_gamma; p.tv_delta = op.var_ref_delta;
-  p.tv_innerit = 1; p.tv_solverit = op.var_ref_iter; p.tv_sor = op.var_ref_sor_weight; p.sor_mode = op.sor_mode;
+  p.tv_innerit = op.var_ref_inner_iter; p.tv_solverit = op.var_ref_iter; p.tv_sor = op.var_ref_sor_weight; p.sor_mode = op.sor_mode;
   p.costfct = op.cost_func; p.normoutlier = op.norm_outlier; p.usefbcon = op.use_fbcon; p.depth = op.depth_mode;
   p.u8_color = op.u8_color;
   p.fast_math = op.fast_math;

@@ -202,7 +202,8 @@ def test_depth_random_parameter_sweep():
         op.var_ref_iter = int(rng.integers(1, 5))
         op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta = float(rng.choice([10.0, 3.0, 25.0])), float(rng.choice([10.0, 0.5, 20.0])), float(rng.choice([5.0, 0.0, 12.0]))
         op.var_ref_sor_weight = float(rng.choice([1.6, 1.0, 1.9]))
-        desc = dict(w=w, h=h, noc=noc, ps=op.patch_size, ov=op.patch_stride, sc=(op.coarsest_scale, op.finest_scale), it=(op.min_iter, op.grad_descent_iter),
+        op.var_ref_inner_iter = int(rng.choice([1, 1, 2, 3]))                   # kroeger tv_innerit (run_dense.cpp:288)
+        desc = dict(inner=op.var_ref_inner_iter, w=w, h=h, noc=noc, ps=op.patch_size, ov=op.patch_stride, sc=(op.coarsest_scale, op.finest_scale), it=(op.min_iter, op.grad_descent_iter),
                     thr=(op.dp_thresh, op.dr_thresh, op.res_thresh), norm=op.use_mean_normalization, cost=op.cost_func,
                     ref=(op.use_var_ref, op.var_ref_iter, op.var_ref_alpha, op.var_ref_gamma, op.var_ref_delta, op.var_ref_sor_weight))
         try:

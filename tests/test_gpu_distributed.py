@@ -282,9 +282,14 @@ def test_bench_gpus_2_end_to_end_on_one_gpu():
     assert len(lines) == 1                                          # rank 0 prints, once
     d = lines[0]
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["shared_gpu_test"] is True and "SHARED-GPU TEST RUN" in d["metric"]
-    assert len(d["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in d["ms_per_step_per_rank"])
-    assert d["config"]["global_batch"] == 32 and d["value"] > 0 and d["pipeline_matches_single_context"]
-    assert [p["rank"] for p in d["rank_placement"]] == [0, 1]
+    assert len(r.stdout.strip().splitlines()[-1]) < 6000 and json.loads(r.stdout.strip().splitlines()[-1]) == d      # the short line is the LAST stdout line
+    assert set(d["ms_per_step_per_rank"]) == {"min", "max"} and 0 < d["ms_per_step_per_rank"]["min"] <= d["ms_per_step_per_rank"]["max"]
+    assert d["config"]["global_batch"] == 32 and d["value"] > 0 and d["gpus_distinct"] == 1
+    # the detail (per-rank times, placement, the pipe-vs-single-context check) is in the side file and on stderr
+    det = json.loads([l for l in r.stderr.splitlines() if l.startswith("bench.py detail: ")][-1][len("bench.py detail: "):])
+    assert json.load(open(os.path.join(ROOT, d["detail"]))) == det
+    assert len(det["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in det["ms_per_step_per_rank"]) and det["pipeline_matches_single_context"]
+    assert [p["rank"] for p in det["rank_placement"]] == [0, 1] and det["value"] == pytest.approx(d["value"], rel=1e-4)
 
 
 def test_node_heals_or_reports_a_stalled_wait_per_job(monkeypatch):
