@@ -72,6 +72,7 @@ struct FotgTune {
   int vr_fused_nt;  // FOTG_VR_FUSED_NT: threads per workgroup of the fused per-level kernel on gray levels of 1025..2048 pixels (512 / 1024)
   int lk_shw;       // FOTG_LK_SHW: shared LDS window of a wave's four patches: -1 automatic (RGB patches of 8 x 8 and more), 0 off, 1 on; 2 / 3 with FOTG_TEST_TAPS: on + some / all rows on the global-memory path
   int lk_lpp;       // FOTG_LK_LPP: lanes per patch of the LK kernel: 0 automatic, 8, 16
+  int lk_banded;    // FOTG_LK_BANDED: 0 = plain workgroup order for launches of 1..7 pairs (1: XCD-banded, xcd_banded_x)
   int lk_fast_r;    // FOTG_LK_FAST_R: fast_math, gray 8 x 8 / 12 x 12 patches: radius of the staged window (2), 0 = the whole reachable region
   int lk_lpp_min_waves;   // FOTG_LK_LPP_MIN_WAVES: automatic: eight lanes per patch from this many waves per launch on
   int test_taps;    // FOTG_TEST_TAPS: 1 = fotg_ctx_counter(ctx, "inject_stall") is live (tests of the FOTG_ERR_STALL reporting)
@@ -262,6 +263,7 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->tune.test_taps = env_int("FOTG_TEST_TAPS", 0);
   c->tune.lk_shw = env_int("FOTG_LK_SHW", -1);
   c->tune.lk_lpp = env_int("FOTG_LK_LPP", 0);
+  c->tune.lk_banded = env_int("FOTG_LK_BANDED", 1);
   c->tune.lk_lpp_min_waves = env_int("FOTG_LK_LPP_MIN_WAVES", 2048);
   c->tune.lk_fast_r = env_int("FOTG_LK_FAST_R", 2);
   if (hipHostMalloc((void **)&c->stall_host, 64, hipHostMallocMapped) != hipSuccess ||
@@ -660,6 +662,11 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
                     (c->tune.lk_lpp == 8 || (c->tune.lk_lpp == 0 && c->ps == 8 && waves8 >= c->tune.lk_lpp_min_waves));
   const int ppw = lpp8 ? 8 : 4;
   dim3 block(64), grid((g.nop + ppw - 1) / ppw, n);
+  // pair counts that are not a multiple of 8 (xcd_local_wg() keeps the plain order then): XCD-banded placement for launches that span the
+  // chip (FOTG_LK_BANDED=0: plain order; tests)
+  const bool banded = (n & 7) != 0 && c->tune.lk_banded;
+  a.nwg = 0;
+  if (banded && grid.x >= 64) { a.nwg = (int)grid.x; grid.x = (grid.x + 7) & ~7u; }
   // the operating points' L2 cost: specialised kernels, with one shared LDS area per wave where private windows limit occupancy
   // (measured: RGB patches -- two to three waves per SIMD with private windows -- gain 9-19 % per level; gray ones are bound by
   // the issue rate of their instruction stream at any occupancy and lose the time of the packing plan: docs/EXPERIMENTS.md)
@@ -672,6 +679,8 @@ int fotg_grid_optimize(fotg_ctx *c, int l, int n, void *stream)
     // equal at every launch size (docs/EXPERIMENTS.md, round 5).
     const bool small = c->noc == 1 && (c->ps == 8 || c->ps == 12) && c->tune.lk_fast_r > 0;
     dim3 gridf((g.nop + 3) / 4, n);
+    a.nwg = 0;
+    if (banded && gridf.x >= 64) { a.nwg = (int)gridf.x; gridf.x = (gridf.x + 7) & ~7u; }
 #define LKF(PS_, NOC_, R_) lk_fast_kernel<PS_, NOC_, 16, R_><<<gridf, block, 0, s>>>(a)
     switch (c->ps * 10 + c->noc) {
       case 41: LKF(4, 1, 0); break;   case 43: LKF(4, 3, 0); break;
@@ -1053,12 +1062,14 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
     // (tune.vr_setup = 0: memset + the three plane-at-a-time launches; tests)
     // (the launch also builds the system of the first inner iteration unless tune.vr_first_data = 0)
     merged_first = c->tune.vr_first_data && inner > 0;
+    dim3 gs_(((g.w + 31) / 32) * ((g.h + 7) / 8), n);
+    if ((n & 7) != 0 && gs_.x >= 256 && c->tune.lk_banded) { az.nwg = (int)gs_.x; gs_.x = (gs_.x + 7) & ~7u; }     // XCD-banded tiles (FOTG_LK_BANDED=0: plain order)
     if (c->p.fast_math)
-      vr_setup_kernel<NOC, 2, true><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
-                                                                                                  merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
+      vr_setup_kernel<NOC, 2, true><<<gs_, 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
+                                                         merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
     else
-      vr_setup_kernel<NOC><<<dim3(((g.w + 31) / 32) * ((g.h + 7) / 8), n), 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
-                                                                                         merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
+      vr_setup_kernel<NOC><<<gs_, 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
+                                                merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
     LAUNCHCHK();
   } else {
     HIPCHK(hipMemsetAsync(a.D, 0, (size_t)n * a.d_pair_stride * sizeof(float2), s));      // image_erase(du), image_erase(dv) (:185-186)

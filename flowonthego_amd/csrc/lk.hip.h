@@ -39,6 +39,7 @@ struct LkArgs {
   LevelGeom g;
   int camlr;                          // depth mode: 0 displacement <= 0 (forward grid), 1 displacement >= 0 (oflow.cpp:153,157)
   int max_iter, min_iter, patnorm, costfct;
+  int nwg;                            // > 0: XCD-banded placement of the workgroups (xcd_banded_x, common.h): launches whose pair count is not a multiple of 8
   int shw_test;                       // test tap of the shared-window kernels (FOTG_LK_SHW=2 / 3 with FOTG_TEST_TAPS=1): 1 = rows 1, 3 read global memory, 2 = all rows
   float dp_thresh_sq, dr_thresh, res_thresh, outlier, outlier_sq, huber_bsq, huber_2bsq;
 };
@@ -120,7 +121,11 @@ __global__ __launch_bounds__(64, lk_min_waves(PS * PS * NOC, SHW, LPP)) void lk_
   static_assert(NPIX % 16 == 0, "a patch fills the 16 lanes of its row");
   __shared__ float win_all[SHW ? SWW * RB * NOC : PPW * WIN * WIN * NOC];
   const int lane = threadIdx.x & 63, row = lane / LPP, j = lane % LPP;
-  const WgId wg = xcd_local_wg();                    // all patches of a pair on the XCD of its refinement workgroup
+  WgId wg = xcd_local_wg();                          // all patches of a pair on the XCD of its refinement workgroup
+  // a launch for 1..7 pairs (a single 4K pair): consecutive waves hold neighbouring patches, whose templates and windows overlap (a pixel is
+  // in (ps / steps)^2 patches); dealt round robin, every XCD's L2 fetched the whole level for itself (4K level 2: 110 MB per launch for 45
+  // MB of inputs + outputs).  Every XCD gets a contiguous run of patch columns instead.
+  if (a.nwg > 0) { wg.x = xcd_banded_x(a.nwg); if (wg.x < 0) return; }
   const int ipw = wg.x * PPW;                        // first patch of this wave
   const int pair = wg.y;
   const int tw = a.g.tw;

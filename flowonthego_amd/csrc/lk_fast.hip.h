@@ -100,7 +100,8 @@ __global__ __launch_bounds__(64, lkf_min_waves(PS, NOC, LPP, R)) void lk_fast_ke
   __shared__ float win_all[PPW * WIN * WIN * NOC];
   const int lane = threadIdx.x & 63, row = lane / LPP, j = lane % LPP;
   const int by = (j / LC) * BH, bx = (j % LC) * BW;  // the lane's block inside the patch
-  const WgId wg = xcd_local_wg();
+  WgId wg = xcd_local_wg();
+  if (a.nwg > 0) { wg.x = xcd_banded_x(a.nwg); if (wg.x < 0) return; }      // (see lk_kernel)
   const int ipw = wg.x * PPW;
   const int pair = wg.y;
   const int tw = a.g.tw;

@@ -43,6 +43,7 @@ struct VrArgs {
   int S, SC, RP, RPD, K, nlanes, nsweeps, nbands, band_rows, band_mode, taps;
   int *zsync;            // sync words of the tile pipeline the NEXT launch (the level's sor_coupled call) expects zeroed: the data-term
   int zsync_n;           // launch clears them on its way (a memset launch per call otherwise: 13 per 4K pair)
+  int nwg;               // vr_setup_kernel: > 0 = XCD-banded placement of the tiles (xcd_banded_x; launches of 1..7 pairs that span the chip)
   int redblack;          // FOTG_SOR_REDBLACK: the fused per-level kernel relaxes with red-black half-sweeps instead of the wavefront solver
   int point;             // FOTG_SOR_POINT: cells hold (A11 + sum psi, A12, b1, b2 | A22 + sum psi, psi_r, psi_b, psi_t), no block inverse
   __host__ __device__ int pix(int i, int j) const { return j * st + i; }
@@ -210,13 +211,17 @@ __global__ __launch_bounds__(256) void vr_setup_kernel(VrArgs a, const float *__
   __shared__ float Xa[NOC][XH * XW], Xz[NOC][XH * XW], Yx[NOC][YH * YW], Yy[NOC][YH * YW];
   if (first_data && a.zsync_n > 0)
     for (long k = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; k < a.zsync_n; k += (long)gridDim.x * gridDim.y * 256) a.zsync[k] = 0;
-  const WgId wg = xcd_local_wg();
+  WgId wg = xcd_local_wg();
+  int ntiles = (int)gridDim.x;
+  // a single pair (4K): neighbouring tiles share their halos (the warp is evaluated on tile + 4, the derivatives on tile + 2); dealt
+  // round robin every XCD's L2 fetched the halo rows of all its neighbours' tiles -- bands of tile rows per XCD instead
+  if (a.nwg > 0) { wg.x = xcd_banded_x(a.nwg); ntiles = a.nwg; if (wg.x < 0) return; }
   const int pair = wg.y, w = a.w, h = a.h;
   const int tiles_x = (w + TW_ - 1) / TW_;
   if (zero_d == 1) {
     // image_erase(du), image_erase(dv) (refine_variational.cpp:185-186): the pair's tiles share the zeroing of its skewed D
     float2 *D = a.Dp(pair);
-    for (long k = (long)wg.x * 256 + threadIdx.x; k < a.d_pair_stride; k += (long)gridDim.x * 256) D[k] = make_float2(0.f, 0.f);
+    for (long k = (long)wg.x * 256 + threadIdx.x; k < a.d_pair_stride; k += (long)ntiles * 256) D[k] = make_float2(0.f, 0.f);
   }
   const int tx0 = (wg.x % tiles_x) * TW_, ty0 = (wg.x / tiles_x) * TH_;
   // stage A: warp + mask + average / difference at the clamped coordinate of every tile+4 position
