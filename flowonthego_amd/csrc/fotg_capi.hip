@@ -62,14 +62,10 @@ struct GridState {
 struct FotgTune {
   int vr_path;      // FOTG_VR_PATH: 0 automatic, 1 single-wave global-memory solver only, 2 no fused per-level kernel
   int vr_stream;    // FOTG_VR_STREAM: 0 = resident-D kernel instead of the streaming solver
-  int vr_clds;      // FOTG_VR_CLDS: 0 = fused levels keep the system in global memory
   int vr_levelpipe; // FOTG_VR_LEVELPIPE: 1 (default) = tall levels run all inner iterations as one pipeline launch (varref_levelpipe.hip.h); 0 = one tile-solver launch per sor_coupled call; + 16 x diagnosis bits
   int lp_max_pairs; // pairs per launch up to which the level pipeline is used (contexts of a pipe: 4 / depth -- with more pairs resident the launch-per-stage path has the higher THROUGHPUT, the level pipeline the lower latency: measured)
-  int vr_setup;     // FOTG_VR_SETUP: 0 = plane-at-a-time set-up launches
   int vr_first_data; // FOTG_VR_FIRST_DATA: 0 = the first inner iteration's data term in a launch of its own (not in the set-up launch)
   int pyr_split;    // FOTG_PYR_SPLIT: launches the base pyramid kernel of a batch is cut into (1 = one launch)
-  int pyr_persist;  // FOTG_PYR_PERSIST: 0 = one workgroup per tile group; k > 0 = persistent launch of about k workgroups per CU
-  int vr_fused_nt;  // FOTG_VR_FUSED_NT: threads per workgroup of the fused per-level kernel on gray levels of 1025..2048 pixels (512 / 1024)
   int lk_shw;       // FOTG_LK_SHW: shared LDS window of a wave's four patches: -1 automatic (RGB patches of 8 x 8 and more), 0 off, 1 on; 2 / 3 with FOTG_TEST_TAPS: on + some / all rows on the global-memory path
   int lk_lpp;       // FOTG_LK_LPP: lanes per patch of the LK kernel: 0 automatic, 8, 16
   int lk_banded;    // FOTG_LK_BANDED: 0 = plain workgroup order for launches of 1..7 pairs (1: XCD-banded, xcd_banded_x)
@@ -252,14 +248,10 @@ int fotg_create(const fotg_params *p, int w_org, int h_org, int device, int max_
   c->noc = p->noc; c->ps = p->ps; c->nch = p->depth ? 1 : 2;
   c->tune.vr_path = env_int("FOTG_VR_PATH", 0);
   c->tune.vr_stream = env_int("FOTG_VR_STREAM", 1);
-  c->tune.vr_clds = env_int("FOTG_VR_CLDS", 1);
-  c->tune.vr_setup = env_int("FOTG_VR_SETUP", 1);
   c->tune.vr_levelpipe = env_int("FOTG_VR_LEVELPIPE", 1);
   c->tune.lp_max_pairs = env_int("FOTG_VR_LEVELPIPE_MAX_PAIRS", 1 << 20);
   c->tune.vr_first_data = env_int("FOTG_VR_FIRST_DATA", 1);
-  c->tune.vr_fused_nt = env_int("FOTG_VR_FUSED_NT", 1024);
   c->tune.pyr_split = env_int("FOTG_PYR_SPLIT", 1);
-  c->tune.pyr_persist = env_int("FOTG_PYR_PERSIST", 0);
   c->tune.test_taps = env_int("FOTG_TEST_TAPS", 0);
   c->tune.lk_shw = env_int("FOTG_LK_SHW", -1);
   c->tune.lk_lpp = env_int("FOTG_LK_LPP", 0);
@@ -429,14 +421,8 @@ static int pyramid_impl(fotg_ctx *c, int n, const T *I0, const T *I1, hipStream_
   const int fast = (c->padw == 0) && ((c->w_org * SRCC) % 4 == 0) && (((uintptr_t)A & amask) == 0) && (!B || ((uintptr_t)B & amask) == 0) && ((fstride % 4) == 0);
   const int groups = (tiles + 3) / 4;
   dim3 grid(groups, nimg), block(256);
-  // FOTG_PYR_PERSIST = k > 0 (pipes: FOTG_PIPE_PYR_PERSIST): a persistent launch of about k workgroups per CU (pyr_base_kernel)
-  if (c->tune.pyr_persist > 0 && B) {
-    const int total = c->tune.pyr_persist >= 100 ? c->tune.pyr_persist : 256 * c->tune.pyr_persist;       // (>= 100: the total number of workgroups)
-    const int per_img = (total + nimg - 1) / nimg;
-    if (per_img >= 1 && per_img < groups) grid.x = per_img;
-  }
-#define BASE(LV) do { if (fast) pyr_base_kernel<T, NOC, LV, true, SRCC><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, coef0, coef2, groups); \
-    else pyr_base_kernel<T, NOC, LV, false, SRCC><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, coef0, coef2, groups); } while (0)
+#define BASE(LV) do { if (fast) pyr_base_kernel<T, NOC, LV, true, SRCC><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, coef0, coef2); \
+    else pyr_base_kernel<T, NOC, LV, false, SRCC><<<grid, block, 0, s>>>(A, B, n, fstride, c->w_org, c->h_org, c->padw / 2, c->padh / 2, c->Wp, c->Hp, dA, dB, c->lev_stride[lv], g0.tw, ps, coef0, coef2); } while (0)
   if (stages & 1) {
     // FOTG_PYR_SPLIT > 1: the batch's images in that many launches, one after the other.  The launch is the path's only HBM-bound
     // kernel and fills every wave slot of the chip for its whole duration; with several batches in flight the kernels of the
@@ -824,6 +810,8 @@ static bool ensure_dyn_lds(const void *fn, int lds, int (&set)[32])
   return true;
 }
 
+static std::atomic<long> g_fused_cglobal_launches{0};   // fotg_debug_counter("fused_cglobal"): fused per-level launches with the system in global memory
+static std::atomic<long> g_pipe_launches{0};            // fotg_debug_counter("sor_pipe"): vr_sor_pipe_kernel launches
 static bool launch_sor_pipe(int n, float omega, hipStream_t s, const VrArgs &b)
 {
   constexpr int P = 8, U = 32;
@@ -831,6 +819,7 @@ static bool launch_sor_pipe(int n, float omega, hipStream_t s, const VrArgs &b)
   static int lds_set[32] = {0};
   if (!ensure_dyn_lds(reinterpret_cast<const void *>(&vr_sor_pipe_kernel<P, U>), lds, lds_set)) return false;
   vr_sor_pipe_kernel<P, U><<<n, 1024, lds, s>>>(b, omega);          // all 16 waves copy D in and out
+  ++g_pipe_launches;
   return true;
 }
 
@@ -931,18 +920,21 @@ static bool dispatch_inner_fused(const fotg_ctx *c, const VrArgs &a, int n, int 
 #endif
   set_bands(b, sweeps);
   if (b.band_mode != 3 || b.nbands > 1) return false;           // the fused kernel's barrier-stepped waves assume a single band (<= 64 rows)
-  // system cells in LDS as well when they fit (tune.vr_clds = 0: keep them in global memory; tests)
-  if (c->tune.vr_clds && fused_lds_bytes(a, true) <= 160 * 1024) {
+  // system cells in LDS as well when they fit
+  if (fused_lds_bytes(a, true) <= 160 * 1024) {
     // gray levels of <= 4 pixels per thread also keep their per-pixel inputs in registers over the loop
     if constexpr (NOC == 1) {
       // (levels of more than 1024 pixels: 1024 threads, two pixels each -- 4 waves per SIMD hide the latencies of the per-pixel phases)
-      if (c->tune.vr_fused_nt == 1024 && a.w * a.h > 1024 && a.w * a.h <= 2048 && FOTG_FUSED(1, true, true, 1024)) return true;
+      if (a.w * a.h > 1024 && a.w * a.h <= 2048 && FOTG_FUSED(1, true, true, 1024)) return true;
       if (a.w * a.h <= 4 * 512 && FOTG_FUSED(1, true, true, 512)) return true;
     }
     if (FOTG_FUSED(NOC, true, false, 512)) return true;
   }
-
-  return FOTG_FUSED(NOC, false, false, 512);
+  // wide, short levels whose skewed system (w + h) x h x 32 B does not fit beside (du,dv) and the smoothness plane -- e.g. 100 x 30: 133 KB --
+  // keep it in global memory (fotg_debug_counter("fused_cglobal") counts these launches)
+  if (!FOTG_FUSED(NOC, false, false, 512)) return false;
+  ++g_fused_cglobal_launches;
+  return true;
 #undef FOTG_FUSED
 }
 
@@ -1047,7 +1039,7 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
   // levels that go through the tile pipeline: the launch in front of every sor_coupled call (data term; set-up with the first data
   // term) clears the pipeline's sync words
   VrArgs az = a;
-  const bool tiles = c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->vrX[l] && c->tileSync && c->p.tv_solverit > 0 && c->tune.vr_setup;
+  const bool tiles = c->p.sor_mode == FOTG_SOR_LEXICOGRAPHIC && c->vrX[l] && c->tileSync && c->p.tv_solverit > 0;
   if (tiles) { az.zsync = c->tileSync; az.zsync_n = (int)tile_sync_words(n, c->tile_nbs); }
   // FOTG_VR_LEVELPIPE=1: the level's whole fixed-point loop as ONE pipeline launch behind the set-up launch (varref_levelpipe.hip.h).
   // At least two sweeps per call (what keeps a band's last sweep behind the data term of its neighbours), at most four (X buffers).
@@ -1057,28 +1049,19 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
                          lp_tile_words(n, c->tile_nbs) + lp_data_words(n, ntr) <= c->sync_total;
   if (levelpipe) { az.zsync_n = (int)(lp_tile_words(n, c->tile_nbs) + lp_data_words(n, ntr)); }
   bool merged_first = false;
-  if (c->tune.vr_setup) {
-    // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
-    // (tune.vr_setup = 0: memset + the three plane-at-a-time launches; tests)
-    // (the launch also builds the system of the first inner iteration unless tune.vr_first_data = 0)
-    merged_first = c->tune.vr_first_data && inner > 0;
-    dim3 gs_(((g.w + 31) / 32) * ((g.h + 7) / 8), n);
-    if ((n & 7) != 0 && gs_.x >= 256 && c->tune.lk_banded) { az.nwg = (int)gs_.x; gs_.x = (gs_.x + 7) & ~7u; }     // XCD-banded tiles (FOTG_LK_BANDED=0: plain order)
-    if (c->p.fast_math)
-      vr_setup_kernel<NOC, 2, true><<<gs_, 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
-                                                         merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
-    else
-      vr_setup_kernel<NOC><<<gs_, 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
-                                                merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
-    LAUNCHCHK();
-  } else {
-    HIPCHK(hipMemsetAsync(a.D, 0, (size_t)n * a.d_pair_stride * sizeof(float2), s));      // image_erase(du), image_erase(dv) (:185-186)
-    vr_prep_kernel<NOC><<<grid, block, 0, s>>>(a, I0, I1, img_stride, g.tw, c->ps, flow, fs);
-    LAUNCHCHK();
-    vr_deriv1_kernel<NOC><<<grid, block, 0, s>>>(a);
-    LAUNCHCHK();
-    vr_deriv2_kernel<NOC><<<grid, block, 0, s>>>(a);
-    LAUNCHCHK();
+  {
+  // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
+  // (the launch also builds the system of the first inner iteration unless tune.vr_first_data = 0)
+  merged_first = c->tune.vr_first_data && inner > 0;
+  dim3 gs_(((g.w + 31) / 32) * ((g.h + 7) / 8), n);
+  if ((n & 7) != 0 && gs_.x >= 256 && c->tune.lk_banded) { az.nwg = (int)gs_.x; gs_.x = (gs_.x + 7) & ~7u; }     // XCD-banded tiles (FOTG_LK_BANDED=0: plain order)
+  if (c->p.fast_math)
+    vr_setup_kernel<NOC, 2, true><<<gs_, 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
+                                                       merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
+  else
+    vr_setup_kernel<NOC><<<gs_, 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
+                                              merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
+  LAUNCHCHK();
   }
   if (levelpipe) {
     TileArgs tg;
@@ -1563,7 +1546,6 @@ int fotg_pipe_create(const fotg_params *p, int w_org, int h_org, int device, int
     // several batches in flight: the base pyramid launch of a batch in up to 16 parts (pyramid_impl; measured 170 -> 181 k pairs/s
     // at batch 64 with four in flight, at the price of ~5 % on a batch that runs alone -- which is why only pipes do it)
     if (depth > 1) q->ctx[k]->tune.pyr_split = env_int("FOTG_PIPE_PYR_SPLIT", 16);
-    if (depth > 1) q->ctx[k]->tune.pyr_persist = env_int("FOTG_PIPE_PYR_PERSIST", 0);
     // several batches in flight: the level pipeline (latency) only while few pairs are resident, the launch-per-stage path (throughput) beyond
     if (depth > 1) q->ctx[k]->tune.lp_max_pairs = env_int("FOTG_PIPE_LEVELPIPE_MAX_PAIRS", 4 / depth > 1 ? 4 / depth : 1);
   }
@@ -1770,6 +1752,8 @@ int fotg_calc_sequence_u8(fotg_ctx *c, int n_frames, const unsigned char *frames
 long fotg_debug_counter(const char *name)
 {
   if (name && !strcmp(name, "sor_stream")) return g_stream_launches;
+  if (name && !strcmp(name, "sor_pipe")) return g_pipe_launches;
+  if (name && !strcmp(name, "fused_cglobal")) return g_fused_cglobal_launches;
   if (name && !strcmp(name, "sor_tiles")) return g_tile_launches;
   if (name && !strcmp(name, "sor_tall")) return g_tall_launches;
   if (name && !strcmp(name, "level_pipe")) return g_levelpipe_launches;

@@ -293,28 +293,16 @@ __device__ __forceinline__ void pyr_base_tiles(
   }
 }
 
-// The kernel: grid (tile groups, images).  A launch with fewer tile groups than the level has (gridDim.x < groups) is PERSISTENT:
-// every workgroup walks the groups gridDim.x apart.  Several batches in flight use that to cap the pyramid's share of the chip's
-// wave slots: the plain launch fills every slot with 256-thread workgroups for its whole duration and hands freed slots to its
-// own pending workgroups one at a time, so a 1024-thread workgroup of another batch (the level solvers) never finds its sixteen
-// slots on one CU and waits for the launch to end; the HBM stream itself needs a fraction of the slots (sixteen 16-byte loads per
-// lane in flight).
+// The kernel: grid (tile groups, images)
 template <typename T, int NOC, int LV, bool FAST, int SRCC = NOC>
 __global__ __launch_bounds__(256) void pyr_base_kernel(
     const T *__restrict__ frames0, const T *__restrict__ frames1, int n_per_src, long frame_stride,
     int w_org, int h_org, int left, int top, int Wp, int Hp,
     float *__restrict__ dst0, float *__restrict__ dst1, long dst_stride, int tw, int ps,
-    int coef0 = 0, int coef2 = 0, int groups = 0)
+    int coef0 = 0, int coef2 = 0)
 {
   const WgId wg = xcd_local_wg();            // image k (pair k % n) on XCD k % 8, where pyr_finish and the per-pair kernels run
-  if (groups <= (int)gridDim.x) {
-    pyr_base_tiles<T, NOC, LV, FAST, SRCC>(frames0, frames1, n_per_src, frame_stride, w_org, h_org, left, top, Wp, Hp, dst0, dst1, dst_stride, tw, ps, coef0, coef2, wg.x, wg.y);
-    return;
-  }
-  for (int x = wg.x; x < groups; x += (int)gridDim.x) {
-    pyr_base_tiles<T, NOC, LV, FAST, SRCC>(frames0, frames1, n_per_src, frame_stride, w_org, h_org, left, top, Wp, Hp, dst0, dst1, dst_stride, tw, ps, coef0, coef2, x, wg.y);
-    asm volatile("" ::: "memory");             // (the wave-private LDS slabs of one group's hand-over are not reordered with the next group's)
-  }
+  pyr_base_tiles<T, NOC, LV, FAST, SRCC>(frames0, frames1, n_per_src, frame_stride, w_org, h_org, left, top, Wp, Hp, dst0, dst1, dst_stride, tw, ps, coef0, coef2, wg.x, wg.y);
 }
 
 // level l (padded buffer, interior valid) -> level l+1 interior

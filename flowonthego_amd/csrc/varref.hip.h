@@ -157,35 +157,6 @@ __device__ __forceinline__ void deriv2_pixel(const VrArgs &a, int pair, int i, i
   }
 }
 
-template <int NOC>
-__global__ __launch_bounds__(256) void vr_prep_kernel(VrArgs a, const float *__restrict__ I0, const float *__restrict__ I1,
-                                                      long img_stride, int tw, int pad,
-                                                      const float *__restrict__ flow, long flow_stride)
-{
-  const WgId wg = xcd_local_wg();
-  const int idx = wg.x * blockDim.x + threadIdx.x;
-  if (idx >= a.w * a.h) return;
-  prep_pixel<NOC>(a, wg.y, idx % a.w, idx / a.w, I0, I1, img_stride, tw, pad, flow, flow_stride);
-}
-
-template <int NOC>
-__global__ __launch_bounds__(256) void vr_deriv1_kernel(VrArgs a)
-{
-  const WgId wg = xcd_local_wg();
-  const int idx = wg.x * blockDim.x + threadIdx.x;
-  if (idx >= a.w * a.h) return;
-  deriv1_pixel<NOC>(a, wg.y, idx % a.w, idx / a.w);
-}
-
-template <int NOC>
-__global__ __launch_bounds__(256) void vr_deriv2_kernel(VrArgs a)
-{
-  const WgId wg = xcd_local_wg();
-  const int idx = wg.x * blockDim.x + threadIdx.x;
-  if (idx >= a.w * a.h) return;
-  deriv2_pixel<NOC>(a, wg.y, idx % a.w, idx / a.w);
-}
-
 // smoothness weight from the 3x3 cross of (uu,vv): compute_smoothness first half (opticalflow_aux.c:126-139);
 // 3-tap {-0.5,-0,0.5} with the border rows of convolve_vert_fast_3 / replicate columns of convolve_horiz_fast_3
 // (image.c:376-399,436-464).  l,c,r = left/centre/right, t,b = top/bottom (t or b unused on the border rows).

@@ -178,8 +178,14 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
     if (threadIdx.x == 0) {
       const int pub = tx + FOTG_LP_DW >= ntx ? 0x3ffffff0 : x0 + FOTG_LP_DW * MW - 1 + y0;
       __hip_atomic_store(myprog, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (q.stamps && tx / FOTG_LP_DW < 5) q.stamps[(long)ticket * 8 + 3 + tx / FOTG_LP_DW] = wall_clock64();
+      if (q.stamps && tx / FOTG_LP_DW < 4) q.stamps[(long)ticket * 8 + 3 + tx / FOTG_LP_DW] = wall_clock64();
     }
+  }
+  if (q.stamps && threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    q.stamps[(long)ticket * 8 + 7] = ((long long)(xcc & 0xf) << 60) | ((long long)(hw & 0xffff) << 44);
   }
 }
 
@@ -361,6 +367,7 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
       seen_dat = 0x3fffffff;
     }
   };
+  long long nblock = 0;                       // diagnosis (stamps): waits in which the wave had to poll for itself (total | own | below | top | data term: 6 bits each from bit 8)
   struct Stage { float4 c1[2]; float4 rb; float2 top; };
   auto load = [&](Stage &st, unsigned oc, unsigned oi, unsigned ot) {
     st.c1[0] = ld_c(c1o, oc); st.c1[1] = ld_c(c1o16, oc);
@@ -395,7 +402,10 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
     seen_bel = h1 > seen_bel ? h1 : seen_bel;
     seen_top = h2 > seen_top ? h2 : seen_top;
     seen_dat = h3 > seen_dat ? h3 : seen_dat;
-    if (seen_own < need_in_of(d) || seen_bel < need_in_of(d) || seen_top < need_top_of(d) || seen_dat < need_dat_of(d)) ensure_blocking(d);
+    if (seen_own < need_in_of(d) || seen_bel < need_in_of(d) || seen_top < need_top_of(d) || seen_dat < need_dat_of(d)) {
+      if (q.stamps) nblock += 1 + ((seen_own < need_in_of(d)) << 8) + ((seen_bel < need_in_of(d)) << 14) + ((seen_top < need_top_of(d)) << 20) + ((long long)(seen_dat < need_dat_of(d)) << 26);
+      ensure_blocking(d);
+    }
   };
   Stage ring[P];
 #pragma unroll
@@ -466,6 +476,12 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
   for (; s0 + U - 1 + P <= S - 2; s0 += U) trip(s0, std::true_type());
   for (; s0 < T; s0 += U) trip(s0, std::false_type());
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (q.stamps && lane == 0) {                 // diagnosis: where the role ran (XCC, HW_ID) and how often it had to poll for itself
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    q.stamps[(long)ticket * 8 + 7] = ((long long)(xcc & 0xf) << 60) | ((long long)(hw & 0xffff) << 44) | (nblock & 0xfffffffffffll);
+  }
 }
 
 template <int NOC, int P, bool FMA>

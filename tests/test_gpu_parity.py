@@ -490,22 +490,6 @@ def test_tall_level_with_more_than_four_sweeps():
     assert F.lib().fotg_ctx_counter(ofc._h, b"tile_timeouts") == 0
 
 
-def test_plane_at_a_time_setup_stages(alley, monkeypatch):
-    """FOTG_VR_SETUP=0: warp, first and second derivatives as three launches through global memory instead of the tiled
-    single launch (levels that are not refined on chip): same planes, same flow"""
-    F, OFClass, VarRefClass, O = _mods()
-    monkeypatch.setenv("FOTG_VR_SETUP", "0")
-    monkeypatch.setenv("FOTG_VR_PATH", "2")                  # no on-chip levels: every level takes the unfused sequence
-    for case, op_point in (("alley", 2), ("synth_rgb", 2), ("synth_odd", 3)):
-        f0, f1, noc = frames(case, alley)
-        h, w = f0.shape[:2]
-        op = F.operating_point(op_point, w, noc)
-        ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
-        out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
-        p = oracle_params(O, op)
-        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
-
-
 @pytest.mark.parametrize("first_data", ["1", "0"])
 def test_first_data_term_in_the_setup_launch(first_data, alley, monkeypatch):
     """levels refined by separate launches (FOTG_VR_PATH=2: every level): the set-up launch also builds the system of the first
@@ -524,19 +508,28 @@ def test_first_data_term_in_the_setup_launch(first_data, alley, monkeypatch):
         assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
 
 
-def test_fused_level_system_in_global_memory(alley, monkeypatch):
-    """the on-chip levels keep the linear system in LDS when it fits; FOTG_VR_CLDS=0 forces the variant that streams it
-    through global memory (what larger levels use): same bits"""
+def test_default_dispatch_reaches_every_kept_solver_variant():
+    """every solver variant left in the library is what SOME default configuration runs (no switch set) -- the
+    geometries are named here and the library's launch counters prove the variant ran; all == the oracle.
+      * fused per-level kernel with the system in GLOBAL memory: a wide, short level whose skewed system does not fit LDS beside
+        (du,dv) -- 100 x 30 (a 1600 x 480 frame at scale 4): (w + h) x h x 32 B = 133 KB;
+      * vr_sor_pipe_kernel ((du,dv) resident in LDS, system streamed): levels of <= 64 rows with more than 3 000 pixels, too large
+        for the fused kernel -- 120 x 60 (a 1920 x 960 frame at scale 4);
+      * vr_sor_stream_kernel: levels of 65..96 rows -- 120 x 68 (1080p at scale 4, the headline);
+      * tile pipeline / level pipeline: levels of more than 96 rows (the 4K quality preset) -- 240 x 136 here."""
     F, OFClass, _, O = _mods()
-    monkeypatch.setenv("FOTG_VR_CLDS", "0")
-    for case, op_point in (("alley", 2), ("synth_rgb", 2)):
-        f0, f1, noc = frames(case, alley)
-        h, w = f0.shape[:2]
-        op = F.operating_point(op_point, w, noc)
+    L = F.lib()
+    for (w, h, sc_l, sc_f, counter) in ((1600, 480, 4, 5, b"fused_cglobal"), (1920, 960, 4, 5, b"sor_pipe"), (1920, 1080, 4, 5, b"sor_stream"), (960, 544, 2, 3, b"level_pipe")):
+        op = F.operating_point(2, w, 1)
+        op.finest_scale, op.coarsest_scale, op.grad_descent_iter = sc_l, sc_f, 6
         ofc = OFClass(op, F.img_params(width=w, height=h, padding=op.patch_size))
+        f0, f1 = synth_pair(h, w, seed=61)
+        before = L.fotg_debug_counter(counter)
         out = ofc.calc(dev(f0), dev(f1)).cpu().numpy()
+        assert L.fotg_debug_counter(counter) > before, counter
         p = oracle_params(O, op)
-        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), case
+        assert np.array_equal(out, O.flow(O.pad_frame(f0, p.sc_f), O.pad_frame(f1, p.sc_f), p, 0)), (w, h)
+        ofc.close()
 
 
 def test_lk_partial_waves(alley):
@@ -745,9 +738,9 @@ def test_random_sizes_sweep():
         ofc.close()
 
 
-SWITCHES = {"FOTG_VR_PATH": ["0", "1", "2"], "FOTG_VR_STREAM": ["0", "1"], "FOTG_VR_CLDS": ["0", "1"], "FOTG_VR_SETUP": ["0", "1"],
-            "FOTG_VR_LEVELPIPE": ["0", "1"], "FOTG_VR_FIRST_DATA": ["0", "1"], "FOTG_VR_FUSED_NT": ["512", "1024"], "FOTG_PYR_SPLIT": ["1", "3", "16"],
-            "FOTG_PYR_PERSIST": ["0", "2"], "FOTG_LK_SHW": ["-1", "0", "1"], "FOTG_LK_LPP": ["0", "8", "16"], "FOTG_LK_LPP_MIN_WAVES": ["1", "2048"]}
+SWITCHES = {"FOTG_VR_PATH": ["0", "1", "2"], "FOTG_VR_STREAM": ["0", "1"],
+            "FOTG_VR_LEVELPIPE": ["0", "1"], "FOTG_VR_FIRST_DATA": ["0", "1"], "FOTG_PYR_SPLIT": ["1", "3", "16"],
+            "FOTG_LK_SHW": ["-1", "0", "1"], "FOTG_LK_LPP": ["0", "8", "16"], "FOTG_LK_LPP_MIN_WAVES": ["1", "2048"], "FOTG_LK_BANDED": ["0", "1"]}
 
 
 def test_random_switch_sweep(monkeypatch):
