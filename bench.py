@@ -273,7 +273,7 @@ def roofline_lk(ofc, batch, stage_ms):
     return {"bound": "valu", "kernel": "fotg::lk_kernel<8,1,false,true,%s> (level %d: %d patches x %d evaluations x 64 px per pair)" % ("true,8" if lpp8 else "false,16", lvl, nop, evals),
             "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "useful_flops_per_launch": flops,
             "ms_per_launch": ms, "share_of_step": sum(v for k, v in stage_ms.items() if k.startswith("lk[")) / sum(stage_ms.values()),
-            "note": "useful flops only; the instruction stream is ~3-4x that (profiles/r05_pmc_valu.json: 330 VALU wave-instructions per EIGHT-patch "
+            "note": "useful flops only; the instruction stream is ~3-4x that (profiles/r06_pmc_valu.json: 330 VALU wave-instructions per EIGHT-patch "
                     "iteration with eight lanes per patch, 234 per four-patch iteration with sixteen); the launch retires one VALU wave-instruction per ~4.3 cycles and SIMD, where the hardware issues plain f32 / int adds "
                     "at 2.3 and selects, compares, DPP, conversions, packed f32 at 4.1-4.4 (profiles/r03_valu_issue_probe.json): about three quarters "
                     "of the issue rate of its mix"}
@@ -339,9 +339,9 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=
                          "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "useful_flops_per_launch": flops,
                          "ms_per_launch": ms, "share_of_pair": lk_all / sum(st.values()),
                          "note": ("useful flops only (16 per pixel-evaluation); tolerance mode: 91 VALU wave-instructions per four-patch iteration "
-                                  "(profiles/r05_pmc_valu.json), VALU busy 87 %") if fast else
+                                  "(profiles/r06_pmc_valu.json), VALU busy 87 %") if fast else
                                  ("useful flops only (16 per pixel-evaluation); the kernel is bound by the issue rate of its instruction stream (263 VALU "
-                                  "wave-instructions per four-patch iteration, profiles/r05_pmc_valu.json, retired at one per ~4.8 cycles and SIMD; five instead of "
+                                  "wave-instructions per four-patch iteration, profiles/r06_pmc_valu.json, retired at one per ~4.8 cycles and SIMD; five instead of "
                                   "three waves per SIMD do not speed it up: docs/EXPERIMENTS.md)")}]
     # one sor_coupled call of the finest level through the tile pipeline
     try:
@@ -491,36 +491,42 @@ def cpu_baseline(I0, I1, budget_s=12.0):
     single = n1 / (time.perf_counter() - t0)
     # per-stage split of ONE pair on one thread, the oracle's stage entry points in the order of kroeger/oflow.cpp:184-337 (the
     # reference prints the same split as "TIME (Sc: ..)", oflow.cpp:303); ms per pair, comparable with stage_ms / batch
+    # (three passes over the same pair, the fastest time of every stage: a single pass measured the first touch of the stage objects'
+    # memory -- 50 ms instead of 7.7 for the flow of one pair on one of the driver's boxes)
     st = {}
-
-    def lap(name, t):
-        st[name] = st.get(name, 0.0) + (time.perf_counter() - t) * 1e3
-
+    npatch = {}
     a0, b0 = pair(0)
     pa, pb = O.pad_frame(a0, p.sc_f), O.pad_frame(b0, p.sc_f)
-    t = time.perf_counter()
-    for fr in (pa, pb):                                   # the C call alone (the Pyramid wrapper below also copies every level)
-        O.lib().dis_pyramid_free(O.lib().dis_pyramid_build(O.P(fr), fr.shape[1], fr.shape[0], 1, p.sc_f, p.ps))
-    lap("pyramid(I0,I1)", t)
-    P0, P1 = O.Pyramid(pa, p.sc_f, p.ps), O.Pyramid(pb, p.sc_f, p.ps)
-    prev = None
-    npatch = {}
-    for sl in range(p.sc_f, p.sc_l - 1, -1):
-        lw, lh = P0.level_wh(sl)
+    for _pass in range(3):
+        cur = {}
+
+        def lap(name, t):
+            cur[name] = cur.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+
         t = time.perf_counter()
-        g = O.Grid(lw, lh, sl, p)
-        npatch[sl] = g.nop
-        g.init(P0.im[sl], P0.dx[sl], P0.dy[sl])
-        if prev is not None:
-            g.init_from_coarser(prev)
-        g.optimize(P1.im[sl])
-        lap("lk[%d]" % sl, t)
-        t = time.perf_counter()
-        fl = g.aggregate()
-        lap("densify[%d]" % sl, t)
-        t = time.perf_counter()
-        prev = O.varref(P0.im[sl], P1.im[sl], lw, lh, sl, p, fl)
-        lap("varref[%d]" % sl, t)
+        for fr in (pa, pb):                                   # the C call alone (the Pyramid wrapper below also copies every level)
+            O.lib().dis_pyramid_free(O.lib().dis_pyramid_build(O.P(fr), fr.shape[1], fr.shape[0], 1, p.sc_f, p.ps))
+        lap("pyramid(I0,I1)", t)
+        P0, P1 = O.Pyramid(pa, p.sc_f, p.ps), O.Pyramid(pb, p.sc_f, p.ps)
+        prev = None
+        for sl in range(p.sc_f, p.sc_l - 1, -1):
+            lw, lh = P0.level_wh(sl)
+            t = time.perf_counter()
+            g = O.Grid(lw, lh, sl, p)
+            npatch[sl] = g.nop
+            g.init(P0.im[sl], P0.dx[sl], P0.dy[sl])
+            if prev is not None:
+                g.init_from_coarser(prev)
+            g.optimize(P1.im[sl])
+            lap("lk[%d]" % sl, t)
+            t = time.perf_counter()
+            fl = g.aggregate()
+            lap("densify[%d]" % sl, t)
+            t = time.perf_counter()
+            prev = O.varref(P0.im[sl], P1.im[sl], lw, lh, sl, p, fl)
+            lap("varref[%d]" % sl, t)
+        for k, v in cur.items():
+            st[k] = min(st.get(k, v), v)
     # all cores: dis_flow_many -- pthreads inside the C library, one pair per thread at a time, thread-private block caches (no
     # allocation per pair after a thread's first), every thread runs one untimed pair first.  Threads are bounded by memory:
     # a worker holds both pyramids of its pair (~90 MB at 1080p).

@@ -24,6 +24,8 @@ python3 tools/make_valu_profile.py $OUT/valu $OUT/valu4k $TAG $OUT/valuf $OUT/va
 python3 tools/make_4k_profiles.py $OUT/f4k $OUT/w4k $OUT/k4f $OUT/k4f.log $TAG >> $OUT/summary_valu.txt 2>&1
 python3 tools/make_profiles.py $OUT/stats $OUT/fetch $OUT/write $TAG $OUT/k4 $OUT/k4.log $OUT/fl4 > $OUT/summary.txt 2>&1
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_err.log
-cp $OUT/bench_line.json profiles/${TAG}_bench_line.json
+cp $OUT/bench_line.json profiles/${TAG}_bench_line.json              # the ONE short stdout line the driver parses
+cp gpurun_out/bench_detail.json profiles/${TAG}_bench_detail.json     # everything else (stage tables, rooflines list, notes)
+cp profiles/${TAG}_bench_detail.json $OUT/
 cp profiles/${TAG}_* $OUT/ 2>/dev/null
 tail -20 $OUT/summary.txt; tail -2 $OUT/k4.log
