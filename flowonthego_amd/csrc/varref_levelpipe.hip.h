@@ -116,7 +116,10 @@ __device__ __forceinline__ void lp_data_role(const VrArgs &a, const TileArgs &g,
           if (seen0 < need) seen0 = lp_poll(p0);
           if (seen1 < need) seen1 = lp_poll(p1);
           if (seen0 >= need && seen1 >= need) break;
-          __builtin_amdgcn_s_sleep(4);
+#ifndef FOTG_LP_DSLEEP
+#define FOTG_LP_DSLEEP 4
+#endif
+          __builtin_amdgcn_s_sleep(FOTG_LP_DSLEEP);
           if (++spins >= (1 << 20)) { if ((threadIdx.x & 63) == 0) lp_report_timeout(g); seen0 = seen1 = 0x3fffffff; }
         }
       }
@@ -238,14 +241,17 @@ __device__ __forceinline__ void lp_tile_role(const VrArgs &a, const TileArgs &g,
     typedef __attribute__((address_space(3))) void lvoid;
     for (int k = 0; k < NBAR; ++k) {
       asm volatile("s_barrier" ::: "memory");
-      if (lane == 0) {
-        if (prog_own) __builtin_amdgcn_global_load_lds((gvoid *)prog_own, (lvoid *)&seen_lds[0], 4, 0, 16);      // (aux 16 = sc1)
-        if (prog_bel) __builtin_amdgcn_global_load_lds((gvoid *)prog_bel, (lvoid *)&seen_lds[1], 4, 0, 16);
-        if (prog_top) __builtin_amdgcn_global_load_lds((gvoid *)prog_top, (lvoid *)&seen_lds[2], 4, 0, 16);
+#ifndef FOTG_LP_POLL_EVERY
+#define FOTG_LP_POLL_EVERY 1
+#endif
+      if (lane == 0 && (k % FOTG_LP_POLL_EVERY) == 0) {
+        if (prog_own) __builtin_amdgcn_global_load_lds((gvoid *)prog_own, lds_addr_of(&seen_lds[0]), 4, 0, 16);      // (aux 16 = sc1)
+        if (prog_bel) __builtin_amdgcn_global_load_lds((gvoid *)prog_bel, lds_addr_of(&seen_lds[1]), 4, 0, 16);
+        if (prog_top) __builtin_amdgcn_global_load_lds((gvoid *)prog_top, lds_addr_of(&seen_lds[2]), 4, 0, 16);
       }
       if (wdata) {
         // the rows' words, one lane each; the minimum of what has landed so far goes to seen_lds[3] (a stale view only delays)
-        if (lane < nty * FOTG_LP_DW) __builtin_amdgcn_global_load_lds((gvoid *)(dpw + 32 * lane), (lvoid *)&dp_lds[0], 4, 0, 16);
+        if (lane < nty * FOTG_LP_DW) __builtin_amdgcn_global_load_lds((gvoid *)(dpw + 32 * lane), lds_addr_of(&dp_lds[0]), 4, 0, 16);
         if (lane == 0) {
           int m = 0x3fffffff;
 #pragma unroll

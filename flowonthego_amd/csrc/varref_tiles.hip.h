@@ -73,6 +73,11 @@ __device__ __forceinline__ void st_sc1_f2(float2 *p, float2 v)
 {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The LDS address of a __shared__ object for a direct-to-LDS load: the low 32 bits of its generic address.  (The address-space cast
+// `(address_space(3) void *)&word` carries a null check that this compiler version sometimes lowers to an illegal VALU compare with
+// the aperture register -- "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base" -- depending on the code around it.)
+typedef __attribute__((address_space(3))) void fotg_lds_void;
+__device__ __forceinline__ fotg_lds_void *lds_addr_of(const void *p) { return (fotg_lds_void *)(unsigned)(unsigned long long)p; }
 // lane L reads src of lane L-1; lane 0 gets `old`
 __device__ __forceinline__ float dpp_wave_shr1_old(float old, float src)
 {
@@ -142,9 +147,9 @@ __global__ __launch_bounds__(FOTG_TILE_THREADS) __attribute__((amdgpu_waves_per_
     for (int k = 0; k < NBAR; ++k) {
       asm volatile("s_barrier" ::: "memory");
       if (lane == 0) {
-        if (prog_own) __builtin_amdgcn_global_load_lds((gvoid *)prog_own, (lvoid *)&seen_lds[0], 4, 0, 16);      // (aux 16 = sc1)
-        if (prog_bel) __builtin_amdgcn_global_load_lds((gvoid *)prog_bel, (lvoid *)&seen_lds[1], 4, 0, 16);
-        if (prog_top) __builtin_amdgcn_global_load_lds((gvoid *)prog_top, (lvoid *)&seen_lds[2], 4, 0, 16);
+        if (prog_own) __builtin_amdgcn_global_load_lds((gvoid *)prog_own, lds_addr_of(&seen_lds[0]), 4, 0, 16);      // (aux 16 = sc1)
+        if (prog_bel) __builtin_amdgcn_global_load_lds((gvoid *)prog_bel, lds_addr_of(&seen_lds[1]), 4, 0, 16);
+        if (prog_top) __builtin_amdgcn_global_load_lds((gvoid *)prog_top, lds_addr_of(&seen_lds[2]), 4, 0, 16);
       }
       asm volatile("s_waitcnt vmcnt(9)" ::: "memory");            // at most three intervals' polls in flight
     }
