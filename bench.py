@@ -68,6 +68,7 @@ def latest_profile(suffix):
 
 TRAFFIC_FILE = latest_profile("pmc_traffic.json") or "r02_pmc_traffic.json"
 TRAFFIC_FILE_4K = latest_profile("4k_pmc_traffic.json")
+TRAFFIC_FILE_4K_TILES = latest_profile("4k_tiles_pmc_traffic.json")      # the same passes with FOTG_VR_LEVELPIPE=0 (one vr_sor_tile_kernel launch per call)
 TRAFFIC_NOTE = ("L2-MISS bytes per launch (requests that left an XCD's L2: Infinity-Cache hits are INCLUDED, so this is an upper bound of the HBM "
                 "traffic) from profiles/%s: separate rocprofv3 --pmc passes of this command, bytes = 2 x FETCH_SIZE + WRITE_SIZE -- the x 2 is the guide's "
                 "gfx950 correction, established for 16-byte-per-lane streaming reads (pyr_base_kernel); kernels that read with dword loads (lk, densify, "
@@ -355,13 +356,16 @@ def config_4k_op4(F, OFClass, lib, local, dev, stream_ptr, fast=False, ref_flow=
         inner = lvl + 1
         traffic4k, src4k = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE_4K)) as f:
-                tk = json.load(f)["kernels"]
+            tk = {}
+            for tf in (TRAFFIC_FILE_4K, TRAFFIC_FILE_4K_TILES):
+                if tf:
+                    with open(os.path.join(ROOT, "profiles", tf)) as f:
+                        tk.update(json.load(f)["kernels"])
             cand = [v["hbm_bytes_per_launch_corrected"] for k, v in tk.items() if "vr_sor_tile_kernel" in k]
             if cand:
                 traffic4k = int(max(cand))                       # (the largest tile launch = the finest level)
                 src4k = ("L2-miss bytes per launch (Infinity-Cache hits included) from profiles/%s (separate rocprofv3 --pmc passes of "
-                         "tools/time_4k_op4.py; bytes = 2 x FETCH_SIZE + WRITE_SIZE) -- NOT measured in this run" % TRAFFIC_FILE_4K)
+                         "tools/time_4k_op4.py with FOTG_VR_LEVELPIPE=0; bytes = 2 x FETCH_SIZE + WRITE_SIZE) -- NOT measured in this run" % (TRAFFIC_FILE_4K_TILES or TRAFFIC_FILE_4K))
         except Exception:
             pass
         res["rooflines"].append({"bound": "hbm", "bound_note": "nearest roof the contract names; the kernel is a pipeline of dependency chains (bound_by)",
