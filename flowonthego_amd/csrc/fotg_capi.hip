@@ -1048,20 +1048,18 @@ static int varref_impl(fotg_ctx *c, int l, int n, const float *I0, const float *
                          c->p.tv_solverit >= 2 && c->p.tv_solverit <= 4 && ntr <= c->lp_ntr &&
                          lp_tile_words(n, c->tile_nbs) + lp_data_words(n, ntr) <= c->sync_total;
   if (levelpipe) { az.zsync_n = (int)(lp_tile_words(n, c->tile_nbs) + lp_data_words(n, ntr)); }
-  bool merged_first = false;
+  // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (refine_variational.cpp:185-186) and builds the
+  // system of the first inner iteration (unless tune.vr_first_data = 0: a data-term launch of its own)
+  const bool merged_first = c->tune.vr_first_data && inner > 0;
   {
-  // warp + first + second derivatives in one tiled launch, which also zeroes (du,dv) (:185-186)
-  // (the launch also builds the system of the first inner iteration unless tune.vr_first_data = 0)
-  merged_first = c->tune.vr_first_data && inner > 0;
-  dim3 gs_(((g.w + 31) / 32) * ((g.h + 7) / 8), n);
-  if ((n & 7) != 0 && gs_.x >= 256 && c->tune.lk_banded) { az.nwg = (int)gs_.x; gs_.x = (gs_.x + 7) & ~7u; }     // XCD-banded tiles (FOTG_LK_BANDED=0: plain order)
-  if (c->p.fast_math)
-    vr_setup_kernel<NOC, 2, true><<<gs_, 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
-                                                       merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
-  else
-    vr_setup_kernel<NOC><<<gs_, 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1,
-                                              merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
-  LAUNCHCHK();
+    dim3 gs_(((g.w + 31) / 32) * ((g.h + 7) / 8), n);
+    // (1..7 pairs, a launch that spans the chip: XCD-banded tiles like the LK launches; FOTG_LK_BANDED=0: plain order)
+    if ((n & 7) != 0 && gs_.x >= 256 && c->tune.lk_banded) { az.nwg = (int)gs_.x; gs_.x = (gs_.x + 7) & ~7u; }
+    if (c->p.fast_math)
+      vr_setup_kernel<NOC, 2, true><<<gs_, 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1, merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
+    else
+      vr_setup_kernel<NOC><<<gs_, 256, 0, s>>>(az, I0, I1, img_stride, g.tw, c->ps, flow, fs, 1, merged_first ? 1 : 0, quarter_alpha, half_delta_over3, half_gamma_over3);
+    LAUNCHCHK();
   }
   if (levelpipe) {
     TileArgs tg;
