@@ -44,6 +44,16 @@ class FlowPipeline {
     fotgCheck(fotg_pipe_submit_u8(pipe, n, I0, I1, initflow, outflow_dev, after_stream, &ticket), "FlowPipeline::submit_u8");
     return ticket;
   }
+  // frames / outflow in staging buffers that are recycled behind a device-side wait: a flagged stall of this batch is reported by
+  // wait_host() / synchronize() instead of being recomputed from buffers that may be gone (fotg.h: RECOMPUTE CONTRACT)
+  long submit_no_recompute(int n, const void *I0, const void *I1, bool u8, const float *initflow, float *outflow_dev, void *after_stream = nullptr)
+  {
+    long ticket = -1;
+    fotgCheck(fotg_pipe_submit_ex(pipe, n, I0, I1, u8 ? 1 : 0, initflow, outflow_dev, after_stream, FOTG_SUBMIT_NO_RECOMPUTE, &ticket), "FlowPipeline::submit_no_recompute");
+    return ticket;
+  }
+  // (after wait(ticket, stream) the waiting stream owns the result: the buffers of that batch may be freed or reused behind it, and the
+  // pipe will not recompute into them)
   void wait(long ticket, void *stream = nullptr) { fotgCheck(fotg_pipe_wait(pipe, ticket, stream, 0), "FlowPipeline::wait"); }
   void wait_host(long ticket) { fotgCheck(fotg_pipe_wait(pipe, ticket, nullptr, 1), "FlowPipeline::wait_host"); }
   void synchronize() { fotgCheck(fotg_pipe_sync(pipe), "FlowPipeline::synchronize"); }
